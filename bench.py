@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the NV12 luma equalizeHist hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (mi_equalize_hist_nv12_batch_dev: histogram -> CDF/LUT ->
+LUT apply + UV fill) over one batch of `--batch` synthetic 3840x2160 NV12 frames that are already
+resident in HBM (BASELINE.json configs[1], batched so the working set exceeds the 256 MiB
+Infinity Cache).  Frames are sharded one batch per GPU, no data-path collective (weak scaling);
+value = frames all ranks processed / max-over-ranks time.
+
+The JSON line also carries
+  roofline     -- the LUT-apply kernel's algorithmic bytes per launch / its average launch duration
+                  (HIP events recorded by the library on the launch stream inside the timed region)
+                  against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (a port of OpenCV 4.4's arithmetic, see oracle/) timed on this
+                  host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+The oracle is used here only for that leg and for a one-frame parity spot check.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "opencv-opencl_amd" / "python"))
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_MEASURED_COPY_GBS = 6290.0  # same guide: float4 copy ceiling
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--dist", default="D2", help="Y distribution D1..D5 (mi_lumaeq.synth)")
+    ap.add_argument("--uv", default="fill128", choices=["fill128", "copy"])
+    ap.add_argument("--op", default="equalize", choices=["equalize", "clahe"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, w, h):
+    """CPU oracle (kind 'port') on a bounded sample: whole NV12 frames, same op, all host threads."""
+    import numpy as np
+    import oracle
+    from mi_lumaeq import synth
+    threads = oracle.set_threads(0)
+    nfr = 6
+    frames = [synth.nv12_frame(w, h, args.dist, 1000 + k) for k in range(nfr)]
+    uv_mode = 1 if args.uv == "copy" else 0
+    op = 1 if args.op == "clahe" else 0
+    for k in range(2):
+        oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=op)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        oracle.nv12_frame(frames[done % nfr], w, h, uv_mode=uv_mode, op=op)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or done >= 2000:
+            break
+    multi = done / el
+    # single-thread figure on a shorter sample
+    oracle.set_threads(1)
+    oracle.nv12_frame(frames[0], w, h, uv_mode=uv_mode, op=op)
+    d1, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < min(4.0, args.cpu_seconds / 3) and d1 < 500:
+        oracle.nv12_frame(frames[d1 % nfr], w, h, uv_mode=uv_mode, op=op)
+        d1 += 1
+    single = d1 / (time.perf_counter() - t1)
+    oracle.set_threads(threads)
+    return {"value": round(multi, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{done} x {w}x{h} NV12 frames ({args.dist}, {args.op}, uv={args.uv}) in {el:.1f} s, "
+                      f"OpenMP row/tile-striped CPU restatement of OpenCV 4.4 (oracle/lumaeq_oracle.c), "
+                      f"host has {os.cpu_count()} logical CPUs",
+            "value_1thread": round(single, 2)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import mi_lumaeq
+    from mi_lumaeq import synth, shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs HIP devices (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("for --gpus N>1 launch with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    w, h, B = args.width, args.height, args.batch
+    ysz = w * h
+    fbytes = ysz + ysz // 2
+    uv_mode = mi_lumaeq.UV_COPY if args.uv == "copy" else mi_lumaeq.UV_FILL128
+    ctx = mi_lumaeq.Context(local_rank)
+
+    # this rank's shard: global frame indices k with k mod world == rank (no collective on the data path)
+    my_frames = shard.frames_for_rank(B * world, rank, world)
+    assert len(my_frames) == B
+    d_in = synth.nv12_batch_torch(w, h, B, args.dist, device, seed=0x5EED0000 + rank)
+    d_out = torch.empty_like(d_in)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        if args.op == "equalize":
+            ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, B, uv_mode, stream=stream)
+        else:
+            ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, uv_mode, 2.0, 8, 8, stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_read(reset=True)
+    ctx.set_profiling(True)          # HIP events around every kernel, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    prof = ctx.profile_read(reset=True)
+    elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None)
+
+    # parity spot check of the measured configuration (one frame, rank 0) -- checker only
+    parity = None
+    if rank == 0:
+        import numpy as np
+        import oracle
+        got = d_out[B // 2].cpu().numpy()
+        want = oracle.nv12_frame(d_in[B // 2].cpu().numpy(), w, h, uv_mode=uv_mode, op=1 if args.op == "clahe" else 0,
+                                 clip_limit=2.0, tiles_x=8, tiles_y=8)
+        parity = bool(np.array_equal(got, want))
+        if not parity:
+            raise SystemExit("PARITY FAILURE: GPU output differs from the oracle; refusing to report a number")
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_frames = B * world * args.steps
+    fps = total_frames / elapsed
+    ms_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel -------------------------------------------------------
+    uv_bytes = (ysz // 2) * (2 if args.uv == "copy" else 1)
+    if args.op == "equalize":
+        dom = "lut_apply_kernel"
+        alg_bytes = (2 * ysz + uv_bytes) * B          # read Y + write Y (+ UV fill/copy fused in the same launch)
+    else:
+        dom = "clahe_interp_kernel"
+        alg_bytes = (2 * ysz + uv_bytes) * B
+    kinfo = {}
+    per_kernel_alg = {"hist_partial_kernel": ysz * B, "lut_apply_kernel": (2 * ysz + uv_bytes) * B,
+                      "tile_hist_kernel": ysz * B, "clahe_interp_kernel": (2 * ysz + uv_bytes) * B}
+    for name, p in prof.items():
+        if p["launches"]:
+            avg_ms = p["total_ms"] / p["launches"]
+            e = {"avg_ms": round(avg_ms, 5), "launches": p["launches"]}
+            if name in per_kernel_alg:
+                e["alg_GBs"] = round(per_kernel_alg[name] / (avg_ms * 1e-3) / 1e9, 1)
+            kinfo[name] = e
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text()).get(f"{dom}:{args.op}:{w}x{h}x{B}:{args.uv}")
+        except Exception:
+            traffic = None
+    roofline = None
+    if dom in kinfo:
+        achieved = alg_bytes / (kinfo[dom]["avg_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kinfo[dom]["avg_ms"],
+                    "frac_of_measured_copy_ceiling": round(achieved / HBM_MEASURED_COPY_GBS, 4)}
+
+    out = {
+        "metric": "frames/sec, 3840x2160 NV12 Y equalizeHist" if (args.op == "equalize" and (w, h) == (3840, 2160))
+                  else f"frames/sec, {w}x{h} NV12 Y {args.op}",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4), "ms_per_frame": round(elapsed / total_frames * 1e3 * world, 6),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{B} x {w}x{h} NV12 frames per GPU per step, Y {args.op}"
+                               f"{'' if args.op == 'equalize' else ' 8x8 clip 2.0'} + UV {args.uv}, device-resident "
+                               f"(BASELINE.json configs[1] batched), Y distribution {args.dist}",
+                   "frames_per_gpu_per_step": B, "width": w, "height": h, "uv": args.uv, "op": args.op,
+                   "sharding": f"frame k -> GPU k mod {world}, no collective"},
+        "parity_spot_check": parity,
+        "whole_path_alg_GBs": round((3 * ysz + uv_bytes) * fps / 1e9, 1),
+        "roofline": roofline,
+        "kernels": kinfo,
+    }
+
+    if world == 1 and not args.no_extras:
+        out["extras"] = extras(ctx, args, torch, mi_lumaeq, synth)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, w, h)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extras(ctx, args, torch, mi_lumaeq, synth):
+    """Secondary figures outside the timed region (N=1 only): single-frame latency, device-resident and
+    through the host cv::Mat boundary (PCIe-inclusive; never the headline value), and CLAHE."""
+    import numpy as np
+    w, h = args.width, args.height
+    res = {}
+    frame = synth.nv12_batch_torch(w, h, 1, args.dist, "cuda", seed=99)
+    outb = torch.empty_like(frame)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timeit(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    res["single_frame_dev_equalize_ms"] = round(timeit(
+        lambda: ctx.equalize_hist_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, stream=stream), 200), 4)
+    res["single_frame_dev_clahe8x8_ms"] = round(timeit(
+        lambda: ctx.clahe_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 200), 4)
+    y = frame[0, : w * h].cpu().numpy().reshape(h, w)
+    dst = np.empty_like(y)
+    res["host_mat_equalize_ms_pcie_inclusive"] = round(timeit(lambda: ctx.equalize_hist(y, dst), 20), 3)
+    res["host_mat_clahe8x8_ms_pcie_inclusive"] = round(timeit(lambda: ctx.clahe(y, 2.0, 8, 8, dst), 20), 3)
+    B = min(args.batch, 32)
+    d_in = synth.nv12_batch_torch(w, h, B, args.dist, "cuda", seed=5)
+    d_out = torch.empty_like(d_in)
+    ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 10)
+    res["clahe8x8_batch_frames_per_s"] = round(B / (ms * 1e-3), 1)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/*
+ * mi_lumaeq.h -- C ABI of the MI355X (gfx950) luma histogram-equalization library.
+ *
+ * This is the drop-in boundary for the ONE hot path of kimkimhun3/OpenCV-OpenCL: the call the
+ * reference makes on the CV_8UC1 Y plane of every NV12 frame,
+ *
+ *     cv::equalizeHist(src, dst)                    OpenCVequalHist.cpp:145, nextimprovement.cpp:168,
+ *                                                   AirplanMP4.cpp:90, 1frameMeasure.cpp:44
+ *     cv::createCLAHE(clip, Size(t,t))->apply(..)   clahevideo.cpp:184-195/:497, clahe1frame.cpp:88-93,
+ *                                                   CLAHECompare.cpp:144-150
+ *
+ * and for the accelerator backend the reference wires behind that call,
+ *
+ *     cl::Kernel "equalizeHist_accel"(in, ref, out, rows, cols)
+ *                                                   OpenCLequalHist.cpp:346-365 (host sequence),
+ *                                                   accel.cpp:36-61 (device kernel), 1frameMeasure.cpp:60-87
+ *
+ * Plain C: pointers, sizes, integer status codes.  No exceptions, no STL, no torch / OpenCV types.
+ * The C++ adapter that presents the cv::Mat-in / cv::Mat-out surface on top of it is
+ * opencv-opencl_amd/cxx/mi_cv.hpp; the binding a maintainer of the reference would add is shown
+ * in INTEGRATION.md.
+ *
+ * Threading: every function is safe to call concurrently on DISTINCT contexts (the reference
+ * runs 1..8 worker threads, OpenCVequalHist.cpp:274/:397-402 -> one context per worker).  A
+ * context is internally locked, so sharing one between threads is safe but serialises.
+ *
+ * There is no CPU fallback: every entry point needs a HIP device and returns MI_ERR_NO_DEVICE /
+ * MI_ERR_HIP otherwise.
+ */
+#ifndef MI_LUMAEQ_H_
+#define MI_LUMAEQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_LUMAEQ_VERSION_MAJOR 0
+#define MI_LUMAEQ_VERSION_MINOR 1
+
+typedef enum mi_status {
+    MI_OK = 0,
+    MI_ERR_BAD_ARG = 1,          /* null pointer, negative size, step < width, tiles <= 0 ...        */
+    MI_ERR_UNSUPPORTED = 2,      /* not CV_8UC1-shaped work (the adapter maps this to cv::Exception) */
+    MI_ERR_HIP = 3,              /* a HIP call failed; see mi_ctx_last_hip_error()                   */
+    MI_ERR_OOM = 4,              /* host or device allocation failed                                 */
+    MI_ERR_NO_DEVICE = 5         /* no usable HIP device / device index out of range                 */
+} mi_status;
+
+/* UV handling of whole-NV12-frame entry points:
+ *   MI_UV_FILL128 : memset(out + W*H, 128, W*H/2)      OpenCVequalHist.cpp:160-162, clahevideo.cpp:200-201
+ *   MI_UV_COPY    : memcpy(out + W*H, in + W*H, W*H/2) ColoropenCVCwqualHist.cpp:165, improvement.cpp:163,
+ *                                                      nextimprovement.cpp:160 */
+typedef enum mi_uv_mode { MI_UV_FILL128 = 0, MI_UV_COPY = 1 } mi_uv_mode;
+
+typedef struct mi_ctx mi_ctx;    /* opaque: device id, streams, pinned staging, device scratch */
+
+/* ---- context ------------------------------------------------------------------------------
+ * Replaces the per-worker OpenCL objects of the reference (context/queue/kernel/3 buffers,
+ * OpenCLequalHist.cpp:106-192): scratch is allocated lazily for the largest frame seen and
+ * reused ("allocate once per size", OpenCLequalHist.cpp:175-186). */
+mi_status   mi_ctx_create(int device, mi_ctx** out);
+void        mi_ctx_destroy(mi_ctx* ctx);
+int         mi_ctx_device(const mi_ctx* ctx);
+int         mi_ctx_last_hip_error(const mi_ctx* ctx);      /* raw hipError_t of the last MI_ERR_HIP */
+const char* mi_ctx_last_error_msg(const mi_ctx* ctx);      /* human readable, never NULL           */
+const char* mi_status_str(mi_status s);
+const char* mi_version(void);
+int         mi_device_count(void);                         /* 0 when no HIP device is usable       */
+
+/* ---- host-pointer forms: the cv::Mat boundary -----------------------------------------------
+ * Synchronous: on return dst is fully written in host memory (SURVEY 8b "Semantics to keep").
+ * src/dst are CV_8UC1 planes with row pitch `*_step` >= width (ROI views: clahevideo.cpp:179);
+ * dst may be the same memory as src (in place).  width==0 or height==0 is a no-op (MI_OK).
+ * Replaces  cv::equalizeHist(y_in, y_out)  (OpenCVequalHist.cpp:145) and the whole blocking
+ * write/write/task/read sequence of OpenCLequalHist.cpp:356-365. */
+mi_status mi_equalize_hist_u8(mi_ctx* ctx, const uint8_t* src, size_t src_step,
+                              uint8_t* dst, size_t dst_step, int width, int height);
+
+/* Replaces  clahe->apply(y_in, y_out)  with clahe = cv::createCLAHE(clip_limit, Size(tiles_x, tiles_y))
+ * (clahevideo.cpp:184-195, clahe1frame.cpp:88-93). */
+mi_status mi_clahe_u8(mi_ctx* ctx, const uint8_t* src, size_t src_step,
+                      uint8_t* dst, size_t dst_step, int width, int height,
+                      double clip_limit, int tiles_x, int tiles_y);
+
+/* Whole tightly packed NV12 frame in host memory: Y op + UV fill/copy in one call, writing
+ * straight into the caller's output frame (the zero-copy semantics of nextimprovement.cpp:159-168;
+ * removes the Y clone + memcpy + memset of OpenCVequalHist.cpp:141/:160-162).
+ * in/out hold width*height + width*height/2 bytes; in == out is allowed. */
+mi_status mi_equalize_hist_nv12(mi_ctx* ctx, const uint8_t* in, uint8_t* out,
+                                int width, int height, mi_uv_mode uv_mode);
+mi_status mi_clahe_nv12(mi_ctx* ctx, const uint8_t* in, uint8_t* out, int width, int height,
+                        mi_uv_mode uv_mode, double clip_limit, int tiles_x, int tiles_y);
+
+/* ---- device-resident, batched, stream-ordered forms -------------------------------------------
+ * Pointers are device pointers on the context's device.  `stream` is a hipStream_t passed as
+ * void* (NULL = the context's own stream).  Asynchronous: the call returns after enqueueing.
+ * Frame f of a batch lives at base + f * frame_stride.  These are what a per-GPU worker of the
+ * frame-sharded pipeline (reference analogue: worker pool OpenCVequalHist.cpp:397-402)
+ * calls, and what bench.py measures. */
+mi_status mi_equalize_hist_u8_batch_dev(mi_ctx* ctx,
+                                        const void* d_src, size_t src_step, size_t src_frame_stride,
+                                        void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                        int width, int height, int n_frames, void* stream);
+
+mi_status mi_clahe_u8_batch_dev(mi_ctx* ctx,
+                                const void* d_src, size_t src_step, size_t src_frame_stride,
+                                void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                int width, int height, int n_frames,
+                                double clip_limit, int tiles_x, int tiles_y, void* stream);
+
+/* n_frames tightly packed NV12 frames (frame pitch = W*H + W*H/2 bytes), Y op + UV fill/copy
+ * fused into the same launches. d_in == d_out is allowed. */
+mi_status mi_equalize_hist_nv12_batch_dev(mi_ctx* ctx, const void* d_in, void* d_out,
+                                          int width, int height, int n_frames,
+                                          mi_uv_mode uv_mode, void* stream);
+mi_status mi_clahe_nv12_batch_dev(mi_ctx* ctx, const void* d_in, void* d_out,
+                                  int width, int height, int n_frames, mi_uv_mode uv_mode,
+                                  double clip_limit, int tiles_x, int tiles_y, void* stream);
+
+/* ---- stage-level device entry points ---------------------------
+ * The same kernels the fused forms launch, exposed one stage at a time so each can be checked
+ * against the oracle and timed against its own roofline. */
+
+/* A2: d_hist[f][256] (int32) = exact histogram of frame f. */
+mi_status mi_hist_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
+                               int width, int height, int n_frames, void* d_hist, void* stream);
+/* A3: d_lut[f][256] (uint8) from d_hist[f][256]; total = width*height pixels per frame. */
+mi_status mi_equalize_lut_batch_dev(mi_ctx* ctx, const void* d_hist, int64_t total, int n_frames,
+                                    void* d_lut, void* stream);
+/* A4: dst = lut_f[src] for every frame (the north-star roofline kernel). */
+mi_status mi_lut_apply_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                    void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                    int width, int height, int n_frames, const void* d_lut, void* stream);
+/* A6 steps 1-4: d_luts[f][tiles_y*tiles_x][256] (uint8) per-tile clipped LUTs. */
+mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                       int width, int height, int n_frames,
+                                       double clip_limit, int tiles_x, int tiles_y,
+                                       void* d_luts, void* stream);
+
+/* ---- timing of the library's own kernels -------------------------------------------------------
+ * With profiling on, every kernel the library launches is bracketed by hipEvents on the stream
+ * it is launched on (the reference brackets its kernel with CL profiling events the same way,
+ * 1frameMeasure.cpp:77-85).  mi_ctx_profile_read() synchronises those events and accumulates. */
+enum { MI_K_HIST = 0, MI_K_EQ_LUT = 1, MI_K_LUT_APPLY = 2, MI_K_TILE_HIST = 3, MI_K_TILE_LUT = 4,
+       MI_K_CLAHE_INTERP = 5, MI_K_COUNT = 6 };
+typedef struct mi_profile {
+    double   total_ms[MI_K_COUNT];   /* summed kernel durations since the last reset */
+    uint64_t launches[MI_K_COUNT];
+} mi_profile;
+mi_status   mi_ctx_set_profiling(mi_ctx* ctx, int enabled);
+mi_status   mi_ctx_profile_read(mi_ctx* ctx, mi_profile* out, int reset);
+const char* mi_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_LUMAEQ_H_ */

@@ -1,0 +1,548 @@
+// lumaeq_kernels.hip.h -- hand-written gfx950 (CDNA4, wave64) kernels for the luma-equalization path.
+//
+// What they compute is fixed by OpenCV 4.4's cv::equalizeHist / CLAHE::apply as the reference calls
+// them (OpenCVequalHist.cpp:145, clahevideo.cpp:195); how they compute it is MI355X-first:
+//   * everything is byte/LUT work bound by HBM (no MFMA): 16 B/lane coalesced loads and stores,
+//     grid sized to ~8 workgroups/CU, a batch of frames per launch (grid.y / grid.z = frame);
+//   * histograms are privatised in LDS as hist[bin][32]: the copy a lane uses is (lane & 31), so
+//     its LDS bank is fixed by the lane and a ds_add_u32 wave-instruction is bank-conflict free
+//     whatever the pixel values are (a constant frame costs the same as noise);
+//   * the equalizeHist LUT is replicated the same way (lut[value][32]) so the per-pixel gather is
+//     conflict free as well;
+//   * float steps (LUT scale, CLAHE blend) use explicit __fmul_rn/__fadd_rn/__fsub_rn/__fdiv_rn so
+//     no FMA contraction can change a rounding (the file is also built with -ffp-contract=off).
+// Kernels never synchronise between workgroups inside a launch; stage results cross kernel
+// boundaries only (partials -> LUT -> apply).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));   // gfx950 global_load/store_dwordx4 accept any alignment
+
+constexpr int kThreads = 256;        // 4 waves of 64
+constexpr int kCopies = 32;          // LDS replication = number of ds_*_b32 banks
+constexpr int kCopyShift = 5;
+
+// A batch of strided 8-bit planes. "rows == 1" means the plane is contiguous and row_bytes = W*H.
+struct PlaneBatch {
+    const uint8_t* src;
+    uint8_t* dst;
+    long long src_step, dst_step;     // bytes between rows
+    long long src_frame, dst_frame;   // bytes between frames
+    long long row_bytes;              // bytes per row
+    int rows;
+};
+
+// Trailing UV job of an NV12 frame fused into the apply launch.
+struct UVJob {
+    const uint8_t* src;
+    uint8_t* dst;
+    long long src_frame, dst_frame;
+    long long bytes;                  // 0 = none
+    int mode;                         // 0 = fill 128, 1 = copy
+};
+
+struct Split16 { long long head, nvec, tail; };
+
+__device__ __forceinline__ Split16 split16(const void* p, long long n)
+{
+    Split16 s;
+    s.head = (16 - (long long)((uintptr_t)p & 15)) & 15;
+    if (s.head > n) s.head = n;
+    s.nvec = (n - s.head) >> 4;
+    s.tail = n - s.head - (s.nvec << 4);
+    return s;
+}
+
+__device__ __forceinline__ void lds_inc(uint32_t* h, uint32_t idx)
+{
+    __hip_atomic_fetch_add(h + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32
+}
+
+__device__ __forceinline__ void hist_add_dword(uint32_t* h, uint32_t w, uint32_t copy)
+{
+    lds_inc(h, ((w & 0xffu) << kCopyShift) + copy);
+    lds_inc(h, (((w >> 8) & 0xffu) << kCopyShift) + copy);
+    lds_inc(h, (((w >> 16) & 0xffu) << kCopyShift) + copy);
+    lds_inc(h, ((w >> 24) << kCopyShift) + copy);
+}
+
+__device__ __forceinline__ void hist_add_vec(uint32_t* h, u32x4 q, uint32_t copy)
+{
+    hist_add_dword(h, q.x, copy);
+    hist_add_dword(h, q.y, copy);
+    hist_add_dword(h, q.z, copy);
+    hist_add_dword(h, q.w, copy);
+}
+
+// Histogram of the bytes [p, p+n) shared between `nparts` workgroups; this one is `part`.
+__device__ __forceinline__ void hist_flat(uint32_t* h, const uint8_t* p, long long n, int part, int nparts)
+{
+    const int t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    const Split16 s = split16(p, n);
+    if (part == 0 && t < s.head) lds_inc(h, ((uint32_t)p[t] << kCopyShift) + copy);
+    if (part == nparts - 1 && t < s.tail) lds_inc(h, ((uint32_t)p[s.head + (s.nvec << 4) + t] << kCopyShift) + copy);
+    const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
+    const u32x4* vp = reinterpret_cast<const u32x4*>(p + s.head);
+    long long i = v0 + t;
+    for (; i + 3 * kThreads < v1; i += 4 * kThreads) {      // 4 x 16 B in flight per lane
+        const u32x4 a = vp[i], b = vp[i + kThreads], c = vp[i + 2 * kThreads], d = vp[i + 3 * kThreads];
+        hist_add_vec(h, a, copy); hist_add_vec(h, b, copy); hist_add_vec(h, c, copy); hist_add_vec(h, d, copy);
+    }
+    for (; i < v1; i += kThreads) hist_add_vec(h, vp[i], copy);
+}
+
+__device__ __forceinline__ void lds_hist_zero(uint32_t* h)
+{
+    for (int i = threadIdx.x; i < 256 * kCopies; i += kThreads) h[i] = 0;
+    __syncthreads();
+}
+
+// Sum of the 32 copies of bin `t` (skewed so that the 64 lanes of a wave hit 32 different banks).
+__device__ __forceinline__ uint32_t lds_hist_bin(const uint32_t* h, int t)
+{
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kCopies; ++k) s += h[(t << kCopyShift) + ((k + t) & (kCopies - 1))];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1  histogram partials.  grid = (B, n_frames); partial[f][b][256].
+// Reads W*H bytes per frame once; writes B KiB per frame.  Bound: HBM read.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void hist_partial_kernel(PlaneBatch p, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[256 * kCopies];
+    lds_hist_zero(h);
+    const uint8_t* base = p.src + (long long)blockIdx.y * p.src_frame;
+    if (p.rows == 1) {
+        hist_flat(h, base, p.row_bytes, blockIdx.x, gridDim.x);
+    } else {
+        for (int r = blockIdx.x; r < p.rows; r += gridDim.x) hist_flat(h, base + (long long)r * p.src_step, p.row_bytes, 0, 1);
+    }
+    __syncthreads();
+    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = lds_hist_bin(h, threadIdx.x);
+}
+
+// Block-wide helpers for 256 threads = 4 waves ------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// inclusive scan over the 256 threads of the block; *block_total receives the grand total.
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* block_total)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t incl = wave_incl_scan(v);
+    __syncthreads();                               // s_wave may be in use by a previous call
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t x = s_wave[k]; if (k < w) off += x; tot += x; }
+    if (block_total) *block_total = tot;
+    return incl + off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  CDF -> LUT (oracle: orc_equalize_lut).  grid = n_frames, 256 threads = bins.
+// partial[f][b][256] summed over b (b = 1 turns it into "LUT from a finished histogram").
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void equalize_lut_kernel(const uint32_t* __restrict__ partial, int nparts, int total,
+                                                               uint8_t* __restrict__ lut_out, int32_t* __restrict__ hist_out)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ int s_first[4];
+    __shared__ uint32_t s_hfirst;
+    const int t = threadIdx.x, f = blockIdx.x;
+    const uint32_t* pp = partial + (size_t)f * nparts * 256 + t;
+    uint32_t c = 0;
+    int b = 0;
+    for (; b + 4 <= nparts; b += 4) {
+        const uint32_t c0 = pp[(size_t)b * 256], c1 = pp[(size_t)(b + 1) * 256], c2 = pp[(size_t)(b + 2) * 256], c3 = pp[(size_t)(b + 3) * 256];
+        c += c0 + c1 + c2 + c3;
+    }
+    for (; b < nparts; ++b) c += pp[(size_t)b * 256];
+    if (hist_out) hist_out[(size_t)f * 256 + t] = (int32_t)c;
+    if (!lut_out) return;
+
+    const unsigned long long nz = __ballot(c != 0);
+    if ((t & 63) == 0) s_first[t >> 6] = nz ? (t + __builtin_ctzll(nz)) : 256;
+    const uint32_t cdf = block_incl_scan(c, s_wave, nullptr);      // contains the barriers that publish s_first
+    const int first = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
+    if (t == first) s_hfirst = c;
+    __syncthreads();
+    const uint32_t hfirst = s_hfirst;
+    uint8_t out;
+    if ((int)hfirst == total) {
+        out = (uint8_t)first;                                       // dst.setTo(i)
+    } else if (t <= first) {
+        out = 0;
+    } else {
+        const float scale = __fdiv_rn(255.0f, (float)(total - (int)hfirst));
+        const int sum = (int)(cdf - hfirst);                        // bins first+1 .. t
+        int r = __float2int_rn(__fmul_rn((float)sum, scale));       // cvRound: nearest, ties to even
+        r = r < 0 ? 0 : (r > 255 ? 255 : r);
+        out = (uint8_t)r;
+    }
+    lut_out[(size_t)f * 256 + t] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  LUT apply (+ fused NV12 UV fill/copy)  (SURVEY 8a rows A4, A7).  grid = (B, n_frames).
+// Reads W*H, writes W*H (plus UV: writes W*H/2, reads W*H/2 when copying).  Bound: HBM.
+// LDS: lut[value][32] replicated -> conflict-free ds_read per pixel.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lut_dword(const uint32_t* lut, uint32_t w, uint32_t copy)
+{
+    const uint32_t a = lut[((w & 0xffu) << kCopyShift) + copy];
+    const uint32_t b = lut[(((w >> 8) & 0xffu) << kCopyShift) + copy];
+    const uint32_t c = lut[(((w >> 16) & 0xffu) << kCopyShift) + copy];
+    const uint32_t d = lut[((w >> 24) << kCopyShift) + copy];
+    return a | (b << 8) | (c << 16) | (d << 24);
+}
+
+__device__ __forceinline__ u32x4 lut_vec(const uint32_t* lut, u32x4 q, uint32_t copy)
+{
+    u32x4 r;
+    r.x = lut_dword(lut, q.x, copy); r.y = lut_dword(lut, q.y, copy);
+    r.z = lut_dword(lut, q.z, copy); r.w = lut_dword(lut, q.w, copy);
+    return r;
+}
+
+// dst[i] = lut[src[i]] for i in [0,n), vector body aligned on dst (src loads may be unaligned).
+__device__ __forceinline__ void lut_flat(const uint32_t* lut, const uint8_t* src, uint8_t* dst, long long n, int part, int nparts)
+{
+    const int t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    const Split16 s = split16(dst, n);
+    if (part == 0 && t < s.head) dst[t] = (uint8_t)lut[((uint32_t)src[t] << kCopyShift) + copy];
+    if (part == nparts - 1 && t < s.tail) {
+        const long long o = s.head + (s.nvec << 4) + t;
+        dst[o] = (uint8_t)lut[((uint32_t)src[o] << kCopyShift) + copy];
+    }
+    const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
+    const u32x4_u* sp = reinterpret_cast<const u32x4_u*>(src + s.head);
+    u32x4* dp = reinterpret_cast<u32x4*>(dst + s.head);
+    long long i = v0 + t;
+    for (; i + 3 * kThreads < v1; i += 4 * kThreads) {
+        const u32x4 a = sp[i], b = sp[i + kThreads], c = sp[i + 2 * kThreads], d = sp[i + 3 * kThreads];
+        dp[i] = lut_vec(lut, a, copy);
+        dp[i + kThreads] = lut_vec(lut, b, copy);
+        dp[i + 2 * kThreads] = lut_vec(lut, c, copy);
+        dp[i + 3 * kThreads] = lut_vec(lut, d, copy);
+    }
+    for (; i < v1; i += kThreads) dp[i] = lut_vec(lut, sp[i], copy);
+}
+
+// UV plane: fill with 128 or copy, dst aligned stores.
+__device__ __forceinline__ void uv_flat(const uint8_t* src, uint8_t* dst, long long n, int mode, int part, int nparts)
+{
+    const int t = threadIdx.x;
+    const Split16 s = split16(dst, n);
+    if (part == 0 && t < s.head) dst[t] = mode ? src[t] : (uint8_t)128;
+    if (part == nparts - 1 && t < s.tail) {
+        const long long o = s.head + (s.nvec << 4) + t;
+        dst[o] = mode ? src[o] : (uint8_t)128;
+    }
+    const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
+    u32x4* dp = reinterpret_cast<u32x4*>(dst + s.head);
+    if (mode == 0) {
+        const u32x4 g = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+        for (long long i = v0 + t; i < v1; i += kThreads) dp[i] = g;
+    } else {
+        const u32x4_u* sp = reinterpret_cast<const u32x4_u*>(src + s.head);
+        long long i = v0 + t;
+        for (; i + 3 * kThreads < v1; i += 4 * kThreads) {
+            const u32x4 a = sp[i], b = sp[i + kThreads], c = sp[i + 2 * kThreads], d = sp[i + 3 * kThreads];
+            dp[i] = a; dp[i + kThreads] = b; dp[i + 2 * kThreads] = c; dp[i + 3 * kThreads] = d;
+        }
+        for (; i < v1; i += kThreads) dp[i] = sp[i];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void lut_apply_kernel(PlaneBatch p, const uint8_t* __restrict__ luts, UVJob uv)
+{
+    __shared__ uint32_t lut[256 * kCopies];
+    const int t = threadIdx.x, f = blockIdx.y;
+    {
+        const uint32_t v = luts[(size_t)f * 256 + t];
+#pragma unroll
+        for (int k = 0; k < kCopies; ++k) lut[(t << kCopyShift) + ((k + t) & (kCopies - 1))] = v;
+    }
+    __syncthreads();
+    const uint8_t* src = p.src + (long long)f * p.src_frame;
+    uint8_t* dst = p.dst + (long long)f * p.dst_frame;
+    if (p.rows == 1) {
+        lut_flat(lut, src, dst, p.row_bytes, blockIdx.x, gridDim.x);
+    } else {
+        for (int r = blockIdx.x; r < p.rows; r += gridDim.x)
+            lut_flat(lut, src + (long long)r * p.src_step, dst + (long long)r * p.dst_step, p.row_bytes, 0, 1);
+    }
+    if (uv.bytes > 0)
+        uv_flat(uv.src + (long long)f * uv.src_frame, uv.dst + (long long)f * uv.dst_frame, uv.bytes, uv.mode, blockIdx.x, gridDim.x);
+}
+
+// =============================================================================================
+// CLAHE  (oracle: orc_clahe_tile_luts / orc_clahe_interpolate)
+// =============================================================================================
+struct ClaheGeom {
+    int width, height;          // unpadded image
+    int tiles_x, tiles_y;
+    int tile_w, tile_h;         // tile size on the REFLECT_101-extended image
+    int clip;                   // integer clip limit (0 = off)
+    float lut_scale;            // 255.f / (tile_w*tile_h), computed on the host (IEEE division)
+    float inv_tw, inv_th;       // 1.f/tile_w, 1.f/tile_h, computed on the host
+};
+
+// core/src/copy.cpp borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4  per-tile histogram partials.  grid = (S, tiles, n_frames); partial[f][tile][s][256].
+// The padded image is never materialised: rows/columns beyond the frame are read by index
+// reflection.  Work items are (row, 16-byte slot) pairs walked incrementally so short tile rows
+// (480 B at 4K 8x8) still give every lane a vector load.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                            ClaheGeom g, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[256 * kCopies];
+    lds_hist_zero(h);
+    const int t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    const int S = gridDim.x, s = blockIdx.x, tile = blockIdx.y, f = blockIdx.z;
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    const uint8_t* src = src_base + (long long)f * frame_stride;
+    const int r0 = (int)((long long)g.tile_h * s / S), r1 = (int)((long long)g.tile_h * (s + 1) / S);
+    const int x0 = tx * g.tile_w;
+    const int in_w = max(0, min(g.tile_w, g.width - x0));     // columns of this tile that lie inside the frame
+    const int slots = (in_w + 15) >> 4;                        // 16-byte slots per row (last may be partial)
+    if (slots > 0) {
+        const int rows = r1 - r0;
+        const long long items = (long long)rows * slots;
+        int row = t / slots, slot = t - row * slots;
+        const int drow = kThreads / slots, dslot = kThreads - drow * slots;
+        for (long long it = t; it < items; it += kThreads) {
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            const uint8_t* p = src + (long long)y * step + x0 + (slot << 4);
+            const int nb = min(16, in_w - (slot << 4));
+            if (nb == 16) {
+                hist_add_vec(h, *reinterpret_cast<const u32x4_u*>(p), copy);
+            } else {
+                for (int k = 0; k < nb; ++k) lds_inc(h, ((uint32_t)p[k] << kCopyShift) + copy);
+            }
+            row += drow; slot += dslot;
+            if (slot >= slots) { slot -= slots; ++row; }
+        }
+    }
+    if (in_w < g.tile_w) {                                      // reflected columns (right border tiles only)
+        const int pw = g.tile_w - in_w;
+        const long long items = (long long)(r1 - r0) * pw;
+        for (long long it = t; it < items; it += kThreads) {
+            const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            const int x = reflect101(x0 + in_w + c, g.width);
+            lds_inc(h, ((uint32_t)src[(long long)y * step + x] << kCopyShift) + copy);
+        }
+    }
+    __syncthreads();
+    partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = lds_hist_bin(h, t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5  per-tile clip + redistribute + CDF -> uchar LUT.  grid = (tiles, n_frames), 256 threads = bins.
+// clahe.cpp CLAHE_CalcLut_Body: the sequential residual loop
+//     for (i = 0; i < 256 && residual > 0; i += step, --residual) ++h[i];
+// increments bin b iff b % step == 0 and b / step < residual.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void tile_lut_kernel(const uint32_t* __restrict__ partial, int S, ClaheGeom g,
+                                                           uint8_t* __restrict__ luts)
+{
+    __shared__ uint32_t s_wave[4];
+    const int t = threadIdx.x;
+    const size_t tile_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t* pp = partial + tile_id * S * 256 + t;
+    uint32_t c = 0;
+    for (int s = 0; s < S; ++s) c += pp[(size_t)s * 256];
+    int hv = (int)c;
+    if (g.clip > 0) {
+        const uint32_t excess = hv > g.clip ? (uint32_t)(hv - g.clip) : 0u;
+        uint32_t clipped;
+        block_incl_scan(excess, s_wave, &clipped);
+        if (hv > g.clip) hv = g.clip;
+        const int batch = (int)clipped / 256;
+        int residual = (int)clipped - batch * 256;
+        hv += batch;
+        if (residual != 0) {
+            int rstep = 256 / residual; if (rstep < 1) rstep = 1;
+            if (t % rstep == 0 && t / rstep < residual) ++hv;
+        }
+    }
+    const uint32_t sum = block_incl_scan((uint32_t)hv, s_wave, nullptr);
+    int r = __float2int_rn(__fmul_rn((float)(int)sum, g.lut_scale));
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    luts[tile_id * 256 + t] = (uint8_t)r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6  bilinear interpolation of the four neighbouring tile LUTs (clahe.cpp CLAHE_Interpolation_Body).
+// grid = (bands*subs, n_frames, col_segments).  A "band" is the set of rows with the same unclamped
+// ty1 (= band-1), so the two LUT rows a workgroup needs are fixed; it stages, for every
+// horizontal tile pair p (unclamped tx1 = p-1), quad[p][v] = {LUT[ty1][tx1][v], LUT[ty1][tx2][v],
+// LUT[ty2][tx1][v], LUT[ty2][tx2][v]} as one dword in LDS, so a pixel costs ONE ds_read_b32.
+// A lane owns 16 fixed columns (their xa/xa1/pair are lane constants) and walks down the rows.
+// Float ops: nine individually rounded f32 ops per pixel, no FMA (App. A.2 step 5).
+// ---------------------------------------------------------------------------------------------
+constexpr int kInterpPx = 16;           // pixels per lane per row
+constexpr int kMaxPairsLds = 63;        // (tiles_x + 1) KiB of LDS (<= 64 KiB dynamic); wider grids use the global-LUT kernel
+constexpr int kBandMargin = 4;          // rows; covers the f32 rounding of y*inv_th - 0.5 for any height <= 2^24
+
+__device__ __forceinline__ int floor_f32_to_int(float v) { const int i = (int)v; return i - ((float)i > v); }   // cvFloor
+
+__device__ __forceinline__ uint32_t clahe_px(uint32_t q, float xa, float xa1, float ya, float ya1)
+{
+    const float a = (float)(q & 0xffu), b = (float)((q >> 8) & 0xffu), c = (float)((q >> 16) & 0xffu), d = (float)(q >> 24);
+    const float top = __fmul_rn(__fadd_rn(__fmul_rn(a, xa1), __fmul_rn(b, xa)), ya1);
+    const float bot = __fmul_rn(__fadd_rn(__fmul_rn(c, xa1), __fmul_rn(d, xa)), ya);
+    int r = __float2int_rn(__fadd_rn(top, bot));
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    return (uint32_t)r;
+}
+
+__global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, ClaheGeom g, const uint8_t* __restrict__ luts,
+                                                               int subs, int groups, UVJob uv)
+{
+    extern __shared__ uint32_t quad[];                        // [(tiles_x + 1)][256]
+    const int t = threadIdx.x, f = blockIdx.y;
+    const int band = blockIdx.x / subs, sub = blockIdx.x - band * subs;
+    const int ty1u = band - 1;                                // unclamped ty1 of every row of the band
+    const int ty1 = max(ty1u, 0), ty2 = min(ty1u + 1, g.tiles_y - 1);
+    const uint8_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * 256;
+    const uint8_t* l1 = lf + (size_t)ty1 * g.tiles_x * 256;
+    const uint8_t* l2 = lf + (size_t)ty2 * g.tiles_x * 256;
+    const int npairs = g.tiles_x + 1;
+    for (int i = t; i < npairs * 256; i += kThreads) {
+        const int pr = i >> 8, v = i & 255;
+        const int ta = max(pr - 1, 0), tb = min(pr, g.tiles_x - 1);
+        quad[i] = (uint32_t)l1[ta * 256 + v] | ((uint32_t)l1[tb * 256 + v] << 8) |
+                  ((uint32_t)l2[ta * 256 + v] << 16) | ((uint32_t)l2[tb * 256 + v] << 24);
+    }
+    __syncthreads();
+
+    // rows of this band: ideal range [(band-0.5)*th, (band+0.5)*th), widened by kBandMargin rows each side and
+    // filtered by the float-computed ty1 so the decision is exactly the reference's.
+    const int y_lo_band = (int)max(0LL, ((long long)(2 * band - 1) * g.tile_h) / 2 - kBandMargin);
+    const int y_hi_band = (int)min((long long)g.height, ((long long)(2 * band + 1) * g.tile_h + 1) / 2 + kBandMargin);
+    const int nrows = max(0, y_hi_band - y_lo_band);
+    const int y_lo = y_lo_band + (int)((long long)nrows * sub / subs);
+    const int y_hi = y_lo_band + (int)((long long)nrows * (sub + 1) / subs);
+
+    const int phases = kThreads / groups;
+    const int grp = t % groups, phase = t / groups;
+    const int x0 = (blockIdx.z * groups + grp) * kInterpPx;
+    if (phase < phases && x0 < g.width) {
+        float xa[kInterpPx], xa1[kInterpPx];
+        int poff[kInterpPx];
+#pragma unroll
+        for (int j = 0; j < kInterpPx; ++j) {
+            const float txf = __fsub_rn(__fmul_rn((float)(x0 + j), g.inv_tw), 0.5f);
+            const int tx1 = floor_f32_to_int(txf);
+            xa[j] = __fsub_rn(txf, (float)tx1);
+            xa1[j] = __fsub_rn(1.0f, xa[j]);
+            int pr = tx1 + 1;                                  // pair index; columns beyond the frame are never used
+            pr = pr < 0 ? 0 : (pr > g.tiles_x ? g.tiles_x : pr);
+            poff[j] = pr << 8;
+        }
+        const uint8_t* src = p.src + (long long)f * p.src_frame;
+        uint8_t* dst = p.dst + (long long)f * p.dst_frame;
+        const bool full = x0 + kInterpPx <= g.width;
+        for (int y = y_lo + phase; y < y_hi; y += phases) {
+            const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+            const int ty1r = floor_f32_to_int(tyf);
+            if (ty1r != ty1u) continue;                        // belongs to the neighbouring band
+            const float ya = __fsub_rn(tyf, (float)ty1r), ya1 = __fsub_rn(1.0f, ya);
+            const uint8_t* sr = src + (long long)y * p.src_step + x0;
+            uint8_t* dr = dst + (long long)y * p.dst_step + x0;
+            if (full) {
+                const u32x4 q = *reinterpret_cast<const u32x4_u*>(sr);
+                u32x4 o;
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int j = k * 4 + b;
+                        const uint32_t v = (w[k] >> (8 * b)) & 0xffu;
+                        acc |= clahe_px(quad[poff[j] + v], xa[j], xa1[j], ya, ya1) << (8 * b);
+                    }
+                    ow[k] = acc;
+                }
+                o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
+                *reinterpret_cast<u32x4_u*>(dr) = o;
+            } else {
+#pragma unroll
+                for (int j = 0; j < kInterpPx; ++j)
+                    if (x0 + j < g.width) dr[j] = (uint8_t)clahe_px(quad[poff[j] + sr[j]], xa[j], xa1[j], ya, ya1);
+            }
+        }
+    }
+    if (uv.bytes > 0 && blockIdx.z == 0)
+        uv_flat(uv.src + (long long)f * uv.src_frame, uv.dst + (long long)f * uv.dst_frame, uv.bytes, uv.mode, blockIdx.x, gridDim.x);
+}
+
+// Fallback for tile grids too wide for the LDS pair table: LUTs gathered from global memory (L2).
+__global__ __launch_bounds__(kThreads) void clahe_interp_global_kernel(PlaneBatch p, ClaheGeom g, const uint8_t* __restrict__ luts)
+{
+    const int f = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * kThreads + threadIdx.x;
+    if (x >= g.width) return;
+    const uint8_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * 256;
+    const float txf = __fsub_rn(__fmul_rn((float)x, g.inv_tw), 0.5f);
+    int tx1 = floor_f32_to_int(txf);
+    const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
+    int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
+    const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+    int ty1 = floor_f32_to_int(tyf);
+    const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
+    int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
+    const uint32_t v = p.src[(long long)f * p.src_frame + (long long)y * p.src_step + x];
+    const uint32_t q = (uint32_t)lf[((size_t)ty1 * g.tiles_x + tx1) * 256 + v] |
+                       ((uint32_t)lf[((size_t)ty1 * g.tiles_x + tx2) * 256 + v] << 8) |
+                       ((uint32_t)lf[((size_t)ty2 * g.tiles_x + tx1) * 256 + v] << 16) |
+                       ((uint32_t)lf[((size_t)ty2 * g.tiles_x + tx2) * 256 + v] << 24);
+    p.dst[(long long)f * p.dst_frame + (long long)y * p.dst_step + x] = (uint8_t)clahe_px(q, xa, xa1, ya, ya1);
+}
+
+// UV-only launch (used when the Y kernel cannot carry the UV job).
+__global__ __launch_bounds__(kThreads) void uv_kernel(UVJob uv)
+{
+    const int f = blockIdx.y;
+    uv_flat(uv.src + (long long)f * uv.src_frame, uv.dst + (long long)f * uv.dst_frame, uv.bytes, uv.mode, blockIdx.x, gridDim.x);
+}
+
+}  // namespace mi

@@ -1,0 +1,668 @@
+// mi_lumaeq.hip -- C ABI (include/mi_lumaeq.h) over the gfx950 kernels in lumaeq_kernels.hip.h.
+//
+// Boundary being replaced (reference file:line):
+//   cv::equalizeHist call site            OpenCVequalHist.cpp:145, nextimprovement.cpp:168
+//   cv::CLAHE::apply call site            clahevideo.cpp:195, clahe1frame.cpp:93
+//   FPGA backend host sequence            OpenCLequalHist.cpp:346-365 (setArg x5, write x2, task, read)
+//   per-worker device objects + buffers   OpenCLequalHist.cpp:142-152, :175-186
+// There is NO CPU fallback in this file: without a HIP device every entry point fails loudly.
+#include "../../include/mi_lumaeq.h"
+#include "lumaeq_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mi;
+
+namespace {
+
+struct PendingEvent { hipEvent_t a, b; int kernel; };
+
+}  // namespace
+
+struct mi_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    int last_hip = 0;
+    std::string last_msg = "ok";
+    int cu_count = 256;
+
+    // device scratch, grown lazily ("allocate once per size", OpenCLequalHist.cpp:175-186)
+    uint32_t* d_partial = nullptr; size_t partial_bytes = 0;     // histogram partials
+    uint8_t*  d_luts = nullptr;    size_t luts_bytes = 0;        // per-frame / per-tile LUTs
+    uint8_t*  d_stage_in = nullptr;  size_t stage_in_bytes = 0;  // device frame for the host-pointer forms
+    uint8_t*  d_stage_out = nullptr; size_t stage_out_bytes = 0;
+    uint8_t*  h_pin_in = nullptr;  size_t pin_in_bytes = 0;      // pinned staging
+    uint8_t*  h_pin_out = nullptr; size_t pin_out_bytes = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> free_events;
+    mi_profile prof{};
+};
+
+namespace {
+
+mi_status fail_hip(mi_ctx* c, hipError_t e, const char* what)
+{
+    c->last_hip = (int)e;
+    c->last_msg = std::string(what) + ": " + hipGetErrorString(e);
+    return MI_ERR_HIP;
+}
+mi_status fail(mi_ctx* c, mi_status s, const char* msg)
+{
+    if (c) c->last_msg = msg;
+    return s;
+}
+
+#define HIPCHK(c, expr)                                         \
+    do {                                                        \
+        hipError_t e__ = (expr);                                \
+        if (e__ != hipSuccess) return fail_hip((c), e__, #expr); \
+    } while (0)
+
+template <class T>
+mi_status grow_dev(mi_ctx* c, T** p, size_t* have, size_t need)
+{
+    if (need <= *have) return MI_OK;
+    if (*p) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(*p)); *p = nullptr; *have = 0; }   // rare: scratch may be in use on a caller stream
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, need);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(c, MI_ERR_OOM, "device allocation failed"); }
+    if (e != hipSuccess) return fail_hip(c, e, "hipMalloc");
+    *p = (T*)q; *have = need;
+    return MI_OK;
+}
+
+mi_status grow_pinned(mi_ctx* c, uint8_t** p, size_t* have, size_t need)
+{
+    if (need <= *have) return MI_OK;
+    if (*p) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipHostFree(*p)); *p = nullptr; *have = 0; }
+    void* q = nullptr;
+    hipError_t e = hipHostMalloc(&q, need, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(c, MI_ERR_OOM, "pinned allocation failed"); }
+    if (e != hipSuccess) return fail_hip(c, e, "hipHostMalloc");
+    *p = (uint8_t*)q; *have = need;
+    return MI_OK;
+}
+
+// ---- kernel launch with optional event bracketing ---------------------------------------------
+struct Bracket {
+    mi_ctx* c; hipStream_t s; int kernel; hipEvent_t a = nullptr, b = nullptr; bool on;
+    Bracket(mi_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kernel(k), on(c_->profiling) {}
+    hipError_t begin()
+    {
+        if (!on) return hipSuccess;
+        for (hipEvent_t* e : {&a, &b}) {
+            if (!c->free_events.empty()) { *e = c->free_events.back(); c->free_events.pop_back(); }
+            else { hipError_t r = hipEventCreate(e); if (r != hipSuccess) return r; }
+        }
+        return hipEventRecord(a, s);
+    }
+    hipError_t end()
+    {
+        if (!on) return hipSuccess;
+        hipError_t r = hipEventRecord(b, s);
+        c->pending.push_back({a, b, kernel});
+        return r;
+    }
+};
+
+#define LAUNCH(c, s, kid, kern, grid, block, shmem, ...)                          \
+    do {                                                                          \
+        Bracket br__((c), (s), (kid));                                            \
+        HIPCHK((c), br__.begin());                                                \
+        hipLaunchKernelGGL(kern, grid, block, shmem, (s), __VA_ARGS__);           \
+        HIPCHK((c), hipGetLastError());                                           \
+        HIPCHK((c), br__.end());                                                  \
+    } while (0)
+
+// ---- geometry / grid heuristics -----------------------------------------------------------------
+// Memory-bound kernels: aim for ~8 workgroups per CU in total, never less than 16 KiB per workgroup
+// (a workgroup pays 64 LDS wave-ops to zero and fold its replicated histogram / LUT).
+int blocks_per_frame(const mi_ctx* c, long long bytes_per_frame, int rows, int n_frames, int cap)
+{
+    const long long target = (long long)c->cu_count * 8;
+    long long b = (target + n_frames - 1) / n_frames;
+    const long long by_bytes = std::max<long long>(1, bytes_per_frame / 16384);
+    b = std::min(b, by_bytes);
+    if (rows > 1) b = std::min<long long>(b, rows);
+    b = std::min<long long>(b, cap);
+    return (int)std::max<long long>(1, b);
+}
+
+struct PlaneArgs {
+    const uint8_t* src; size_t src_step, src_frame;
+    uint8_t* dst; size_t dst_step, dst_frame;
+    int width, height, n_frames;
+};
+
+mi_status check_plane(mi_ctx* c, const PlaneArgs& a, bool need_dst)
+{
+    if (!c) return MI_ERR_BAD_ARG;
+    if (a.width < 0 || a.height < 0 || a.n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "negative size");
+    if (a.width == 0 || a.height == 0 || a.n_frames == 0) return MI_OK;
+    if (!a.src || (need_dst && !a.dst)) return fail(c, MI_ERR_BAD_ARG, "null plane pointer");
+    if (a.src_step < (size_t)a.width || (need_dst && a.dst_step < (size_t)a.width)) return fail(c, MI_ERR_BAD_ARG, "step < width");
+    if ((long long)a.width * a.height > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "width*height must be < 2^31 (OpenCV: int total)");
+    if (a.width > (1 << 24) || a.height > (1 << 24)) return fail(c, MI_ERR_UNSUPPORTED, "width/height must be <= 2^24");
+    return MI_OK;
+}
+
+PlaneBatch make_plane(const PlaneArgs& a)
+{
+    PlaneBatch p;
+    p.src = a.src; p.dst = a.dst;
+    p.src_frame = (long long)a.src_frame; p.dst_frame = (long long)a.dst_frame;
+    const bool contiguous = a.src_step == (size_t)a.width && (!a.dst || a.dst_step == (size_t)a.width);
+    if (contiguous || a.height == 1) {
+        p.rows = 1; p.row_bytes = (long long)a.width * a.height;
+        p.src_step = p.row_bytes; p.dst_step = p.row_bytes;
+    } else {
+        p.rows = a.height; p.row_bytes = a.width;
+        p.src_step = (long long)a.src_step; p.dst_step = (long long)a.dst_step;
+    }
+    return p;
+}
+
+constexpr int kMaxGridY = 65535;
+
+// ---- stage launchers (all assume ctx lock held, device set) -------------------------------------
+mi_status launch_hist_partials(mi_ctx* c, hipStream_t s, const PlaneArgs& a, int f0, int nf, int* nparts_out)
+{
+    PlaneArgs b = a;
+    b.src = a.src + (size_t)f0 * a.src_frame; b.dst = nullptr; b.n_frames = nf;
+    PlaneBatch p = make_plane(b);
+    const int B = blocks_per_frame(c, (long long)a.width * a.height, p.rows, nf, 256);
+    mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * B * 256 * sizeof(uint32_t));
+    if (st) return st;
+    LAUNCH(c, s, MI_K_HIST, hist_partial_kernel, dim3(B, nf), dim3(kThreads), 0, p, c->d_partial);
+    *nparts_out = B;
+    return MI_OK;
+}
+
+mi_status launch_apply(mi_ctx* c, hipStream_t s, const PlaneArgs& a, int f0, int nf, const uint8_t* d_luts, const UVJob* uv_all)
+{
+    PlaneArgs b = a;
+    b.src = a.src + (size_t)f0 * a.src_frame; b.dst = a.dst + (size_t)f0 * a.dst_frame; b.n_frames = nf;
+    PlaneBatch p = make_plane(b);
+    UVJob uv{};
+    long long bytes = (long long)a.width * a.height * 2;
+    if (uv_all && uv_all->bytes > 0) {
+        uv = *uv_all;
+        uv.src = uv_all->src ? uv_all->src + (long long)f0 * uv_all->src_frame : nullptr;
+        uv.dst = uv_all->dst + (long long)f0 * uv_all->dst_frame;
+        bytes += uv.bytes * (uv.mode ? 2 : 1);
+    }
+    const int B = blocks_per_frame(c, bytes / 2, p.rows, nf, 2048);
+    LAUNCH(c, s, MI_K_LUT_APPLY, lut_apply_kernel, dim3(B, nf), dim3(kThreads), 0, p, d_luts, uv);
+    return MI_OK;
+}
+
+mi_status equalize_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
+{
+    for (int f0 = 0; f0 < a.n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, a.n_frames - f0);
+        int nparts = 0;
+        mi_status st = launch_hist_partials(c, s, a, f0, nf, &nparts);
+        if (st) return st;
+        st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * 256);
+        if (st) return st;
+        LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf), dim3(kThreads), 0,
+               (const uint32_t*)c->d_partial, nparts, (int)((long long)a.width * a.height), c->d_luts, (int32_t*)nullptr);
+        st = launch_apply(c, s, a, f0, nf, c->d_luts, uv);
+        if (st) return st;
+    }
+    return MI_OK;
+}
+
+// ---- CLAHE ----------------------------------------------------------------------------------------
+mi_status clahe_geometry(mi_ctx* c, int width, int height, double clip_limit, int tiles_x, int tiles_y, ClaheGeom* g)
+{
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if ((long long)tiles_x * tiles_y > (1 << 20)) return fail(c, MI_ERR_UNSUPPORTED, "tile grid too large");
+    g->width = width; g->height = height; g->tiles_x = tiles_x; g->tiles_y = tiles_y;
+    long long ew = width, eh = height;
+    if (width % tiles_x != 0 || height % tiles_y != 0) {          // clahe.cpp: BOTH pads whenever EITHER is indivisible
+        ew = (long long)width + (tiles_x - width % tiles_x);
+        eh = (long long)height + (tiles_y - height % tiles_y);
+    }
+    g->tile_w = (int)(ew / tiles_x); g->tile_h = (int)(eh / tiles_y);
+    const long long area = (long long)g->tile_w * g->tile_h;
+    if (area > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "tile area must be < 2^31");
+    g->lut_scale = 255.0f / (float)(int)area;
+    int clip = 0;
+    if (clip_limit > 0.0) {
+        clip = (int)(clip_limit * (int)area / 256);                // double math, truncation (clahe.cpp)
+        clip = std::max(clip, 1);
+    }
+    g->clip = clip;
+    g->inv_tw = 1.0f / (float)g->tile_w;
+    g->inv_th = 1.0f / (float)g->tile_h;
+    return MI_OK;
+}
+
+mi_status launch_tile_luts(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const ClaheGeom& g, int f0, int nf, uint8_t* d_luts_out)
+{
+    const int tiles = g.tiles_x * g.tiles_y;
+    // splits per tile: enough workgroups to fill the chip, at least ~8 rows of work each
+    long long want = ((long long)c->cu_count * 8 + (long long)tiles * nf - 1) / ((long long)tiles * nf);
+    int S = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 8), 64LL}));
+    mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * tiles * S * 256 * sizeof(uint32_t));
+    if (st) return st;
+    const uint8_t* src = a.src + (size_t)f0 * a.src_frame;
+    // grid.y = tiles, grid.z = frames
+    if (tiles > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "more than 65535 tiles per frame");
+    LAUNCH(c, s, MI_K_TILE_HIST, tile_hist_kernel, dim3(S, tiles, nf), dim3(kThreads), 0,
+           src, (long long)a.src_step, (long long)a.src_frame, g, c->d_partial);
+    LAUNCH(c, s, MI_K_TILE_LUT, tile_lut_kernel, dim3(tiles, nf), dim3(kThreads), 0,
+           (const uint32_t*)c->d_partial, S, g, d_luts_out);
+    return MI_OK;
+}
+
+mi_status launch_interp(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const ClaheGeom& g, int f0, int nf,
+                        const uint8_t* d_luts, const UVJob* uv_all)
+{
+    PlaneBatch p;
+    p.src = a.src + (size_t)f0 * a.src_frame; p.dst = a.dst + (size_t)f0 * a.dst_frame;
+    p.src_step = (long long)a.src_step; p.dst_step = (long long)a.dst_step;
+    p.src_frame = (long long)a.src_frame; p.dst_frame = (long long)a.dst_frame;
+    p.row_bytes = a.width; p.rows = a.height;
+    UVJob uv{};
+    if (uv_all && uv_all->bytes > 0) {
+        uv = *uv_all;
+        uv.src = uv_all->src ? uv_all->src + (long long)f0 * uv_all->src_frame : nullptr;
+        uv.dst = uv_all->dst + (long long)f0 * uv_all->dst_frame;
+    }
+    const int npairs = g.tiles_x + 1;
+    if (npairs <= kMaxPairsLds) {
+        const int ngroups = (a.width + kInterpPx - 1) / kInterpPx;
+        const int groups = std::min(ngroups, kThreads);
+        const int segs = (ngroups + groups - 1) / groups;
+        const int bands = g.tiles_y + 1;
+        long long want = ((long long)c->cu_count * 8 + (long long)bands * nf * segs - 1) / ((long long)bands * nf * segs);
+        const int rows_per_band = g.tile_h + 2 * kBandMargin;
+        int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, rows_per_band / 8), 64LL}));
+        if ((long long)bands * subs > 0x7fffffffLL || segs > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "image too wide");
+        LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_kernel, dim3(bands * subs, nf, segs), dim3(kThreads),
+               (size_t)npairs * 256 * sizeof(uint32_t), p, g, d_luts, subs, groups, uv);
+    } else {
+        if (a.height > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "height > 65535 with tiles_x > 62");
+        LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_global_kernel,
+               dim3((a.width + kThreads - 1) / kThreads, a.height, nf), dim3(kThreads), 0, p, g, d_luts);
+        if (uv.bytes > 0) {
+            const int B = blocks_per_frame(c, uv.bytes, 1, nf, 2048);
+            LAUNCH(c, s, MI_K_LUT_APPLY, uv_kernel, dim3(B, nf), dim3(kThreads), 0, uv);
+        }
+    }
+    return MI_OK;
+}
+
+mi_status clahe_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, double clip_limit, int tiles_x, int tiles_y, const UVJob* uv)
+{
+    ClaheGeom g;
+    mi_status st = clahe_geometry(c, a.width, a.height, clip_limit, tiles_x, tiles_y, &g);
+    if (st) return st;
+    const int tiles = tiles_x * tiles_y;
+    const int chunk = std::min(kMaxGridY, 65535);
+    for (int f0 = 0; f0 < a.n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, a.n_frames - f0);
+        st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * tiles * 256);
+        if (st) return st;
+        st = launch_tile_luts(c, s, a, g, f0, nf, c->d_luts);
+        if (st) return st;
+        st = launch_interp(c, s, a, g, f0, nf, c->d_luts, uv);
+        if (st) return st;
+    }
+    return MI_OK;
+}
+
+UVJob nv12_uv(const uint8_t* in, uint8_t* out, int width, int height, mi_uv_mode mode)
+{
+    const long long y = (long long)width * height, uvb = y / 2;       // OpenCVequalHist.cpp:129-130
+    UVJob uv;
+    uv.src = in ? in + y : nullptr; uv.dst = out + y;
+    uv.src_frame = y + uvb; uv.dst_frame = y + uvb;
+    uv.bytes = uvb; uv.mode = mode == MI_UV_COPY ? 1 : 0;
+    if (uv.mode == 1 && in == out) uv.bytes = 0;                      // in-place passthrough: nothing to move
+    return uv;
+}
+
+struct Guard {
+    mi_ctx* c; std::unique_lock<std::mutex> lk; hipError_t err;
+    explicit Guard(mi_ctx* c_) : c(c_), lk(c_->mu) { err = hipSetDevice(c->device); }
+};
+
+#define ENTER(ctx)                                                   \
+    if (!(ctx)) return MI_ERR_BAD_ARG;                               \
+    Guard guard__(ctx);                                              \
+    if (guard__.err != hipSuccess) return fail_hip((ctx), guard__.err, "hipSetDevice")
+
+hipStream_t pick_stream(mi_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+// ---- host-pointer plumbing ---------------------------------------------------------------------------
+void copy_rows(uint8_t* dst, size_t dst_step, const uint8_t* src, size_t src_step, int width, int height)
+{
+    if (dst_step == (size_t)width && src_step == (size_t)width) { memcpy(dst, src, (size_t)width * height); return; }
+    for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * dst_step, src + (size_t)y * src_step, (size_t)width);
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* mi_version(void) { return "mi_lumaeq 0.1 (gfx950)"; }
+
+const char* mi_status_str(mi_status s)
+{
+    switch (s) {
+        case MI_OK: return "MI_OK";
+        case MI_ERR_BAD_ARG: return "MI_ERR_BAD_ARG";
+        case MI_ERR_UNSUPPORTED: return "MI_ERR_UNSUPPORTED";
+        case MI_ERR_HIP: return "MI_ERR_HIP";
+        case MI_ERR_OOM: return "MI_ERR_OOM";
+        case MI_ERR_NO_DEVICE: return "MI_ERR_NO_DEVICE";
+    }
+    return "MI_ERR_?";
+}
+
+const char* mi_kernel_name(int k)
+{
+    static const char* names[MI_K_COUNT] = {"hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
+                                            "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel"};
+    return (k >= 0 && k < MI_K_COUNT) ? names[k] : "?";
+}
+
+int mi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+mi_status mi_ctx_create(int device, mi_ctx** out)
+{
+    if (!out) return MI_ERR_BAD_ARG;
+    *out = nullptr;
+    const int n = mi_device_count();
+    if (n <= 0 || device < 0 || device >= n) return MI_ERR_NO_DEVICE;
+    mi_ctx* c = new (std::nothrow) mi_ctx();
+    if (!c) return MI_ERR_OOM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return MI_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount;
+    *out = c;
+    return MI_OK;
+}
+
+void mi_ctx_destroy(mi_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_luts) (void)hipFree(c->d_luts);
+    if (c->d_stage_in) (void)hipFree(c->d_stage_in);
+    if (c->d_stage_out) (void)hipFree(c->d_stage_out);
+    if (c->h_pin_in) (void)hipHostFree(c->h_pin_in);
+    if (c->h_pin_out) (void)hipHostFree(c->h_pin_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mi_ctx_device(const mi_ctx* c) { return c ? c->device : -1; }
+int mi_ctx_last_hip_error(const mi_ctx* c) { return c ? c->last_hip : 0; }
+const char* mi_ctx_last_error_msg(const mi_ctx* c) { return c ? c->last_msg.c_str() : "null context"; }
+
+mi_status mi_ctx_set_profiling(mi_ctx* c, int enabled)
+{
+    ENTER(c);
+    c->profiling = enabled != 0;
+    return MI_OK;
+}
+
+mi_status mi_ctx_profile_read(mi_ctx* c, mi_profile* out, int reset)
+{
+    ENTER(c);
+    for (auto& p : c->pending) {
+        HIPCHK(c, hipEventSynchronize(p.b));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, p.a, p.b));
+        c->prof.total_ms[p.kernel] += ms;
+        c->prof.launches[p.kernel] += 1;
+        c->free_events.push_back(p.a);
+        c->free_events.push_back(p.b);
+    }
+    c->pending.clear();
+    if (out) *out = c->prof;
+    if (reset) c->prof = mi_profile{};
+    return MI_OK;
+}
+
+// ---- device-resident batched forms ------------------------------------------------------------------
+mi_status mi_equalize_hist_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                        void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                        int width, int height, int n_frames, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    return equalize_dev(c, pick_stream(c, stream), a, nullptr);
+}
+
+mi_status mi_equalize_hist_nv12_batch_dev(mi_ctx* c, const void* d_in, void* d_out, int width, int height, int n_frames,
+                                          mi_uv_mode uv_mode, void* stream)
+{
+    ENTER(c);
+    if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    const size_t frame = (size_t)width * height + ((size_t)width * height) / 2;
+    PlaneArgs a{(const uint8_t*)d_in, (size_t)width, frame, (uint8_t*)d_out, (size_t)width, frame, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    UVJob uv = nv12_uv((const uint8_t*)d_in, (uint8_t*)d_out, width, height, uv_mode);
+    return equalize_dev(c, pick_stream(c, stream), a, &uv);
+}
+
+mi_status mi_clahe_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    return clahe_dev(c, pick_stream(c, stream), a, clip_limit, tiles_x, tiles_y, nullptr);
+}
+
+mi_status mi_clahe_nv12_batch_dev(mi_ctx* c, const void* d_in, void* d_out, int width, int height, int n_frames,
+                                  mi_uv_mode uv_mode, double clip_limit, int tiles_x, int tiles_y, void* stream)
+{
+    ENTER(c);
+    if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    const size_t frame = (size_t)width * height + ((size_t)width * height) / 2;
+    PlaneArgs a{(const uint8_t*)d_in, (size_t)width, frame, (uint8_t*)d_out, (size_t)width, frame, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    UVJob uv = nv12_uv((const uint8_t*)d_in, (uint8_t*)d_out, width, height, uv_mode);
+    return clahe_dev(c, pick_stream(c, stream), a, clip_limit, tiles_x, tiles_y, &uv);
+}
+
+// ---- stage-level forms ---------------------------------------------------------------------------------
+mi_status mi_hist_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                               int width, int height, int n_frames, void* d_hist, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, nullptr, 0, 0, width, height, n_frames};
+    mi_status st = check_plane(c, a, false);
+    if (st) return st;
+    if (!d_hist) return fail(c, MI_ERR_BAD_ARG, "null d_hist");
+    hipStream_t s = pick_stream(c, stream);
+    if (n_frames == 0) return MI_OK;
+    if (width == 0 || height == 0) { HIPCHK(c, hipMemsetAsync(d_hist, 0, (size_t)n_frames * 1024, s)); return MI_OK; }
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        int nparts = 0;
+        st = launch_hist_partials(c, s, a, f0, nf, &nparts);
+        if (st) return st;
+        LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf), dim3(kThreads), 0,
+               (const uint32_t*)c->d_partial, nparts, 0, (uint8_t*)nullptr, (int32_t*)d_hist + (size_t)f0 * 256);
+    }
+    return MI_OK;
+}
+
+mi_status mi_equalize_lut_batch_dev(mi_ctx* c, const void* d_hist, int64_t total, int n_frames, void* d_lut, void* stream)
+{
+    ENTER(c);
+    if (!d_hist || !d_lut || n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "null pointer / negative count");
+    if (total <= 0 || total > 0x7fffffffLL) return fail(c, MI_ERR_BAD_ARG, "total must be in [1, 2^31)");
+    hipStream_t s = pick_stream(c, stream);
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf), dim3(kThreads), 0,
+               (const uint32_t*)d_hist + (size_t)f0 * 256, 1, (int)total, (uint8_t*)d_lut + (size_t)f0 * 256, (int32_t*)nullptr);
+    }
+    return MI_OK;
+}
+
+mi_status mi_lut_apply_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                    void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                    int width, int height, int n_frames, const void* d_lut, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    if (!d_lut) return fail(c, MI_ERR_BAD_ARG, "null d_lut");
+    hipStream_t s = pick_stream(c, stream);
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        st = launch_apply(c, s, a, f0, nf, (const uint8_t*)d_lut + (size_t)f0 * 256, nullptr);
+        if (st) return st;
+    }
+    return MI_OK;
+}
+
+mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                       int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y,
+                                       void* d_luts, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, nullptr, 0, 0, width, height, n_frames};
+    mi_status st = check_plane(c, a, false);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    if (!d_luts) return fail(c, MI_ERR_BAD_ARG, "null d_luts");
+    ClaheGeom g;
+    st = clahe_geometry(c, width, height, clip_limit, tiles_x, tiles_y, &g);
+    if (st) return st;
+    hipStream_t s = pick_stream(c, stream);
+    const size_t per_frame = (size_t)tiles_x * tiles_y * 256;
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        st = launch_tile_luts(c, s, a, g, f0, nf, (uint8_t*)d_luts + (size_t)f0 * per_frame);
+        if (st) return st;
+    }
+    return MI_OK;
+}
+
+// ---- host-pointer forms (the cv::Mat boundary) -----------------------------------------------------------
+// Host rows -> pinned staging -> H2D -> kernels -> D2H -> pinned -> host rows, all on the context's
+// stream, synchronous on return.  `nv12_mode` < 0: plain Y plane; otherwise whole NV12 frame.
+static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step,
+                         int width, int height, int nv12_mode, bool is_clahe, double clip_limit, int tiles_x, int tiles_y)
+{
+    const size_t ybytes = (size_t)width * height;
+    const size_t uvbytes = nv12_mode >= 0 ? ybytes / 2 : 0;
+    const bool copy_uv_in = nv12_mode == MI_UV_COPY;
+    const size_t in_bytes = ybytes + (copy_uv_in ? uvbytes : 0);
+    const size_t frame_bytes = ybytes + uvbytes;
+    mi_status st;
+    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, in_bytes))) return st;
+    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, frame_bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, frame_bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, frame_bytes))) return st;
+    hipStream_t s = c->stream;
+    copy_rows(c->h_pin_in, (size_t)width, src, src_step, width, height);
+    if (copy_uv_in) memcpy(c->h_pin_in + ybytes, src + ybytes, uvbytes);       // tightly packed NV12 (src_step == width)
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, c->h_pin_in, in_bytes, hipMemcpyHostToDevice, s));
+    PlaneArgs a{c->d_stage_in, (size_t)width, frame_bytes, c->d_stage_out, (size_t)width, frame_bytes, width, height, 1};
+    UVJob uv{};
+    if (nv12_mode >= 0) uv = nv12_uv(c->d_stage_in, c->d_stage_out, width, height, (mi_uv_mode)nv12_mode);
+    st = is_clahe ? clahe_dev(c, s, a, clip_limit, tiles_x, tiles_y, nv12_mode >= 0 ? &uv : nullptr)
+                  : equalize_dev(c, s, a, nv12_mode >= 0 ? &uv : nullptr);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, frame_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    copy_rows(dst, dst_step, c->h_pin_out, (size_t)width, width, height);
+    if (uvbytes) memcpy(dst + ybytes, c->h_pin_out + ybytes, uvbytes);
+    return MI_OK;
+}
+
+mi_status mi_equalize_hist_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height)
+{
+    ENTER(c);
+    PlaneArgs a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0) return st;
+    return host_op(c, src, src_step, dst, dst_step, width, height, -1, false, 0.0, 0, 0);
+}
+
+mi_status mi_clahe_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height,
+                      double clip_limit, int tiles_x, int tiles_y)
+{
+    ENTER(c);
+    PlaneArgs a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
+    mi_status st = check_plane(c, a, true);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0) return MI_OK;
+    return host_op(c, src, src_step, dst, dst_step, width, height, -1, true, clip_limit, tiles_x, tiles_y);
+}
+
+mi_status mi_equalize_hist_nv12(mi_ctx* c, const uint8_t* in, uint8_t* out, int width, int height, mi_uv_mode uv_mode)
+{
+    ENTER(c);
+    if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    PlaneArgs a{in, (size_t)std::max(width, 0), 0, out, (size_t)std::max(width, 0), 0, width, height, 1};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0) return st;
+    return host_op(c, in, (size_t)width, out, (size_t)width, width, height, (int)uv_mode, false, 0.0, 0, 0);
+}
+
+mi_status mi_clahe_nv12(mi_ctx* c, const uint8_t* in, uint8_t* out, int width, int height, mi_uv_mode uv_mode,
+                        double clip_limit, int tiles_x, int tiles_y)
+{
+    ENTER(c);
+    if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    PlaneArgs a{in, (size_t)std::max(width, 0), 0, out, (size_t)std::max(width, 0), 0, width, height, 1};
+    mi_status st = check_plane(c, a, true);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0) return MI_OK;
+    return host_op(c, in, (size_t)width, out, (size_t)width, width, height, (int)uv_mode, true, clip_limit, tiles_x, tiles_y);
+}
+
+}  // extern "C"

@@ -1,0 +1,12 @@
+"""ctypes view of libmi_lumaeq.so (include/mi_lumaeq.h) for tests and bench.py.
+
+This is glue, not the product: the product is the C ABI + HIP kernels in ../../csrc and the C++
+cv::Mat adapter in ../../cxx.  Nothing here computes pixels; there is no CPU fallback -- if the
+library or a GPU is missing the calls raise.
+"""
+from .capi import (Context, MiError, lib, lib_path, device_count, version, status_str,
+                   UV_FILL128, UV_COPY, KERNEL_NAMES, DECLARED_SYMBOLS)
+from . import synth, shard
+
+__all__ = ["Context", "MiError", "lib", "lib_path", "device_count", "version", "status_str",
+           "UV_FILL128", "UV_COPY", "KERNEL_NAMES", "DECLARED_SYMBOLS", "synth", "shard"]

@@ -1,0 +1,260 @@
+"""ctypes binding of include/mi_lumaeq.h.  Fails loudly when the HIP library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_ROOT = Path(__file__).resolve().parents[2]          # opencv-opencl_amd/
+_LIB_PATH = _ROOT / "lib" / "libmi_lumaeq.so"
+
+UV_FILL128, UV_COPY = 0, 1
+KERNEL_NAMES = ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
+                "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel"]
+
+# every extern "C" symbol include/mi_lumaeq.h declares (tests check the .so exports them all)
+DECLARED_SYMBOLS = [
+    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_device", "mi_ctx_last_hip_error", "mi_ctx_last_error_msg",
+    "mi_status_str", "mi_version", "mi_device_count",
+    "mi_equalize_hist_u8", "mi_clahe_u8", "mi_equalize_hist_nv12", "mi_clahe_nv12",
+    "mi_equalize_hist_u8_batch_dev", "mi_clahe_u8_batch_dev",
+    "mi_equalize_hist_nv12_batch_dev", "mi_clahe_nv12_batch_dev",
+    "mi_hist_u8_batch_dev", "mi_equalize_lut_batch_dev", "mi_lut_apply_u8_batch_dev",
+    "mi_clahe_tile_luts_batch_dev",
+    "mi_ctx_set_profiling", "mi_ctx_profile_read", "mi_kernel_name",
+]
+
+_K = len(KERNEL_NAMES)
+
+
+class _Profile(C.Structure):
+    _fields_ = [("total_ms", C.c_double * _K), ("launches", C.c_uint64 * _K)]
+
+
+class MiError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{what}: {status_str(status)}" + (f" ({detail})" if detail else ""))
+
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("MI_LUMAEQ_LIB", str(_LIB_PATH)))
+
+
+def lib() -> C.CDLL:
+    """Load libmi_lumaeq.so.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise FileNotFoundError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C opencv-opencl_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(str(p))
+    vp, sz, i, d, i64 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int64
+    L.mi_ctx_create.argtypes = [i, C.POINTER(vp)]
+    L.mi_ctx_destroy.argtypes = [vp]; L.mi_ctx_destroy.restype = None
+    L.mi_ctx_device.argtypes = [vp]
+    L.mi_ctx_last_hip_error.argtypes = [vp]
+    L.mi_ctx_last_error_msg.argtypes = [vp]; L.mi_ctx_last_error_msg.restype = C.c_char_p
+    L.mi_status_str.argtypes = [i]; L.mi_status_str.restype = C.c_char_p
+    L.mi_version.restype = C.c_char_p
+    L.mi_kernel_name.argtypes = [i]; L.mi_kernel_name.restype = C.c_char_p
+    L.mi_equalize_hist_u8.argtypes = [vp, vp, sz, vp, sz, i, i]
+    L.mi_clahe_u8.argtypes = [vp, vp, sz, vp, sz, i, i, d, i, i]
+    L.mi_equalize_hist_nv12.argtypes = [vp, vp, vp, i, i, i]
+    L.mi_clahe_nv12.argtypes = [vp, vp, vp, i, i, i, d, i, i]
+    L.mi_equalize_hist_u8_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, vp]
+    L.mi_clahe_u8_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, d, i, i, vp]
+    L.mi_equalize_hist_nv12_batch_dev.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    L.mi_clahe_nv12_batch_dev.argtypes = [vp, vp, vp, i, i, i, i, d, i, i, vp]
+    L.mi_hist_u8_batch_dev.argtypes = [vp, vp, sz, sz, i, i, i, vp, vp]
+    L.mi_equalize_lut_batch_dev.argtypes = [vp, vp, i64, i, vp, vp]
+    L.mi_lut_apply_u8_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, vp, vp]
+    L.mi_clahe_tile_luts_batch_dev.argtypes = [vp, vp, sz, sz, i, i, i, d, i, i, vp, vp]
+    L.mi_ctx_set_profiling.argtypes = [vp, i]
+    L.mi_ctx_profile_read.argtypes = [vp, C.POINTER(_Profile), i]
+    _lib = L
+    return L
+
+
+def status_str(s: int) -> str:
+    try:
+        return lib().mi_status_str(int(s)).decode()
+    except Exception:
+        return f"status {s}"
+
+
+def version() -> str:
+    return lib().mi_version().decode()
+
+
+def device_count() -> int:
+    return int(lib().mi_device_count())
+
+
+def _host2d(a: np.ndarray, name: str) -> np.ndarray:
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.ndim != 2:
+        raise MiError(2, name, "expected a 2-D uint8 ndarray (CV_8UC1)")
+    if a.size and a.strides[1] != 1:
+        raise MiError(1, name, "pixel stride must be 1")
+    return a
+
+
+def _step(a: np.ndarray) -> int:
+    return int(a.strides[0]) if a.shape[0] > 1 else max(int(a.strides[0]), a.shape[1])
+
+
+def _dptr(t) -> int:
+    """Device pointer of a torch CUDA tensor (or a raw int)."""
+    if isinstance(t, int):
+        return t
+    if not t.is_cuda:
+        raise MiError(1, "device pointer", "tensor is not on a HIP device")
+    return int(t.data_ptr())
+
+
+class Context:
+    """mi_ctx wrapper.  One per (thread x device), like the reference's per-worker OpenCL objects."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        rc = lib().mi_ctx_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise MiError(rc, f"mi_ctx_create(device={device})")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().mi_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc: int, what: str):
+        if rc != 0:
+            raise MiError(rc, what, lib().mi_ctx_last_error_msg(self._h).decode())
+
+    # ---- host-pointer forms (numpy = stand-in for cv::Mat memory) ----
+    def equalize_hist(self, src: np.ndarray, dst: np.ndarray | None = None) -> np.ndarray:
+        src = _host2d(src, "equalize_hist")
+        if dst is None or dst.shape != src.shape or dst.dtype != np.uint8:
+            dst = np.empty(src.shape, np.uint8)      # Mat::create semantics: reallocate only on mismatch
+        _host2d(dst, "equalize_hist")
+        h, w = src.shape
+        self._chk(lib().mi_equalize_hist_u8(self._h, src.ctypes.data, _step(src), dst.ctypes.data, _step(dst), w, h),
+                  "mi_equalize_hist_u8")
+        return dst
+
+    def clahe(self, src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_y: int = 8,
+              dst: np.ndarray | None = None) -> np.ndarray:
+        src = _host2d(src, "clahe")
+        if dst is None or dst.shape != src.shape or dst.dtype != np.uint8:
+            dst = np.empty(src.shape, np.uint8)
+        h, w = src.shape
+        self._chk(lib().mi_clahe_u8(self._h, src.ctypes.data, _step(src), dst.ctypes.data, _step(dst), w, h,
+                                    float(clip_limit), int(tiles_x), int(tiles_y)), "mi_clahe_u8")
+        return dst
+
+    def equalize_hist_nv12(self, frame: np.ndarray, width: int, height: int, uv_mode: int = UV_FILL128,
+                           out: np.ndarray | None = None) -> np.ndarray:
+        n = width * height + (width * height) // 2
+        frame = np.ascontiguousarray(frame, np.uint8).reshape(-1)
+        if frame.size < n:
+            raise MiError(1, "equalize_hist_nv12", "frame smaller than W*H*3/2")
+        if out is None:
+            out = np.empty(n, np.uint8)
+        self._chk(lib().mi_equalize_hist_nv12(self._h, frame.ctypes.data, out.ctypes.data, width, height, uv_mode),
+                  "mi_equalize_hist_nv12")
+        return out
+
+    def clahe_nv12(self, frame: np.ndarray, width: int, height: int, uv_mode: int = UV_FILL128,
+                   clip_limit: float = 2.0, tiles_x: int = 8, tiles_y: int = 8,
+                   out: np.ndarray | None = None) -> np.ndarray:
+        n = width * height + (width * height) // 2
+        frame = np.ascontiguousarray(frame, np.uint8).reshape(-1)
+        if frame.size < n:
+            raise MiError(1, "clahe_nv12", "frame smaller than W*H*3/2")
+        if out is None:
+            out = np.empty(n, np.uint8)
+        self._chk(lib().mi_clahe_nv12(self._h, frame.ctypes.data, out.ctypes.data, width, height, uv_mode,
+                                      float(clip_limit), int(tiles_x), int(tiles_y)), "mi_clahe_nv12")
+        return out
+
+    # ---- device-resident batched forms (torch tensors only carry the memory) ----
+    def equalize_hist_batch_dev(self, src, dst, width, height, n_frames, src_step=None, src_frame=None,
+                                dst_step=None, dst_frame=None, stream=0):
+        ss = width if src_step is None else src_step
+        ds = width if dst_step is None else dst_step
+        sf = ss * height if src_frame is None else src_frame
+        df = ds * height if dst_frame is None else dst_frame
+        self._chk(lib().mi_equalize_hist_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df,
+                                                      width, height, n_frames, stream), "mi_equalize_hist_u8_batch_dev")
+
+    def clahe_batch_dev(self, src, dst, width, height, n_frames, clip_limit, tiles_x, tiles_y,
+                        src_step=None, src_frame=None, dst_step=None, dst_frame=None, stream=0):
+        ss = width if src_step is None else src_step
+        ds = width if dst_step is None else dst_step
+        sf = ss * height if src_frame is None else src_frame
+        df = ds * height if dst_frame is None else dst_frame
+        self._chk(lib().mi_clahe_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df, width, height,
+                                              n_frames, float(clip_limit), tiles_x, tiles_y, stream),
+                  "mi_clahe_u8_batch_dev")
+
+    def equalize_hist_nv12_batch_dev(self, d_in, d_out, width, height, n_frames, uv_mode=UV_FILL128, stream=0):
+        self._chk(lib().mi_equalize_hist_nv12_batch_dev(self._h, _dptr(d_in), _dptr(d_out), width, height,
+                                                        n_frames, uv_mode, stream), "mi_equalize_hist_nv12_batch_dev")
+
+    def clahe_nv12_batch_dev(self, d_in, d_out, width, height, n_frames, uv_mode=UV_FILL128,
+                             clip_limit=2.0, tiles_x=8, tiles_y=8, stream=0):
+        self._chk(lib().mi_clahe_nv12_batch_dev(self._h, _dptr(d_in), _dptr(d_out), width, height, n_frames,
+                                                uv_mode, float(clip_limit), tiles_x, tiles_y, stream),
+                  "mi_clahe_nv12_batch_dev")
+
+    # ---- stages ----
+    def hist_batch_dev(self, src, width, height, n_frames, d_hist, src_step=None, src_frame=None, stream=0):
+        ss = width if src_step is None else src_step
+        sf = ss * height if src_frame is None else src_frame
+        self._chk(lib().mi_hist_u8_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
+                                             _dptr(d_hist), stream), "mi_hist_u8_batch_dev")
+
+    def equalize_lut_batch_dev(self, d_hist, total, n_frames, d_lut, stream=0):
+        self._chk(lib().mi_equalize_lut_batch_dev(self._h, _dptr(d_hist), int(total), n_frames, _dptr(d_lut), stream),
+                  "mi_equalize_lut_batch_dev")
+
+    def lut_apply_batch_dev(self, src, dst, width, height, n_frames, d_lut, src_step=None, src_frame=None,
+                            dst_step=None, dst_frame=None, stream=0):
+        ss = width if src_step is None else src_step
+        ds = width if dst_step is None else dst_step
+        sf = ss * height if src_frame is None else src_frame
+        df = ds * height if dst_frame is None else dst_frame
+        self._chk(lib().mi_lut_apply_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df, width, height,
+                                                  n_frames, _dptr(d_lut), stream), "mi_lut_apply_u8_batch_dev")
+
+    def clahe_tile_luts_batch_dev(self, src, width, height, n_frames, clip_limit, tiles_x, tiles_y, d_luts,
+                                  src_step=None, src_frame=None, stream=0):
+        ss = width if src_step is None else src_step
+        sf = ss * height if src_frame is None else src_frame
+        self._chk(lib().mi_clahe_tile_luts_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
+                                                     float(clip_limit), tiles_x, tiles_y, _dptr(d_luts), stream),
+                  "mi_clahe_tile_luts_batch_dev")
+
+    # ---- profiling ----
+    def set_profiling(self, on: bool):
+        self._chk(lib().mi_ctx_set_profiling(self._h, 1 if on else 0), "mi_ctx_set_profiling")
+
+    def profile_read(self, reset: bool = True) -> dict:
+        p = _Profile()
+        self._chk(lib().mi_ctx_profile_read(self._h, C.byref(p), 1 if reset else 0), "mi_ctx_profile_read")
+        return {KERNEL_NAMES[k]: {"total_ms": p.total_ms[k], "launches": int(p.launches[k])} for k in range(_K)}

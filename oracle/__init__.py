@@ -1,0 +1,158 @@
+"""CPU oracle for the luma-equalization hot path -- TEST INFRASTRUCTURE, never the product.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  The shipped path (opencv-opencl_amd/) never does and has no CPU fallback.
+
+PARITY UNPINNED: the arithmetic of the reference path lives in OpenCV 4.4 (third-party, absent
+from /root/reference and from this image); see the header of ``lumaeq_oracle.c``.
+
+Two independent restatements are provided so they can be checked against each other:
+  * ``c``  -- ctypes view of ``lumaeq_oracle.c`` (fast; also the CPU baseline),
+  * ``np_*`` functions in ``np_oracle.py`` -- numpy / pure-Python, small inputs only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "build" / "liblumaeq_oracle.so"
+_lib = None
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force: bool = False) -> Path:
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    src = _HERE / "lumaeq_oracle.c"
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-s"] + (["-B"] if force else []), check=True)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(str(_LIB_PATH))
+        L.orc_set_threads.argtypes = [ctypes.c_int]
+        L.orc_set_threads.restype = ctypes.c_int
+        L.orc_hist_u8.argtypes = [_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _i32p]
+        L.orc_equalize_lut.argtypes = [_i32p, ctypes.c_int64, _u8p, ctypes.POINTER(ctypes.c_int)]
+        L.orc_lut_apply_u8.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t,
+                                       ctypes.c_int, ctypes.c_int, _u8p]
+        L.orc_equalize_hist_u8.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t,
+                                           ctypes.c_int, ctypes.c_int]
+        L.orc_clahe_tile_luts.argtypes = [_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, _u8p]
+        L.orc_clahe_u8.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        L.orc_nv12_frame.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        for f in (L.orc_hist_u8, L.orc_equalize_lut, L.orc_lut_apply_u8, L.orc_equalize_hist_u8,
+                  L.orc_clahe_tile_luts, L.orc_clahe_u8, L.orc_nv12_frame):
+            f.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def set_threads(n: int) -> int:
+    """Set the OpenMP thread count of the C restatement; returns the count in effect."""
+    return lib().orc_set_threads(int(n))
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with status {rc}")
+
+
+def _as2d(a: np.ndarray) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise TypeError("oracle: expected a 2-D uint8 array (CV_8UC1)")
+    if a.size and a.strides[1] != 1:
+        raise ValueError("oracle: pixel stride must be 1")
+    return a
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_u8p)
+
+
+def _step(a: np.ndarray) -> int:
+    return int(a.strides[0]) if a.shape[0] > 1 else max(int(a.strides[0]), a.shape[1])
+
+
+def hist(src: np.ndarray) -> np.ndarray:
+    src = _as2d(src)
+    h = np.zeros(256, np.int32)
+    _check(lib().orc_hist_u8(_ptr(src), _step(src), src.shape[1], src.shape[0],
+                             h.ctypes.data_as(_i32p)), "hist")
+    return h
+
+
+def equalize_lut(h: np.ndarray, total: int):
+    h = np.ascontiguousarray(h, np.int32)
+    lut = np.zeros(256, np.uint8)
+    first = ctypes.c_int(-1)
+    _check(lib().orc_equalize_lut(h.ctypes.data_as(_i32p), int(total), _ptr(lut),
+                                  ctypes.byref(first)), "equalize_lut")
+    return lut, first.value
+
+
+def equalize_hist(src: np.ndarray, dst: np.ndarray | None = None) -> np.ndarray:
+    """cv::equalizeHist semantics on a 2-D uint8 array (rows may be strided views)."""
+    src = _as2d(src)
+    if dst is None:
+        dst = np.empty(src.shape, np.uint8)
+    dst = _as2d(dst)
+    if dst.shape != src.shape:
+        raise ValueError("dst shape mismatch")
+    if src.size == 0:
+        return dst
+    _check(lib().orc_equalize_hist_u8(_ptr(src), _step(src), _ptr(dst), _step(dst),
+                                      src.shape[1], src.shape[0]), "equalize_hist")
+    return dst
+
+
+def clahe_tile_luts(src: np.ndarray, clip_limit: float, tiles_x: int, tiles_y: int) -> np.ndarray:
+    src = _as2d(src)
+    luts = np.zeros((tiles_y * tiles_x, 256), np.uint8)
+    _check(lib().orc_clahe_tile_luts(_ptr(src), _step(src), src.shape[1], src.shape[0],
+                                     float(clip_limit), tiles_x, tiles_y, _ptr(luts)), "clahe_tile_luts")
+    return luts
+
+
+def clahe(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_y: int = 8,
+          dst: np.ndarray | None = None) -> np.ndarray:
+    """cv::createCLAHE(clip_limit, Size(tiles_x, tiles_y))->apply semantics."""
+    src = _as2d(src)
+    if dst is None:
+        dst = np.empty(src.shape, np.uint8)
+    dst = _as2d(dst)
+    if src.size == 0:
+        return dst
+    _check(lib().orc_clahe_u8(_ptr(src), _step(src), _ptr(dst), _step(dst), src.shape[1],
+                              src.shape[0], float(clip_limit), tiles_x, tiles_y), "clahe")
+    return dst
+
+
+def nv12_frame(frame: np.ndarray, width: int, height: int, uv_mode: int = 0, op: int = 0,
+               clip_limit: float = 2.0, tiles_x: int = 8, tiles_y: int = 8) -> np.ndarray:
+    """Whole tightly packed NV12 frame: op on Y, UV = 128 (uv_mode 0) or copied (uv_mode 1)."""
+    frame = np.ascontiguousarray(frame, np.uint8).reshape(-1)
+    n = width * height + (width * height) // 2
+    if frame.size < n:
+        raise ValueError("NV12 frame too small")
+    out = np.empty(n, np.uint8)
+    _check(lib().orc_nv12_frame(_ptr(frame), _ptr(out), width, height, uv_mode, op,
+                                float(clip_limit), tiles_x, tiles_y), "nv12_frame")
+    return out
+
+
+from .np_oracle import np_equalize_hist, np_clahe, np_clahe_geometry  # noqa: E402,F401

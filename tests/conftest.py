@@ -1,0 +1,51 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "opencv-opencl_amd" / "python"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly, never pass on a fallback: leave gpu tests
+    # selected; they raise from mi_ctx_create.  Without -m they are skipped when no GPU exists.
+    if config.getoption("-m"):
+        return
+    if not _have_gpu():
+        skip = pytest.mark.skip(reason="no HIP device")
+        for it in items:
+            if "gpu" in it.keywords:
+                it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libmi_lumaeq.so, built on demand (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    import mi_lumaeq
+    if not mi_lumaeq.lib_path().exists():
+        subprocess.run(["make", "-C", str(ROOT / "opencv-opencl_amd" / "csrc")], check=True)
+    return mi_lumaeq.lib()
+
+
+@pytest.fixture(scope="session")
+def ctx(built_lib):
+    import mi_lumaeq
+    c = mi_lumaeq.Context(0)
+    yield c
+    c.close()

@@ -1,0 +1,210 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP path through the C ABI vs the CPU oracle,
+bit-exact (integer/byte work; the float steps are reproduced operation by operation)."""
+import numpy as np
+import pytest
+
+import mi_lumaeq
+import oracle
+from mi_lumaeq import synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+SMALL = [(1, 1), (1, 17), (3, 4097), (47, 63), (48, 64), (15, 16), (135, 241), (270, 480), (360, 640)]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("shape", SMALL, ids=str)
+@pytest.mark.parametrize("dist", synth.DISTS)
+def test_equalize_host_form(ctx, shape, dist):
+    h, w = shape
+    src = synth.y_plane(w, h, dist, 21)
+    assert np.array_equal(ctx.equalize_hist(src), oracle.equalize_hist(src))
+
+
+def test_equalize_kats(ctx):
+    assert ctx.equalize_hist(np.array([[50, 50, 100, 200]], np.uint8)).tolist() == [[0, 0, 128, 255]]
+    a = np.array([0] + [1] * 253 + [2] * 2 + [3] * 255, np.uint8)[None, :]
+    o = ctx.equalize_hist(a)
+    assert (o[0, 0], o[0, 1], o[0, 254], o[0, 256]) == (0, 126, 128, 255)      # ties to even
+    assert (ctx.equalize_hist(np.full((9, 13), 77, np.uint8)) == 77).all()
+    assert ctx.equalize_hist(np.array([[10, 10, 10, 20]], np.uint8)).tolist() == [[0, 0, 0, 255]]
+    assert ctx.equalize_hist(np.arange(256, dtype=np.uint8)[None, :]).reshape(-1).tolist() == list(range(256))
+
+
+def test_equalize_empty_and_errors(ctx):
+    e = np.empty((0, 0), np.uint8)
+    assert ctx.equalize_hist(e).shape == (0, 0)
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.equalize_hist(np.zeros((4, 4), np.float32))
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.clahe(np.zeros((4, 4), np.uint8), 2.0, 0, 8)
+
+
+def test_equalize_strided_roi_and_inplace(ctx):
+    big = synth.y_plane(300, 200, "D2", 5)
+    view = big[10:190, 37:291]                      # step 300 > width 254, unaligned start
+    want = oracle.equalize_hist(view)
+    assert np.array_equal(ctx.equalize_hist(view), want)
+    out = np.zeros((200, 320), np.uint8)
+    oview = out[3:183, 5:259]
+    ctx.equalize_hist(view, oview)                 # caller-owned dst written in place (nextimprovement.cpp:164-168)
+    assert np.array_equal(oview, want) and out[:3].sum() == 0 and out[:, :5].sum() == 0
+    buf = view.copy()
+    ctx.equalize_hist(buf, buf)
+    assert np.array_equal(buf, want)
+
+
+@pytest.mark.parametrize("wh", [(1920, 1080), (3840, 2160)], ids=str)
+@pytest.mark.parametrize("dist", synth.DISTS)
+def test_equalize_full_size_frames(ctx, wh, dist):
+    """BASELINE.json configs[0]/[1]: one 1080p / 4K frame, bit-exact vs the oracle."""
+    w, h = wh
+    src = synth.y_plane(w, h, dist, 1)
+    assert np.array_equal(ctx.equalize_hist(src), oracle.equalize_hist(src))
+
+
+def test_stage_apis(ctx):
+    w, h, n = 640, 360, 3
+    ys = np.stack([synth.y_plane(w, h, d, 30 + i) for i, d in enumerate(("D1", "D2", "D3"))])
+    d_src = dev(ys)
+    d_hist = torch.zeros((n, 256), dtype=torch.int32, device="cuda:0")
+    ctx.hist_batch_dev(d_src, w, h, n, d_hist)
+    d_lut = torch.zeros((n, 256), dtype=torch.uint8, device="cuda:0")
+    ctx.equalize_lut_batch_dev(d_hist, w * h, n, d_lut)
+    d_dst = torch.empty_like(d_src)
+    ctx.lut_apply_batch_dev(d_src, d_dst, w, h, n, d_lut)
+    torch.cuda.synchronize()
+    hist, lut, dst = d_hist.cpu().numpy(), d_lut.cpu().numpy(), d_dst.cpu().numpy()
+    for k in range(n):
+        oh = oracle.hist(ys[k])
+        assert np.array_equal(hist[k], oh)
+        ol, first = oracle.equalize_lut(oh, w * h)
+        assert np.array_equal(lut[k][first:], ol[first:]) or (oh[first] == w * h and (lut[k] == first).all())
+        assert np.array_equal(dst[k], oracle.equalize_hist(ys[k]))
+
+
+@pytest.mark.parametrize("uv_mode", [0, 1])
+def test_nv12_batch_dev(ctx, uv_mode):
+    w, h, n = 640, 360, 5
+    frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 40 + k) for k in range(n)])
+    d_in = dev(frames)
+    d_out = torch.empty_like(d_in)
+    ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), k
+    # in place
+    ctx.equalize_hist_nv12_batch_dev(d_in, d_in, w, h, n, uv_mode, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_in.cpu().numpy(), out)
+
+
+def test_nv12_host_form(ctx):
+    w, h = 322, 178                                 # odd-ish, unaligned UV start
+    f = synth.nv12_frame(w, h, "D2", 77)
+    for uv_mode in (0, 1):
+        assert np.array_equal(ctx.equalize_hist_nv12(f, w, h, uv_mode), oracle.nv12_frame(f, w, h, uv_mode=uv_mode, op=0))
+        assert np.array_equal(ctx.clahe_nv12(f, w, h, uv_mode, 2.0, 8, 8),
+                              oracle.nv12_frame(f, w, h, uv_mode=uv_mode, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
+
+
+CLAHE_CFG = [(2.0, 8, 8), (3.0, 4, 4), (40.0, 8, 8), (0.0, 3, 5), (1.5, 1, 1), (2.0, 16, 2), (2.0, 70, 3)]
+
+
+@pytest.mark.parametrize("shape", SMALL, ids=str)
+@pytest.mark.parametrize("cfg", CLAHE_CFG, ids=str)
+def test_clahe_host_form(ctx, shape, cfg):
+    h, w = shape
+    clip, tx, ty = cfg
+    for dist in ("D1", "D2", "D3"):
+        src = synth.y_plane(w, h, dist, 22)
+        assert np.array_equal(ctx.clahe(src, clip, tx, ty), oracle.clahe(src, clip, tx, ty)), dist
+
+
+def test_clahe_kats(ctx):
+    assert (ctx.clahe(np.full((4, 4), 7, np.uint8), 2.0, 1, 1) == 32).all()             # CL-1
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    lut = oracle.clahe_tile_luts(src, 4.0, 1, 1)[0]
+    assert np.array_equal(ctx.clahe(src, 4.0, 1, 1), lut[src])                           # CL-2
+
+
+def test_clahe_tile_luts_stage(ctx):
+    for (w, h, tx, ty, clip) in [(640, 360, 8, 8, 2.0), (16, 15, 8, 8, 2.0), (241, 135, 4, 4, 3.0), (1919, 1079, 4, 4, 3.0)]:
+        src = synth.y_plane(w, h, "D2", 50)
+        d_luts = torch.zeros((tx * ty, 256), dtype=torch.uint8, device="cuda:0")
+        ctx.clahe_tile_luts_batch_dev(dev(src), w, h, 1, clip, tx, ty, d_luts)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_luts.cpu().numpy(), oracle.clahe_tile_luts(src, clip, tx, ty)), (w, h, tx, ty)
+
+
+@pytest.mark.parametrize("wh,cfg", [((3840, 2160), (2.0, 8, 8)), ((1920, 1080), (2.0, 8, 8)), ((1919, 1079), (3.0, 4, 4)),
+                                    ((1280, 720), (2.0, 8, 8))], ids=str)
+def test_clahe_full_size(ctx, wh, cfg):
+    """BASELINE.json configs[2] (4K, 8x8, clip 2.0) and the odd hun.png-shaped case of clahe1frame.cpp."""
+    w, h = wh
+    clip, tx, ty = cfg
+    for dist in ("D1", "D2"):
+        src = synth.y_plane(w, h, dist, 2)
+        assert np.array_equal(ctx.clahe(src, clip, tx, ty), oracle.clahe(src, clip, tx, ty)), dist
+
+
+def test_clahe_strided_and_batch(ctx):
+    big = synth.y_plane(400, 300, "D2", 6)
+    view = big[7:287, 21:389]
+    want = oracle.clahe(view, 2.0, 8, 8)
+    assert np.array_equal(ctx.clahe(view, 2.0, 8, 8), want)
+    w, h, n = 480, 270, 4
+    frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 3], 60 + k) for k in range(n)])
+    d_in = dev(frames)
+    d_out = torch.empty_like(d_in)
+    ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 1, 2.0, 8, 8)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=1, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8)), k
+
+
+def test_full_size_batch_properties(ctx):
+    """At BASELINE size (4K batch) check size-independent properties instead of the oracle on every
+    frame: a histogram of the output is the LUT-image of the input histogram; constant frames are
+    fixed points; the UV plane is untouched / 128; one frame is compared against the oracle."""
+    w, h, n = 3840, 2160, 8
+    d_in = synth.nv12_batch_torch(w, h, n, "D2", "cuda:0", seed=123)
+    d_in[3, : w * h] = 128
+    d_out = torch.empty_like(d_in)
+    ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.UV_COPY)
+    torch.cuda.synchronize()
+    assert torch.equal(d_in[:, w * h:], d_out[:, w * h:])
+    assert (d_out[3, : w * h] == 128).all()
+    for k in (0, 5):
+        yi, yo = d_in[k, : w * h], d_out[k, : w * h]
+        hi = torch.bincount(yi.to(torch.int64), minlength=256)
+        first = int(torch.nonzero(hi)[0])
+        assert int(yo.min()) == 0 and int(yo.max()) == 255
+        # monotone: sorting pixels by input value sorts them by output value
+        lut = torch.zeros(256, dtype=torch.int64, device="cuda:0")
+        lut[yi.to(torch.int64)] = yo.to(torch.int64)
+        nzv = torch.nonzero(hi).view(-1)
+        assert (torch.diff(lut[nzv]) >= 0).all() and int(lut[first]) == 0
+    k = 5
+    assert np.array_equal(d_out[k].cpu().numpy(), oracle.nv12_frame(d_in[k].cpu().numpy(), w, h, uv_mode=1, op=0))
+
+
+def test_profiling_counters(ctx):
+    w, h, n = 640, 360, 2
+    d_in = dev(np.stack([synth.nv12_frame(w, h, "D1", k) for k in range(n)]))
+    d_out = torch.empty_like(d_in)
+    ctx.profile_read(reset=True)
+    ctx.set_profiling(True)
+    ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
+    p = ctx.profile_read(reset=True)
+    ctx.set_profiling(False)
+    assert p["hist_partial_kernel"]["launches"] == 1 and p["lut_apply_kernel"]["launches"] == 1
+    assert p["lut_apply_kernel"]["total_ms"] > 0

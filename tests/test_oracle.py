@@ -1,0 +1,146 @@
+"""CPU tests of the oracle itself: SURVEY.md Appendix B known answers, structural properties, the
+two independent restatements against each other, and the committed golden fixtures."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from mi_lumaeq import synth
+
+GOLD = Path(__file__).parent / "golden"
+KAT = json.loads((GOLD / "kat.json").read_text())
+
+
+def _kat_src(k):
+    h, w = k["shape"]
+    if "src" in k:
+        return np.array(k["src"], np.uint8).reshape(h, w)
+    if "src_runs" in k:
+        return np.concatenate([np.full(n, v, np.uint8) for v, n in k["src_runs"]]).reshape(h, w)
+    if "src_const" in k:
+        return np.full((h, w), k["src_const"], np.uint8)
+    if "src_arange" in k:
+        return np.arange(k["src_arange"], dtype=np.uint8).reshape(h, w)
+    raise KeyError(k["id"])
+
+
+@pytest.mark.parametrize("k", KAT["equalize"], ids=lambda k: k["id"])
+@pytest.mark.parametrize("impl", ["c", "numpy"])
+def test_equalize_kat(k, impl):
+    src = _kat_src(k)
+    out = oracle.equalize_hist(src) if impl == "c" else oracle.np_equalize_hist(src)
+    if "dst" in k:
+        assert out.reshape(-1).tolist() == k["dst"]
+    if "dst_const" in k:
+        assert (out == k["dst_const"]).all()
+    if "dst_arange" in k:
+        assert out.reshape(-1).tolist() == list(range(k["dst_arange"]))
+    if "lut" in k:                      # EQ-2: tie direction (round half to even)
+        for v, want in k["lut"].items():
+            assert (out[src == int(v)] == want).all(), (v, want)
+
+
+@pytest.mark.parametrize("impl", ["c", "numpy"])
+def test_clahe_kat_cl1(impl):
+    k = KAT["clahe"][0]
+    src = _kat_src(k)
+    f = oracle.clahe if impl == "c" else oracle.np_clahe
+    out = f(src, k["clip"], *k["tiles"])
+    assert (out == k["dst_const"]).all()
+
+
+def test_clahe_kat_cl3_pad_quirk():
+    k = KAT["clahe"][1]
+    h, w = k["shape"]
+    g = oracle.np_clahe_geometry(w, h, 2.0, *k["tiles"])
+    assert [g["ext_w"], g["ext_h"]] == k["ext"] and [g["tile_w"], g["tile_h"]] == k["tile"]
+    # behavioural form: the LUT of the last tile column must be built from REFLECTED columns 14,13,...
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    luts = oracle.clahe_tile_luts(src, 0.0, 8, 8).reshape(8, 8, 256)
+    ext_cols = [16 - 2 - c for c in range(8)]            # index 16+c reads 16-2-c
+    tile = src[0:2][:, [ext_cols[5], ext_cols[6], ext_cols[7]]]     # tile (ty=0, tx=7) = ext cols 21..23
+    hist = np.bincount(tile.reshape(-1), minlength=256)
+    want = np.clip(np.rint(np.cumsum(hist).astype(np.float32) * (np.float32(255) / np.float32(6))), 0, 255)
+    assert np.array_equal(luts[0, 7], want.astype(np.uint8))
+
+
+def test_clahe_grid_1x1_is_plain_lut():
+    """CL-2: with one tile all four taps are the same LUT, so output == LUT0[src] exactly."""
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    lut = oracle.clahe_tile_luts(src, 4.0, 1, 1)[0]
+    assert np.array_equal(oracle.clahe(src, 4.0, 1, 1), lut[src])
+
+
+SHAPES = [(1, 1), (1, 17), (3, 4097), (47, 63), (48, 64), (15, 16), (270, 480), (135, 241)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=str)
+@pytest.mark.parametrize("dist", synth.DISTS)
+def test_c_vs_numpy_equalize(shape, dist):
+    h, w = shape
+    src = synth.y_plane(w, h, dist, 11)
+    assert np.array_equal(oracle.equalize_hist(src), oracle.np_equalize_hist(src))
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=str)
+@pytest.mark.parametrize("cfg", [(2.0, 8, 8), (3.0, 4, 4), (40.0, 8, 8), (0.0, 3, 5), (1.5, 1, 1), (2.0, 16, 2)], ids=str)
+def test_c_vs_numpy_clahe(shape, cfg):
+    h, w = shape
+    clip, tx, ty = cfg
+    for dist in ("D1", "D2", "D3"):
+        src = synth.y_plane(w, h, dist, 12)
+        assert np.array_equal(oracle.clahe(src, clip, tx, ty), oracle.np_clahe(src, clip, tx, ty)), dist
+
+
+def test_equalize_properties():
+    rng = np.random.default_rng(9)
+    src = np.clip(rng.normal(100, 20, (120, 200)), 0, 255).astype(np.uint8)
+    h = oracle.hist(src)
+    assert h.sum() == src.size and np.array_equal(h, np.bincount(src.reshape(-1), minlength=256))
+    lut, first = oracle.equalize_lut(h, src.size)
+    nz = np.flatnonzero(h)
+    assert first == nz[0] and lut[first] == 0 and lut[nz[-1]] == 255
+    assert (np.diff(lut[first:].astype(int)) >= 0).all()             # monotone non-decreasing
+    # permutation invariance of pixel order
+    perm = rng.permutation(src.size)
+    a = oracle.equalize_hist(src).reshape(-1)[perm]
+    b = oracle.equalize_hist(src.reshape(-1)[perm].reshape(src.shape)).reshape(-1)
+    assert np.array_equal(a, b)
+    # idempotent LUT application through strided views and in place
+    big = np.zeros((130, 260), np.uint8)
+    view = big[5:125, 30:230]
+    view[:] = src
+    out = oracle.equalize_hist(view)
+    assert np.array_equal(out, oracle.equalize_hist(src))
+    oracle.equalize_hist(view, view)
+    assert np.array_equal(view, out) and big[0].sum() == 0
+
+
+def test_nv12_frame_uv_modes():
+    w, h = 64, 36
+    f = synth.nv12_frame(w, h, "D2", 3)
+    fill = oracle.nv12_frame(f, w, h, uv_mode=0)
+    copy = oracle.nv12_frame(f, w, h, uv_mode=1)
+    y = oracle.equalize_hist(f[: w * h].reshape(h, w)).reshape(-1)
+    assert np.array_equal(fill[: w * h], y) and np.array_equal(copy[: w * h], y)
+    assert (fill[w * h:] == 128).all() and np.array_equal(copy[w * h:], f[w * h:])
+
+
+def test_golden_fixtures():
+    """Committed fixtures (tests/golden/make_golden.py): inputs from seeds, outputs from the oracle at
+    the time of commit -- guards against silent drift of the restatement."""
+    z = np.load(GOLD / "golden_small.npz")
+    names = sorted({k.rsplit("__", 1)[0] for k in z.files})
+    assert names
+    for n in names:
+        src = z[n + "__src"]
+        if n.startswith("eq"):
+            got = oracle.equalize_hist(src)
+        else:
+            clip, tx, ty = z[n + "__cfg"]
+            got = oracle.clahe(src, float(clip), int(tx), int(ty))
+        assert np.array_equal(got, z[n + "__dst"]), n
