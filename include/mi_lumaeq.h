@@ -57,6 +57,9 @@ typedef enum mi_uv_mode { MI_UV_FILL128 = 0, MI_UV_COPY = 1 } mi_uv_mode;
 
 typedef struct mi_ctx mi_ctx;    /* opaque: device id, streams, pinned staging, device scratch */
 
+/* stream argument value selecting the context's own stream (see the device-resident forms) */
+#define MI_STREAM_CTX ((void*)(uintptr_t)-1)
+
 /* ---- context ------------------------------------------------------------------------------
  * Replaces the per-worker OpenCL objects of the reference (context/queue/kernel/3 buffers,
  * OpenCLequalHist.cpp:106-192): scratch is allocated lazily for the largest frame seen and
@@ -96,7 +99,12 @@ mi_status mi_clahe_nv12(mi_ctx* ctx, const uint8_t* in, uint8_t* out, int width,
 
 /* ---- device-resident, batched, stream-ordered forms -------------------------------------------
  * Pointers are device pointers on the context's device.  `stream` is a hipStream_t passed as
- * void* (NULL = the context's own stream).  Asynchronous: the call returns after enqueueing.
+ * void*, with HIP's own meaning: NULL is the device's default (null) stream -- what
+ * torch.cuda.current_stream().cuda_stream is unless the caller switched streams.  Pass
+ * MI_STREAM_CTX to use the context's private non-blocking stream (it does NOT order against the
+ * null stream).  Asynchronous: the call returns after enqueueing.  A context owns one set of
+ * scratch buffers: calls that share a context must be issued on one stream at a time (or be
+ * ordered by the caller); use one context per concurrent stream.
  * Frame f of a batch lives at base + f * frame_stride.  These are what a per-GPU worker of the
  * frame-sharded pipeline (reference analogue: worker pool OpenCVequalHist.cpp:397-402)
  * calls, and what bench.py measures. */

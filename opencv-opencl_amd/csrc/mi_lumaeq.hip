@@ -345,7 +345,7 @@ struct Guard {
     Guard guard__(ctx);                                              \
     if (guard__.err != hipSuccess) return fail_hip((ctx), guard__.err, "hipSetDevice")
 
-hipStream_t pick_stream(mi_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+hipStream_t pick_stream(mi_ctx* c, void* stream) { return stream == MI_STREAM_CTX ? c->stream : (hipStream_t)stream; }
 
 // ---- host-pointer plumbing ---------------------------------------------------------------------------
 void copy_rows(uint8_t* dst, size_t dst_step, const uint8_t* src, size_t src_step, int width, int height)

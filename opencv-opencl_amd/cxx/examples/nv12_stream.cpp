@@ -1,0 +1,115 @@
+// nv12_stream.cpp -- the reference's live pipeline with the media I/O removed (GStreamer is out of
+// scope): frames come from a synthetic generator or a raw .nv12 file instead of
+// `v4l2src ... appsink`, go through the same worker-pool + luma-op + NV12-rebuild stage, and leave
+// in frame order to a sink (optional raw file) instead of `appsrc ... omxh264enc`.
+//
+// Mirrors, flag for flag where they still apply:
+//   --workers N (1..8)  --width W  --height H  --fps F           OpenCVequalHist.cpp:262-284
+//   --clipLimit C  --tile T                                      clahevideo.cpp:374-452
+//   2 s status tick: in/out fps, queue depth, errors, backlog    OpenCVequalHist.cpp:200-234,
+//                                                                OpenCLequalHist.cpp:439-508
+// New: --op equalize|clahe, --uv fill128|copy (OpenCVequalHist.cpp:160-162 vs
+// ColoropenCVCwqualHist.cpp:165), --frames N, --input/--output raw NV12 files, --paced.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../mi_pool.hpp"
+
+static bool kv(const char* arg, const char* key, std::string& v, int& i, int argc, char** argv)
+{
+    const std::string k = std::string("--") + key;
+    if (k == arg && i + 1 < argc) { v = argv[++i]; return true; }            // --k v
+    if (strncmp(arg, (k + "=").c_str(), k.size() + 1) == 0) { v = arg + k.size() + 1; return true; }   // --k=v
+    return false;
+}
+
+int main(int argc, char** argv)
+{
+    using namespace micv;
+    int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8;
+    double clip = 2.0;
+    bool paced = false;
+    std::string op = "equalize", uv = "fill128", input, output, v;
+    for (int i = 1; i < argc; ++i) {
+        if (kv(argv[i], "workers", v, i, argc, argv)) workers = std::max(1, std::min(8, atoi(v.c_str())));
+        else if (kv(argv[i], "width", v, i, argc, argv)) width = atoi(v.c_str());
+        else if (kv(argv[i], "height", v, i, argc, argv)) height = atoi(v.c_str());
+        else if (kv(argv[i], "fps", v, i, argc, argv)) fps = atoi(v.c_str());
+        else if (kv(argv[i], "frames", v, i, argc, argv)) frames = atoi(v.c_str());
+        else if (kv(argv[i], "clipLimit", v, i, argc, argv)) clip = atof(v.c_str());
+        else if (kv(argv[i], "tile", v, i, argc, argv)) tile = std::max(1, atoi(v.c_str()));
+        else if (kv(argv[i], "op", v, i, argc, argv)) op = v;
+        else if (kv(argv[i], "uv", v, i, argc, argv)) uv = v;
+        else if (kv(argv[i], "input", v, i, argc, argv)) input = v;
+        else if (kv(argv[i], "output", v, i, argc, argv)) output = v;
+        else if (strcmp(argv[i], "--paced") == 0) paced = true;
+        else fprintf(stderr, "Warning: ignoring unknown arg: %s\n", argv[i]);
+    }
+    if (width <= 0 || height <= 0 || frames <= 0) { fprintf(stderr, "bad size\n"); return 1; }
+    const size_t fb = (size_t)width * height + (size_t)width * height / 2;
+    const int ring = 32;                                            // frames in flight (input + output ring)
+    std::vector<std::vector<unsigned char>> in(ring, std::vector<unsigned char>(fb)), out(ring, std::vector<unsigned char>(fb));
+    FILE* fin = input.empty() ? nullptr : fopen(input.c_str(), "rb");
+    FILE* fout = output.empty() ? nullptr : fopen(output.c_str(), "wb");
+    if (!input.empty() && !fin) { fprintf(stderr, "cannot open %s\n", input.c_str()); return 1; }
+    uint64_t seed = 0x5EED0000;
+    auto synth = [&](std::vector<unsigned char>& f, int k) {
+        uint64_t s = seed + k;
+        for (size_t i = 0; i < fb; i += 8) {
+            s += 0x9E3779B97F4A7C15ull; uint64_t z = s;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+            for (int b = 0; b < 8 && i + b < fb; ++b) f[i + b] = (unsigned char)(64 + ((z >> (8 * b)) & 0x7f));
+        }
+    };
+    try {
+        std::atomic<uint64_t> delivered{0};
+        FramePool pool(workers, width, height, op == "clahe" ? FramePool::CLAHE_OP : FramePool::EQUALIZE,
+                       uv == "copy" ? UV_COPY : UV_FILL128,
+                       [&](const FrameJob& j) {
+                           if (!j.ok) fprintf(stderr, "frame %llu error: %s\n", (unsigned long long)j.index, j.error.c_str());
+                           else if (fout) fwrite(j.out, 1, fb, fout);
+                           delivered.fetch_add(1);
+                       },
+                       clip, Size(tile, tile), ring / (size_t)workers > 2 ? ring / (size_t)workers - 1 : 1);
+        printf("nv12_stream: %dx%d %s uv=%s workers=%d gpus=%d frames=%d%s\n", width, height, op.c_str(), uv.c_str(), workers,
+               getDeviceCount(), frames, paced ? " paced" : "");
+        const auto t0 = std::chrono::steady_clock::now();
+        auto last_tick = t0;
+        uint64_t last_out = 0;
+        for (int k = 0; k < frames; ++k) {
+            // a ring slot may be reused only after its frame was delivered
+            while (delivered.load() + ring <= (uint64_t)k) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            auto& f = in[k % ring];
+            if (fin) { if (fread(f.data(), 1, fb, fin) != fb) { frames = k; break; } }
+            else if (k < ring) synth(f, k);                          // synthetic: reuse the ring's first lap
+            if (paced) std::this_thread::sleep_until(t0 + std::chrono::microseconds((int64_t)k * 1000000 / fps));
+            pool.submit(f.data(), out[k % ring].data());
+            const auto now = std::chrono::steady_clock::now();
+            if (now - last_tick >= std::chrono::seconds(2)) {        // status tick (OpenCVequalHist.cpp:200-234)
+                const uint64_t o = pool.stats().frames_out.load();
+                const double dt = std::chrono::duration<double>(now - last_tick).count();
+                const size_t q = pool.queue_depth();
+                printf("[status] in=%llu out=%llu out_fps=%.1f queue=%zu errors=%llu%s\n", (unsigned long long)pool.stats().frames_in.load(),
+                       (unsigned long long)o, (o - last_out) / dt, q, (unsigned long long)pool.stats().processing_errors.load(),
+                       q > 5 ? "  QUEUE BACKLOG" : "");
+                last_tick = now; last_out = o;
+            }
+        }
+        pool.finish();
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("done: %llu frames in %.3f s = %.1f frames/s (host NV12 in -> host NV12 out, PCIe inclusive), errors=%llu\n",
+               (unsigned long long)pool.stats().frames_out.load(), el, pool.stats().frames_out.load() / el,
+               (unsigned long long)pool.stats().processing_errors.load());
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    if (fin) fclose(fin);
+    if (fout) fclose(fout);
+    return 0;
+}

@@ -11,6 +11,7 @@ _ROOT = Path(__file__).resolve().parents[2]          # opencv-opencl_amd/
 _LIB_PATH = _ROOT / "lib" / "libmi_lumaeq.so"
 
 UV_FILL128, UV_COPY = 0, 1
+STREAM_CTX = C.c_void_p(-1).value      # MI_STREAM_CTX: the context's private stream; 0/None = HIP null stream
 KERNEL_NAMES = ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
                 "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel"]
 
@@ -56,6 +57,14 @@ def lib() -> C.CDLL:
         raise FileNotFoundError(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C opencv-opencl_amd/csrc` (there is no CPU fallback)")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same soname as /opt/rocm's).
+    # If the library were loaded first it would bring in /opt/rocm's runtime and a later `import torch`
+    # would start a second one (its devices then look absent to us).  Importing torch first makes the
+    # dynamic loader resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(str(p))
     vp, sz, i, d, i64 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int64
     L.mi_ctx_create.argtypes = [i, C.POINTER(vp)]

@@ -1,0 +1,129 @@
+// test_adapter.cpp -- C++ parity test of the cv::Mat-style adapter (opencv-opencl_amd/cxx/mi_cv.hpp,
+// mi_pool.hpp) against the CPU oracle.  Written the way the reference's programs use the call
+// (Mat views over NV12 buffers, ROI, preallocated / external dst, try/catch of std::exception).
+// Test code: links oracle/build/liblumaeq_oracle.so as the checker.  Needs a GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../opencv-opencl_amd/cxx/mi_cv.hpp"
+#include "../../opencv-opencl_amd/cxx/mi_pool.hpp"
+
+extern "C" {
+int orc_equalize_hist_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int);
+int orc_clahe_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int, double, int, int);
+int orc_nv12_frame(const uint8_t*, uint8_t*, int, int, int, int, double, int, int);
+}
+
+static int failures = 0;
+#define EXPECT(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); ++failures; } } while (0)
+
+static void fill(std::vector<uint8_t>& v, uint64_t seed)
+{
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (auto& b : v) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; b = (uint8_t)(96 + (s >> 33) % 80); }
+}
+
+int main()
+{
+    using namespace micv;
+    const int W = 640, H = 360;
+    const size_t ysz = (size_t)W * H, uvsz = ysz / 2;
+    std::vector<uint8_t> nv12(ysz + uvsz), ref(ysz + uvsz);
+    fill(nv12, 1);
+
+    // --- OpenCVequalHist.cpp:140-145: Mat over the NV12 buffer, Y ROI clone, preallocated output
+    {
+        Mat nv12_input(H * 3 / 2, W, CV_8UC1, nv12.data());
+        Mat y_plane_in = nv12_input(Rect(0, 0, W, H)).clone();
+        Mat y_plane_out(H, W, CV_8UC1);
+        const unsigned char* before = y_plane_out.data;
+        equalizeHist(y_plane_in, y_plane_out);
+        EXPECT(y_plane_out.data == before);                          // no reallocation when dst matches
+        orc_equalize_hist_u8(nv12.data(), W, ref.data(), W, W, H);
+        EXPECT(memcmp(y_plane_out.data, ref.data(), ysz) == 0);
+    }
+    // --- nextimprovement.cpp:164-168: views straight over input and OUTPUT buffers (external dst)
+    {
+        std::vector<uint8_t> outbuf(ysz + uvsz, 0xEE);
+        Mat y_in(H, W, CV_8UC1, nv12.data());
+        Mat y_out(H, W, CV_8UC1, outbuf.data());
+        equalizeHist(y_in, y_out);
+        EXPECT(y_out.data == outbuf.data() && !y_out.ownsMemory());
+        EXPECT(memcmp(outbuf.data(), ref.data(), ysz) == 0);
+        EXPECT(outbuf[ysz] == 0xEE);                                 // nothing written past the Y plane
+    }
+    // --- dst empty -> created; in place; ROI with step > width
+    {
+        Mat y_in(H, W, CV_8UC1, nv12.data());
+        Mat dst;
+        equalizeHist(y_in, dst);
+        EXPECT(dst.rows == H && dst.cols == W && dst.ownsMemory() && memcmp(dst.data, ref.data(), ysz) == 0);
+        Mat roi = y_in(Rect(17, 9, 301, 200));
+        std::vector<uint8_t> r2((size_t)301 * 200);
+        orc_equalize_hist_u8(roi.data, roi.step, r2.data(), 301, 301, 200);
+        Mat roi_out;
+        equalizeHist(roi, roi_out);
+        EXPECT(roi_out.isContinuous() && memcmp(roi_out.data, r2.data(), r2.size()) == 0);
+        Mat inplace = y_in.clone();
+        equalizeHist(inplace, inplace);
+        EXPECT(memcmp(inplace.data, ref.data(), ysz) == 0);
+        Mat empty;
+        Mat untouched(3, 3, CV_8UC1);
+        untouched.setTo(5);
+        equalizeHist(empty, untouched);                              // empty src: no-op
+        EXPECT(untouched.data[4] == 5);
+    }
+    // --- wrong type throws something derived from std::exception (OpenCVequalHist.cpp:189)
+    {
+        bool threw = false;
+        try { Mat bgr(4, 4, CV_8UC3), o; equalizeHist(bgr, o); } catch (const std::exception& e) { threw = true; EXPECT(strstr(e.what(), "CV_8UC1") != nullptr); }
+        EXPECT(threw);
+    }
+    // --- clahevideo.cpp:178-195: createCLAHE, setters, apply on an ROI VIEW of the NV12 buffer
+    {
+        Mat nv12_in(H * 3 / 2, W, CV_8UC1, nv12.data());
+        Mat y_in = nv12_in(Rect(0, 0, W, H));
+        Mat y_out(H, W, CV_8UC1);
+        Ptr<CLAHE> clahe = createCLAHE(2.0, Size(8, 8));
+        clahe->setClipLimit(2.0);
+        clahe->setTilesGridSize(Size(8, 8));
+        EXPECT(clahe->getClipLimit() == 2.0 && clahe->getTilesGridSize() == Size(8, 8));
+        clahe->apply(y_in, y_out);
+        std::vector<uint8_t> r(ysz);
+        orc_clahe_u8(nv12.data(), W, r.data(), W, W, H, 2.0, 8, 8);
+        EXPECT(memcmp(y_out.data, r.data(), ysz) == 0);
+        // clahe1frame.cpp defaults: clip 3.0, 4x4, odd-sized image (padding path)
+        Mat odd = y_in(Rect(0, 0, 639, 359)).clone();
+        Ptr<CLAHE> c2 = createCLAHE(3.0, Size(4, 4));
+        Mat odd_out(odd.size(), odd.type());
+        c2->apply(odd, odd_out);
+        std::vector<uint8_t> r3((size_t)639 * 359);
+        orc_clahe_u8(odd.data, odd.step, r3.data(), 639, 639, 359, 3.0, 4, 4);
+        EXPECT(memcmp(odd_out.data, r3.data(), r3.size()) == 0);
+        c2->collectGarbage();
+        EXPECT(createCLAHE()->getClipLimit() == 40.0 && createCLAHE()->getTilesGridSize() == Size(8, 8));
+    }
+    // --- worker pool: 3 workers, 24 frames, in-order delivery, both UV modes (A7, A8)
+    for (int uv = 0; uv < 2; ++uv) {
+        const int N = 24;
+        std::vector<std::vector<uint8_t>> in(N, std::vector<uint8_t>(ysz + uvsz)), out(N, std::vector<uint8_t>(ysz + uvsz));
+        for (int k = 0; k < N; ++k) fill(in[k], 100 + k);
+        std::vector<uint64_t> order;
+        {
+            FramePool pool(3, W, H, FramePool::EQUALIZE, uv ? UV_COPY : UV_FILL128, [&](const FrameJob& j) { order.push_back(j.index); EXPECT(j.ok); });
+            for (int k = 0; k < N; ++k) pool.submit(in[k].data(), out[k].data());
+            pool.finish();
+            EXPECT(pool.stats().frames_out.load() == (uint64_t)N && pool.stats().processing_errors.load() == 0);
+        }
+        EXPECT((int)order.size() == N);
+        for (int k = 0; k < (int)order.size(); ++k) EXPECT(order[k] == (uint64_t)k);
+        for (int k = 0; k < N; ++k) {
+            orc_nv12_frame(in[k].data(), ref.data(), W, H, uv, 0, 0.0, 0, 0);
+            EXPECT(memcmp(out[k].data(), ref.data(), ysz + uvsz) == 0);
+        }
+    }
+    printf(failures ? "test_adapter: %d FAILURES\n" : "test_adapter: all checks passed\n", failures);
+    return failures ? 1 : 0;
+}

@@ -164,7 +164,7 @@ def test_clahe_strided_and_batch(ctx):
     frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 3], 60 + k) for k in range(n)])
     d_in = dev(frames)
     d_out = torch.empty_like(d_in)
-    ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 1, 2.0, 8, 8)
+    ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 1, 2.0, 8, 8, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     out = d_out.cpu().numpy()
     for k in range(n):
@@ -179,7 +179,9 @@ def test_full_size_batch_properties(ctx):
     d_in = synth.nv12_batch_torch(w, h, n, "D2", "cuda:0", seed=123)
     d_in[3, : w * h] = 128
     d_out = torch.empty_like(d_in)
-    ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.UV_COPY)
+    # frames were generated asynchronously on torch's stream: launch on that stream (the context's own
+    # stream is non-blocking and does not order against it)
+    ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.UV_COPY, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(d_in[:, w * h:], d_out[:, w * h:])
     assert (d_out[3, : w * h] == 128).all()

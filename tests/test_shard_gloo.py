@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard frames (frame k -> rank k mod N), process their
+shard independently (no data-path collective) and the results re-sequence to the serial answer.
+The compute stand-in here is the oracle (test-only): what is being tested is the sharding, the
+in-order merge and the max-over-ranks timing reduction that bench.py uses."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _worker(rank, world, port, n_frames, q):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "opencv-opencl_amd" / "python"))
+    import oracle
+    from mi_lumaeq import shard, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, h = 64, 36
+        mine = shard.frames_for_rank(n_frames, rank, world)
+        sums = []
+        for k in mine:
+            out = oracle.nv12_frame(synth.nv12_frame(w, h, "D2", k), w, h, uv_mode=1, op=0)
+            sums.append(int(out.astype(np.uint64).sum()) * 1000003 + int(out[::7].astype(np.uint64).sum()))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, sums)          # test-side collection only; the data path has none
+        t = shard.max_over_ranks(0.25 * (rank + 1), dist)
+        if rank == 0:
+            q.put((shard.merge_in_order(gathered, n_frames), t))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [7, 8])
+def test_two_rank_sharding_matches_serial(n_frames):
+    sys.path.insert(0, str(ROOT))
+    import oracle
+    from mi_lumaeq import shard, synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_frames
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged, t = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w, h = 64, 36
+    serial = []
+    for k in range(n_frames):
+        out = oracle.nv12_frame(synth.nv12_frame(w, h, "D2", k), w, h, uv_mode=1, op=0)
+        serial.append(int(out.astype(np.uint64).sum()) * 1000003 + int(out[::7].astype(np.uint64).sum()))
+    assert merged == serial
+    assert t == pytest.approx(0.5)                       # slowest rank
+
+
+def test_shard_helpers():
+    from mi_lumaeq import shard
+    for n in (0, 1, 5, 64, 513):
+        for world in (1, 2, 4, 8):
+            parts = [shard.frames_for_rank(n, r, world) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+            assert all(shard.owner_of(k, world) == r for r, p in enumerate(parts) for k in p)
+            assert shard.merge_in_order([[k * 10 for k in p] for p in parts], n) == [k * 10 for k in range(n)]
+    with pytest.raises(ValueError):
+        shard.frames_for_rank(4, 2, 2)
+    assert shard.max_over_ranks(1.5) == 1.5
