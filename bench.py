@@ -85,7 +85,7 @@ def cpu_baseline(args, w, h):
         oracle.nv12_frame(frames[done % nfr], w, h, uv_mode=uv_mode, op=op)
         done += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or done >= 2000:
+        if el >= args.cpu_seconds or done >= 100000:
             break
     multi = done / el
     # single-thread figure on a shorter sample
@@ -189,16 +189,15 @@ def main():
     ms_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel -------------------------------------------------------
+    # Algorithmic bytes per frame (SURVEY.md 8d / DESIGN.md): equalizeHist on Y = 3*W*H (histogram read +
+    # apply read + apply write); + UV fill W*H/2 (write) or UV copy 2*(W*H/2).  The fused kernel performs
+    # the WHOLE path in one launch, so its algorithmic bytes are the whole-path figure; its HBM traffic is
+    # lower (the Y plane is read once and kept in registers) -- see `traffic` (PMC) and `min_hbm_bytes`.
     uv_bytes = (ysz // 2) * (2 if args.uv == "copy" else 1)
-    if args.op == "equalize":
-        dom = "lut_apply_kernel"
-        alg_bytes = (2 * ysz + uv_bytes) * B          # read Y + write Y (+ UV fill/copy fused in the same launch)
-    else:
-        dom = "clahe_interp_kernel"
-        alg_bytes = (2 * ysz + uv_bytes) * B
-    kinfo = {}
     per_kernel_alg = {"hist_partial_kernel": ysz * B, "lut_apply_kernel": (2 * ysz + uv_bytes) * B,
+                      "equalize_fused_kernel": (3 * ysz + uv_bytes) * B,
                       "tile_hist_kernel": ysz * B, "clahe_interp_kernel": (2 * ysz + uv_bytes) * B}
+    kinfo = {}
     for name, p in prof.items():
         if p["launches"]:
             avg_ms = p["total_ms"] / p["launches"]
@@ -206,20 +205,27 @@ def main():
             if name in per_kernel_alg:
                 e["alg_GBs"] = round(per_kernel_alg[name] / (avg_ms * 1e-3) / 1e9, 1)
             kinfo[name] = e
+    cands = [k for k in kinfo if k in per_kernel_alg]
+    dom = max(cands, key=lambda k: kinfo[k]["avg_ms"] * kinfo[k]["launches"]) if cands else None
     traffic = None
     tfile = ROOT / "profiles" / "traffic.json"
-    if tfile.exists():
+    if tfile.exists() and dom:
         try:
             traffic = json.loads(tfile.read_text()).get(f"{dom}:{args.op}:{w}x{h}x{B}:{args.uv}")
         except Exception:
             traffic = None
     roofline = None
-    if dom in kinfo:
+    if dom:
+        alg_bytes = per_kernel_alg[dom]
         achieved = alg_bytes / (kinfo[dom]["avg_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kinfo[dom]["avg_ms"],
                     "frac_of_measured_copy_ceiling": round(achieved / HBM_MEASURED_COPY_GBS, 4)}
+        if dom == "equalize_fused_kernel":
+            min_hbm = (2 * ysz + uv_bytes) * B
+            roofline["min_hbm_bytes_per_launch"] = min_hbm
+            roofline["hbm_GBs_at_min_traffic"] = round(min_hbm / (kinfo[dom]["avg_ms"] * 1e-3) / 1e9, 1)
 
     out = {
         "metric": "frames/sec, 3840x2160 NV12 Y equalizeHist" if (args.op == "equalize" and (w, h) == (3840, 2160))
@@ -230,6 +236,7 @@ def main():
         "config": {"workload": f"{B} x {w}x{h} NV12 frames per GPU per step, Y {args.op}"
                                f"{'' if args.op == 'equalize' else ' 8x8 clip 2.0'} + UV {args.uv}, device-resident "
                                f"(BASELINE.json configs[1] batched), Y distribution {args.dist}",
+                   "path": "fused single-read kernel" if "equalize_fused_kernel" in kinfo else "staged kernels",
                    "frames_per_gpu_per_step": B, "width": w, "height": h, "uv": args.uv, "op": args.op,
                    "sharding": f"frame k -> GPU k mod {world}, no collective"},
         "parity_spot_check": parity,
@@ -253,6 +260,33 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     import numpy as np
     w, h = args.width, args.height
     res = {}
+    # the north star also asks for the stand-alone LUT-apply kernel's roofline: run the three-kernel path briefly
+    if args.op == "equalize":
+        Bq = args.batch
+        q_in = synth.nv12_batch_torch(w, h, Bq, args.dist, "cuda", seed=3)
+        q_out = torch.empty_like(q_in)
+        uvm = mi_lumaeq.UV_COPY if args.uv == "copy" else mi_lumaeq.UV_FILL128
+        ctx.set_option("fused", 0)
+        for _ in range(3):
+            ctx.equalize_hist_nv12_batch_dev(q_in, q_out, w, h, Bq, uvm)
+        ctx.synchronize()
+        ctx.profile_read(reset=True)
+        ctx.set_profiling(True)
+        for _ in range(20):
+            ctx.equalize_hist_nv12_batch_dev(q_in, q_out, w, h, Bq, uvm)
+        ctx.set_profiling(False)
+        pr = ctx.profile_read(reset=True)
+        ctx.set_option("fused", 1)
+        ysz = w * h
+        uvb = (ysz // 2) * (2 if args.uv == "copy" else 1)
+        ap = pr["lut_apply_kernel"]; hp = pr["hist_partial_kernel"]
+        if ap["launches"]:
+            a_ms = ap["total_ms"] / ap["launches"]; h_ms = hp["total_ms"] / hp["launches"]
+            res["three_kernel_path"] = {
+                "lut_apply_kernel": {"avg_ms": round(a_ms, 5), "alg_GBs": round((2 * ysz + uvb) * Bq / (a_ms * 1e-3) / 1e9, 1),
+                                     "frac_of_8TBs": round((2 * ysz + uvb) * Bq / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "hist_partial_kernel": {"avg_ms": round(h_ms, 5), "alg_GBs": round(ysz * Bq / (h_ms * 1e-3) / 1e9, 1)}}
+        del q_in, q_out
     frame = synth.nv12_batch_torch(w, h, 1, args.dist, "cuda", seed=99)
     outb = torch.empty_like(frame)
     stream = torch.cuda.current_stream().cuda_stream

@@ -148,12 +148,21 @@ mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* ctx, const void* d_src, size_t sr
                                        double clip_limit, int tiles_x, int tiles_y,
                                        void* d_luts, void* stream);
 
+/* ---- stream completion + device-side status -------------------------------------------------------
+ * The batched equalizeHist forms normally run as ONE fused launch whose workgroups hand data to each
+ * other through bounded waits.  mi_ctx_synchronize() waits for `stream` and returns MI_ERR_HIP if such
+ * a wait ever expired (the output of that call is then invalid).  The host-pointer forms check this
+ * themselves.  Options: "fused" (1/0: single-read fused kernel vs the three-kernel path),
+ * "fused_wgs_per_cu" (persistent workgroups per CU, default 4). */
+mi_status mi_ctx_synchronize(mi_ctx* ctx, void* stream);
+mi_status mi_ctx_set_option(mi_ctx* ctx, const char* name, int value);
+
 /* ---- timing of the library's own kernels -------------------------------------------------------
  * With profiling on, every kernel the library launches is bracketed by hipEvents on the stream
  * it is launched on (the reference brackets its kernel with CL profiling events the same way,
  * 1frameMeasure.cpp:77-85).  mi_ctx_profile_read() synchronises those events and accumulates. */
 enum { MI_K_HIST = 0, MI_K_EQ_LUT = 1, MI_K_LUT_APPLY = 2, MI_K_TILE_HIST = 3, MI_K_TILE_LUT = 4,
-       MI_K_CLAHE_INTERP = 5, MI_K_COUNT = 6 };
+       MI_K_CLAHE_INTERP = 5, MI_K_FUSED = 6, MI_K_COUNT = 7 };
 typedef struct mi_profile {
     double   total_ms[MI_K_COUNT];   /* summed kernel durations since the last reset */
     uint64_t launches[MI_K_COUNT];

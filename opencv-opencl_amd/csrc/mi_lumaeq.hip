@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
@@ -36,6 +37,12 @@ struct mi_ctx {
     // device scratch, grown lazily ("allocate once per size", OpenCLequalHist.cpp:175-186)
     uint32_t* d_partial = nullptr; size_t partial_bytes = 0;     // histogram partials
     uint8_t*  d_luts = nullptr;    size_t luts_bytes = 0;        // per-frame / per-tile LUTs
+    uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (zeroed per call)
+    uint32_t* h_status = nullptr;                                // pinned mirror of the device status word
+    int fused_mode = 1;                                          // MI_LUMAEQ_FUSED=0 forces the 3-kernel path
+    int fused_wgs_per_cu = 4;                                    // MI_LUMAEQ_FUSED_WGS_PER_CU
+    int fused_vpt = kVPT;                                        // MI_LUMAEQ_FUSED_VPT (8, 16, 20, 24)
+    int fused_acquire = 1;                                       // MI_LUMAEQ_FUSED_ACQUIRE
     uint8_t*  d_stage_in = nullptr;  size_t stage_in_bytes = 0;  // device frame for the host-pointer forms
     uint8_t*  d_stage_out = nullptr; size_t stage_out_bytes = 0;
     uint8_t*  h_pin_in = nullptr;  size_t pin_in_bytes = 0;      // pinned staging
@@ -206,8 +213,64 @@ mi_status launch_apply(mi_ctx* c, hipStream_t s, const PlaneArgs& a, int f0, int
     return MI_OK;
 }
 
+// ---- fused single-read path -----------------------------------------------------------------------------
+// Layout of the per-call hand-off block (uint32 words), zeroed by ONE memset node before the launch:
+//   [0..31] work counter (u64) | [32..63] status | cnt[nf][32] | ready[nf][32] | ghist[nf][256] | lutpub[nf][128]
+bool fused_applicable(const mi_ctx* c, const PlaneArgs& a, const UVJob* uv)
+{
+    if (!c->fused_mode) return false;
+    if (a.src_step != (size_t)a.width || a.dst_step != (size_t)a.width) return false;      // contiguous planes only
+    const long long ysz = (long long)a.width * a.height;
+    if (ysz % 16 != 0) return false;
+    if (((uintptr_t)a.src | (uintptr_t)a.dst | a.src_frame | a.dst_frame) & 15) return false;
+    const long long slice = (long long)kThreads * c->fused_vpt;
+    const long long T = (ysz / 16 + slice - 1) / slice;
+    if (T > c->cu_count) return false;                      // every slice of a frame must be co-resident (see KF): one WG per CU always is
+    if (a.n_frames > (1 << 20)) return false;
+    (void)uv;
+    return true;
+}
+
+mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
+{
+    const long long ysz = (long long)a.width * a.height;
+    FusedJob j{};
+    j.src = a.src; j.dst = a.dst; j.src_frame = (long long)a.src_frame; j.dst_frame = (long long)a.dst_frame;
+    j.nvec = ysz / 16; j.total = (int)ysz; j.n_frames = a.n_frames;
+    const long long slice = (long long)kThreads * c->fused_vpt;
+    j.T = (int)((j.nvec + slice - 1) / slice);
+    j.acquire = c->fused_acquire;
+    j.U = 0;
+    // UV as stand-alone 64 KiB tickets behind each frame's Y tickets: pure streaming work that fills the gaps while
+    // other workgroups sit in their hand-off (measured 5 % faster than giving every Y ticket a share of the UV plane)
+    if (uv && uv->bytes > 0) { j.uv = *uv; j.U = (int)((uv->bytes + 65535) / 65536); }
+    const size_t nf = (size_t)a.n_frames;
+    const size_t words = 64 + nf * (kFlagStride + kFlagStride + 256 + kLutPubWords);
+    mi_status st = grow_dev(c, &c->d_fused, &c->fused_bytes, words * sizeof(uint32_t));
+    if (st) return st;
+    HIPCHK(c, hipMemsetAsync(c->d_fused, 0, words * sizeof(uint32_t), s));
+    uint32_t* w = c->d_fused;
+    j.work = reinterpret_cast<unsigned long long*>(w);
+    j.status = w + 32;
+    j.cnt = w + 64;
+    j.ready = j.cnt + nf * kFlagStride;
+    j.ghist = j.ready + nf * kFlagStride;
+    j.lutpub = j.ghist + nf * 256;
+    const long long tickets = (long long)(j.T + j.U) * a.n_frames;
+    const long long grid = std::min<long long>(tickets, (long long)c->cu_count * c->fused_wgs_per_cu);
+    switch (c->fused_vpt) {
+        case 8:  LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<8>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
+        case 20: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<20>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
+        case 24: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<24>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
+        case 16: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<16>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
+        default: return fail(c, MI_ERR_BAD_ARG, "bad fused_vpt");
+    }
+    return MI_OK;
+}
+
 mi_status equalize_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
+    if (fused_applicable(c, a, uv)) return equalize_fused_dev(c, s, a, uv);
     for (int f0 = 0; f0 < a.n_frames; f0 += kMaxGridY) {
         const int nf = std::min(kMaxGridY, a.n_frames - f0);
         int nparts = 0;
@@ -379,7 +442,7 @@ const char* mi_status_str(mi_status s)
 const char* mi_kernel_name(int k)
 {
     static const char* names[MI_K_COUNT] = {"hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
-                                            "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel"};
+                                            "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel"};
     return (k >= 0 && k < MI_K_COUNT) ? names[k] : "?";
 }
 
@@ -406,6 +469,10 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount;
+    if (const char* e = getenv("MI_LUMAEQ_FUSED")) c->fused_mode = atoi(e);
+    if (const char* e = getenv("MI_LUMAEQ_FUSED_WGS_PER_CU")) c->fused_wgs_per_cu = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("MI_LUMAEQ_FUSED_VPT")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 20 || v == 24) c->fused_vpt = v; }
+    if (const char* e = getenv("MI_LUMAEQ_FUSED_ACQUIRE")) c->fused_acquire = atoi(e) != 0;
     *out = c;
     return MI_OK;
 }
@@ -419,6 +486,8 @@ void mi_ctx_destroy(mi_ctx* c)
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_luts) (void)hipFree(c->d_luts);
+    if (c->d_fused) (void)hipFree(c->d_fused);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->d_stage_in) (void)hipFree(c->d_stage_in);
     if (c->d_stage_out) (void)hipFree(c->d_stage_out);
     if (c->h_pin_in) (void)hipHostFree(c->h_pin_in);
@@ -453,6 +522,31 @@ mi_status mi_ctx_profile_read(mi_ctx* c, mi_profile* out, int reset)
     c->pending.clear();
     if (out) *out = c->prof;
     if (reset) c->prof = mi_profile{};
+    return MI_OK;
+}
+
+mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
+{
+    ENTER(c);
+    if (!name) return fail(c, MI_ERR_BAD_ARG, "null option name");
+    if (!strcmp(name, "fused")) { c->fused_mode = value; return MI_OK; }
+    if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }
+    if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
+    if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
+    return fail(c, MI_ERR_BAD_ARG, "unknown option");
+}
+
+// Waits for `stream` and reports a device-side failure of the fused kernel's bounded waits.
+mi_status mi_ctx_synchronize(mi_ctx* c, void* stream)
+{
+    ENTER(c);
+    hipStream_t s = pick_stream(c, stream);
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (!c->d_fused) return MI_OK;
+    if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
+    HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (*c->h_status != 0) { c->last_hip = 0; return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid"); }
     return MI_OK;
 }
 
@@ -615,7 +709,13 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
                   : equalize_dev(c, s, a, nv12_mode >= 0 ? &uv : nullptr);
     if (st) return st;
     HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, frame_bytes, hipMemcpyDeviceToHost, s));
+    if (!is_clahe && c->d_fused) {
+        if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
+        HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(c, hipStreamSynchronize(s));
+    if (!is_clahe && c->h_status && *c->h_status != 0)
+        return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
     copy_rows(dst, dst_step, c->h_pin_out, (size_t)width, width, height);
     if (uvbytes) memcpy(dst + ybytes, c->h_pin_out + ybytes, uvbytes);
     return MI_OK;

@@ -13,7 +13,7 @@ _LIB_PATH = _ROOT / "lib" / "libmi_lumaeq.so"
 UV_FILL128, UV_COPY = 0, 1
 STREAM_CTX = C.c_void_p(-1).value      # MI_STREAM_CTX: the context's private stream; 0/None = HIP null stream
 KERNEL_NAMES = ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
-                "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel"]
+                "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel"]
 
 # every extern "C" symbol include/mi_lumaeq.h declares (tests check the .so exports them all)
 DECLARED_SYMBOLS = [
@@ -25,6 +25,7 @@ DECLARED_SYMBOLS = [
     "mi_hist_u8_batch_dev", "mi_equalize_lut_batch_dev", "mi_lut_apply_u8_batch_dev",
     "mi_clahe_tile_luts_batch_dev",
     "mi_ctx_set_profiling", "mi_ctx_profile_read", "mi_kernel_name",
+    "mi_ctx_synchronize", "mi_ctx_set_option",
 ]
 
 _K = len(KERNEL_NAMES)
@@ -87,6 +88,8 @@ def lib() -> C.CDLL:
     L.mi_equalize_lut_batch_dev.argtypes = [vp, vp, i64, i, vp, vp]
     L.mi_lut_apply_u8_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, vp, vp]
     L.mi_clahe_tile_luts_batch_dev.argtypes = [vp, vp, sz, sz, i, i, i, d, i, i, vp, vp]
+    L.mi_ctx_synchronize.argtypes = [vp, vp]
+    L.mi_ctx_set_option.argtypes = [vp, C.c_char_p, i]
     L.mi_ctx_set_profiling.argtypes = [vp, i]
     L.mi_ctx_profile_read.argtypes = [vp, C.POINTER(_Profile), i]
     _lib = L
@@ -258,6 +261,13 @@ class Context:
         self._chk(lib().mi_clahe_tile_luts_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
                                                      float(clip_limit), tiles_x, tiles_y, _dptr(d_luts), stream),
                   "mi_clahe_tile_luts_batch_dev")
+
+    def synchronize(self, stream=0):
+        """Wait for `stream`; raises if the fused kernel reported an expired inter-workgroup wait."""
+        self._chk(lib().mi_ctx_synchronize(self._h, stream), "mi_ctx_synchronize")
+
+    def set_option(self, name: str, value: int):
+        self._chk(lib().mi_ctx_set_option(self._h, name.encode(), int(value)), "mi_ctx_set_option")
 
     # ---- profiling ----
     def set_profiling(self, on: bool):

@@ -203,10 +203,58 @@ def test_profiling_counters(ctx):
     w, h, n = 640, 360, 2
     d_in = dev(np.stack([synth.nv12_frame(w, h, "D1", k) for k in range(n)]))
     d_out = torch.empty_like(d_in)
-    ctx.profile_read(reset=True)
-    ctx.set_profiling(True)
-    ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
-    p = ctx.profile_read(reset=True)
-    ctx.set_profiling(False)
-    assert p["hist_partial_kernel"]["launches"] == 1 and p["lut_apply_kernel"]["launches"] == 1
-    assert p["lut_apply_kernel"]["total_ms"] > 0
+    try:
+        for fused, names in ((1, ["equalize_fused_kernel"]), (0, ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel"])):
+            ctx.set_option("fused", fused)
+            ctx.profile_read(reset=True)
+            ctx.set_profiling(True)
+            ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
+            p = ctx.profile_read(reset=True)
+            ctx.set_profiling(False)
+            for k, v in p.items():
+                assert v["launches"] == (1 if k in names else 0), (fused, k)
+                assert (v["total_ms"] > 0) == (k in names)
+    finally:
+        ctx.set_option("fused", 1)
+        ctx.set_profiling(False)
+
+
+@pytest.mark.parametrize("opts", [dict(fused=0), dict(fused_vpt=8), dict(fused_vpt=16), dict(fused_vpt=20, fused_wgs_per_cu=2),
+                                  dict(fused_vpt=24, fused_acquire=0), dict(fused_wgs_per_cu=1)], ids=str)
+def test_equalize_paths_agree(ctx, opts):
+    """Three-kernel path and every fused-kernel configuration give the oracle's bytes (4K, 1080p, tiny, UV modes)."""
+    try:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        for (w, h, n) in [(3840, 2160, 3), (1920, 1080, 5), (64, 36, 7), (16, 1, 2)]:
+            frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 70 + k) for k in range(n)])
+            d_in = dev(frames)
+            for uv_mode in (0, 1):
+                d_out = torch.zeros_like(d_in)
+                ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode)
+                ctx.synchronize()
+                out = d_out.cpu().numpy()
+                for k in range(n):
+                    assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), (w, h, k, uv_mode)
+    finally:
+        for k, v in dict(fused=1, fused_vpt=20, fused_wgs_per_cu=4, fused_acquire=1).items():
+            ctx.set_option(k, v)
+
+
+def test_fused_stress_many_frames(ctx):
+    """Hand-off protocol under load: 256 1080p frames in one launch, twice, checked frame by frame on the GPU
+    against the three-kernel path (itself oracle-checked above)."""
+    w, h, n = 1920, 1080, 256
+    d_in = synth.nv12_batch_torch(w, h, n, "D2", "cuda:0", seed=77)
+    d_a, d_b = torch.empty_like(d_in), torch.empty_like(d_in)
+    try:
+        ctx.set_option("fused", 0)
+        ctx.equalize_hist_nv12_batch_dev(d_in, d_a, w, h, n, 1)
+        ctx.set_option("fused", 1)
+        for _ in range(3):
+            d_b.zero_()
+            ctx.equalize_hist_nv12_batch_dev(d_in, d_b, w, h, n, 1)
+            ctx.synchronize()
+            assert torch.equal(d_a, d_b)
+    finally:
+        ctx.set_option("fused", 1)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE collected in SEPARATE runs) of bench.py.
+
+Unit and gfx950 correction exactly as MI355X_MICROARCH.md (HBM section) prescribes:
+  * FETCH_SIZE / WRITE_SIZE are in KiB: bytes = value * 1024;
+  * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced streaming
+    read -> doubled here (reported both raw and corrected); WRITE_SIZE is exact for 16 B/lane stores.
+Output: per-kernel average bytes per launch (our mi:: kernels only) -> JSON + updates profiles/traffic.json.
+
+  python tools/pmc_summary.py gpurun_out/pmc_r01_FETCH_SIZE gpurun_out/pmc_r01_WRITE_SIZE profiles/r01_pmc.json [traffic_key]
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+
+def collect(d, counter):
+    vals = defaultdict(list)
+    for f in glob.glob(str(Path(d) / "**" / "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and r["Kernel_Name"].startswith("mi::"):
+                vals[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return vals
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    key = sys.argv[4] if len(sys.argv) > 4 else None
+    fetch, write = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    res = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace; "
+                      "KiB -> bytes (x1024); FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for wide "
+                      "coalesced reads, MI355X_MICROARCH.md HBM section); averages over all launches of the pass "
+                      "(includes warm-up launches)"}
+    for k in sorted(set(fetch) | set(write)):
+        f = sum(fetch[k]) / len(fetch[k]) * 1024 if fetch.get(k) else None
+        w = sum(write[k]) / len(write[k]) * 1024 if write.get(k) else None
+        res[k] = {"launches_fetch_pass": len(fetch.get(k, [])), "launches_write_pass": len(write.get(k, [])),
+                  "fetch_bytes_raw": f, "fetch_bytes_corrected": None if f is None else 2 * f, "write_bytes": w,
+                  "hbm_bytes_per_launch": None if f is None or w is None else 2 * f + w}
+    Path(out).write_text(json.dumps(res, indent=1))
+    print(json.dumps(res, indent=1))
+    if key:
+        kname = key.split(":")[0]
+        tfile = Path(out).parent / "traffic.json"
+        t = json.loads(tfile.read_text()) if tfile.exists() else {}
+        match = [k for k in res if k.endswith(kname)]
+        if match and res[match[0]]["hbm_bytes_per_launch"] is not None:
+            t[key] = round(res[match[0]]["hbm_bytes_per_launch"])
+            tfile.write_text(json.dumps(t, indent=1))
+
+
+if __name__ == "__main__":
+    main()
