@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
         if (k >= total_tickets) break;
         const int f = (int)(k / P);
         const int r = (int)(k - (unsigned long long)f * P);
-        if (r >= j.T) {                               // stand-alone UV ticket (only when U > 0; normally UV rides on the Y tickets)
+        if (r >= j.T) {                               // UV ticket (A7): 64 KiB of plain fill / copy
             uv_flat(j.uv.src ? j.uv.src + (long long)f * j.uv.src_frame : nullptr, j.uv.dst + (long long)f * j.uv.dst_frame,
                     j.uv.bytes, j.uv.mode, r - j.T, j.U);
             continue;
@@ -505,10 +505,6 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
             __builtin_amdgcn_raw_buffer_store_b128(lut_vec(lds, q[i], copy), drsrc, toff, i * (kThreads * 16), 0);
             __builtin_amdgcn_sched_barrier(0);                      // keep the bodies apart: the slice already owns 4*VPT VGPRs
         }
-        // ---- 6. this ticket's share of the frame's UV plane (A7): fill 128 or copy
-        if (j.U == 0 && j.uv.bytes > 0)
-            uv_flat(j.uv.src ? j.uv.src + (long long)f * j.uv.src_frame : nullptr, j.uv.dst + (long long)f * j.uv.dst_frame,
-                    j.uv.bytes, j.uv.mode, r, j.T);
     }
 }
 

@@ -1,0 +1,31 @@
+"""Pins the oracle against a REAL OpenCV wherever one is importable (none is in the authoring image or
+on the GPU box, so this normally skips -- which is why DESIGN.md says 'parity unpinned').  If cv2 is
+present, any disagreement here means the restatement in oracle/ (and therefore the HIP kernels) is wrong."""
+import numpy as np
+import pytest
+
+cv2 = pytest.importorskip("cv2")
+
+import oracle  # noqa: E402
+from mi_lumaeq import synth  # noqa: E402
+
+SHAPES = [(1, 1), (3, 5), (47, 63), (48, 64), (15, 16), (270, 480), (1079, 1919), (1080, 1920)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=str)
+@pytest.mark.parametrize("dist", synth.DISTS)
+def test_equalize_matches_cv2(shape, dist):
+    h, w = shape
+    src = synth.y_plane(w, h, dist, 31)
+    assert np.array_equal(oracle.equalize_hist(src), cv2.equalizeHist(src))
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=str)
+@pytest.mark.parametrize("cfg", [(2.0, 8, 8), (3.0, 4, 4), (40.0, 8, 8), (1.5, 1, 1), (2.0, 16, 2)], ids=str)
+def test_clahe_matches_cv2(shape, cfg):
+    h, w = shape
+    clip, tx, ty = cfg
+    for dist in ("D1", "D2", "D3"):
+        src = synth.y_plane(w, h, dist, 32)
+        want = cv2.createCLAHE(clipLimit=clip, tileGridSize=(tx, ty)).apply(src)
+        assert np.array_equal(oracle.clahe(src, clip, tx, ty), want), (dist, cv2.__version__)

@@ -21,8 +21,11 @@ def collect(d, counter):
     vals = defaultdict(list)
     for f in glob.glob(str(Path(d) / "**" / "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and r["Kernel_Name"].startswith("mi::"):
-                vals[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"]
+            if name.startswith("void "):
+                name = name[5:]
+            if r["Counter_Name"] == counter and name.startswith("mi::"):
+                vals[name.split("(")[0].split("<")[0]].append(float(r["Counter_Value"]))
     return vals
 
 
