@@ -551,23 +551,34 @@ __global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __re
     const int r0 = (int)((long long)g.tile_h * s / S), r1 = (int)((long long)g.tile_h * (s + 1) / S);
     const int x0 = tx * g.tile_w;
     const int in_w = max(0, min(g.tile_w, g.width - x0));     // columns of this tile that lie inside the frame
-    const int slots = (in_w + 15) >> 4;                        // 16-byte slots per row (last may be partial)
+    const int slots = in_w >> 4;                               // full 16-byte slots per row
     if (slots > 0) {
         const int rows = r1 - r0;
         const long long items = (long long)rows * slots;
         int row = t / slots, slot = t - row * slots;
         const int drow = kThreads / slots, dslot = kThreads - drow * slots;
-        for (long long it = t; it < items; it += kThreads) {
+        auto item_ptr = [&]() -> const u32x4_u* {             // address of the current (row, slot), then advance by 256 items
             const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
-            const uint8_t* p = src + (long long)y * step + x0 + (slot << 4);
-            const int nb = min(16, in_w - (slot << 4));
-            if (nb == 16) {
-                hist_add_vec(h, *reinterpret_cast<const u32x4_u*>(p), copy);
-            } else {
-                for (int k = 0; k < nb; ++k) lds_inc(h, ((uint32_t)p[k] << kCopyShift) + copy);
-            }
+            const u32x4_u* p = reinterpret_cast<const u32x4_u*>(src + (long long)y * step + x0 + (slot << 4));
             row += drow; slot += dslot;
             if (slot >= slots) { slot -= slots; ++row; }
+            return p;
+        };
+        long long it = t;
+        for (; it + 3 * kThreads < items; it += 4 * kThreads) {          // 4 x 16 B in flight per lane
+            const u32x4_u* p0 = item_ptr(); const u32x4_u* p1 = item_ptr(); const u32x4_u* p2 = item_ptr(); const u32x4_u* p3 = item_ptr();
+            const u32x4 a = *p0, b = *p1, c = *p2, d = *p3;
+            hist_add_vec(h, a, copy); hist_add_vec(h, b, copy); hist_add_vec(h, c, copy); hist_add_vec(h, d, copy);
+        }
+        for (; it < items; it += kThreads) hist_add_vec(h, *item_ptr(), copy);
+    }
+    if ((in_w & 15) != 0) {                                     // ragged right edge of the in-frame part: byte loads
+        const int pw = in_w & 15, xs = x0 + (slots << 4);
+        const long long items = (long long)(r1 - r0) * pw;
+        for (long long it = t; it < items; it += kThreads) {
+            const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            lds_inc(h, ((uint32_t)src[(long long)y * step + xs + c] << kCopyShift) + copy);
         }
     }
     if (in_w < g.tile_w) {                                      // reflected columns (right border tiles only)
@@ -634,14 +645,38 @@ constexpr int kBandMargin = 4;          // rows; covers the f32 rounding of y*in
 
 __device__ __forceinline__ int floor_f32_to_int(float v) { const int i = (int)v; return i - ((float)i > v); }   // cvFloor
 
-__device__ __forceinline__ uint32_t clahe_px(uint32_t q, float xa, float xa1, float ya, float ya1)
+// res = (a*xa1 + b*xa)*ya1 + (c*xa1 + d*xa)*ya, nine individually rounded f32 ops, then round half to even.
+__device__ __forceinline__ float clahe_blend(uint32_t q, float xa, float xa1, float ya, float ya1)
 {
     const float a = (float)(q & 0xffu), b = (float)((q >> 8) & 0xffu), c = (float)((q >> 16) & 0xffu), d = (float)(q >> 24);
     const float top = __fmul_rn(__fadd_rn(__fmul_rn(a, xa1), __fmul_rn(b, xa)), ya1);
     const float bot = __fmul_rn(__fadd_rn(__fmul_rn(c, xa1), __fmul_rn(d, xa)), ya);
-    int r = __float2int_rn(__fadd_rn(top, bot));
-    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    return rintf(__fadd_rn(top, bot));                               // v_rndne_f32: cvRound
+}
+__device__ __forceinline__ uint32_t clahe_px(uint32_t q, float xa, float xa1, float ya, float ya1)
+{
+    int r = (int)clahe_blend(q, xa, xa1, ya, ya1);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);                             // saturate_cast<uchar>
     return (uint32_t)r;
+}
+// 16 pixels of one row: one ds_read_b32 per pixel, v_cvt_pk_u8_f32 (saturating, input already integral) packs the bytes
+__device__ __forceinline__ u32x4 clahe_vec16(const uint32_t* quad, u32x4 q, const int* poff, const float* xa, const float* xa1, float ya, float ya1)
+{
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = k * 4 + b;
+            const uint32_t v = (w[k] >> (8 * b)) & 0xffu;
+            acc = __builtin_amdgcn_cvt_pk_u8_f32(clahe_blend(quad[poff[j] + v], xa[j], xa1[j], ya, ya1), b, acc);
+        }
+        ow[k] = acc;
+    }
+    u32x4 o; o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
+    return o;
 }
 
 __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, ClaheGeom g, const uint8_t* __restrict__ luts,
@@ -691,32 +726,30 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
         const uint8_t* src = p.src + (long long)f * p.src_frame;
         uint8_t* dst = p.dst + (long long)f * p.dst_frame;
         const bool full = x0 + kInterpPx <= g.width;
-        for (int y = y_lo + phase; y < y_hi; y += phases) {
-            const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
-            const int ty1r = floor_f32_to_int(tyf);
-            if (ty1r != ty1u) continue;                        // belongs to the neighbouring band
-            const float ya = __fsub_rn(tyf, (float)ty1r), ya1 = __fsub_rn(1.0f, ya);
-            const uint8_t* sr = src + (long long)y * p.src_step + x0;
-            uint8_t* dr = dst + (long long)y * p.dst_step + x0;
-            if (full) {
-                const u32x4 q = *reinterpret_cast<const u32x4_u*>(sr);
-                u32x4 o;
-                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-                uint32_t ow[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int j = k * 4 + b;
-                        const uint32_t v = (w[k] >> (8 * b)) & 0xffu;
-                        acc |= clahe_px(quad[poff[j] + v], xa[j], xa1[j], ya, ya1) << (8 * b);
-                    }
-                    ow[k] = acc;
-                }
-                o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
-                *reinterpret_cast<u32x4_u*>(dr) = o;
-            } else {
+        // ty1 is monotone in y: trim the widened range to the rows that really belong to this band, using the
+        // reference's own float expression (at most kBandMargin+1 steps per end)
+        auto ty1_of = [&](int y) { return floor_f32_to_int(__fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f)); };
+        int ya_lo = y_lo, ya_hi = y_hi;
+        while (ya_lo < ya_hi && ty1_of(ya_lo) != ty1u) ++ya_lo;
+        while (ya_hi > ya_lo && ty1_of(ya_hi - 1) != ty1u) --ya_hi;
+        // rows of this lane: ya_lo + phase, + phases, ...  (sub-ranges are contiguous per block, phases interleave inside)
+        int y = ya_lo + ((phase - (ya_lo - y_lo) % phases) % phases + phases) % phases;
+        if (full) {
+            // The loop is VALU-issue bound (~290 instructions per 16 pixels: 64 byte->float converts, 144 blend
+            // flops, 16 LDS reads); an explicit 2-row software pipeline measured 11 % SLOWER than letting the
+            // other resident waves cover the load latency, so the row loop stays simple.
+            for (; y < ya_hi; y += phases) {
+                const u32x4 q = *reinterpret_cast<const u32x4_u*>(src + (long long)y * p.src_step + x0);
+                const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+                const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
+                *reinterpret_cast<u32x4_u*>(dst + (long long)y * p.dst_step + x0) = clahe_vec16(quad, q, poff, xa, xa1, ya, ya1);
+            }
+        } else {
+            for (; y < ya_hi; y += phases) {
+                const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+                const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
+                const uint8_t* sr = src + (long long)y * p.src_step + x0;
+                uint8_t* dr = dst + (long long)y * p.dst_step + x0;
 #pragma unroll
                 for (int j = 0; j < kInterpPx; ++j)
                     if (x0 + j < g.width) dr[j] = (uint8_t)clahe_px(quad[poff[j] + sr[j]], xa[j], xa1[j], ya, ya1);
