@@ -50,6 +50,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (=RCCL) for real multi-GPU runs; gloo only to rehearse the N>1 path on a 1-GPU box")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None,
+                    help="rehearsal only: every rank uses this GPU index instead of LOCAL_RANK")
     return ap.parse_args()
 
 
@@ -114,11 +118,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.all_ranks_on_device is not None:
+        local_rank = args.all_ranks_on_device
     if world > 1:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs HIP devices (no CPU fallback)")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world == 1 and args.gpus > 1:

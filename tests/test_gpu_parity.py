@@ -258,3 +258,67 @@ def test_fused_stress_many_frames(ctx):
             assert torch.equal(d_a, d_b)
     finally:
         ctx.set_option("fused", 1)
+
+
+def test_large_and_degenerate_shapes(ctx):
+    """Maximum / ragged sizes: an 8K plane (more slices than CUs -> three-kernel fallback), a frame taller than
+    65535 rows with a stride, width 1, height 1, non-multiple-of-16 sizes, zero frames."""
+    rng = np.random.default_rng(17)
+    big = rng.integers(0, 256, (4320, 7680), dtype=np.uint8)
+    big[1000:3000] = np.clip(big[1000:3000] // 4 + 90, 0, 255)
+    assert np.array_equal(ctx.equalize_hist(big), oracle.equalize_hist(big))
+    tall = rng.integers(0, 256, (70000, 24), dtype=np.uint8)
+    view = tall[:, 3:20]                                         # 70000 strided rows of 17 bytes
+    assert np.array_equal(ctx.equalize_hist(view), oracle.equalize_hist(view))
+    assert np.array_equal(ctx.clahe(view, 2.0, 2, 64), oracle.clahe(view, 2.0, 2, 64))
+    for shape in [(1, 70001), (70001, 1), (2, 8), (1, 16), (17, 31)]:
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        assert np.array_equal(ctx.equalize_hist(a), oracle.equalize_hist(a)), shape
+        assert np.array_equal(ctx.clahe(a, 2.0, 8, 8), oracle.clahe(a, 2.0, 8, 8)), shape
+    d = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
+    ctx.equalize_hist_nv12_batch_dev(d, d, 8, 4, 0, 0)           # zero frames: no-op
+    ctx.equalize_hist_nv12_batch_dev(d, d, 0, 4, 1, 0)           # empty frame: no-op
+    ctx.synchronize()
+
+
+def test_argument_errors(ctx):
+    d = torch.zeros(1024, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(mi_lumaeq.MiError) as e:
+        ctx.equalize_hist_nv12_batch_dev(d, d, 8, 4, 1, 7)       # bad uv_mode
+    assert e.value.status == 1
+    with pytest.raises(mi_lumaeq.MiError) as e:
+        ctx.equalize_hist_batch_dev(d, d, 16, 4, 1, src_step=8)  # step < width
+    assert e.value.status == 1
+    with pytest.raises(mi_lumaeq.MiError) as e:
+        ctx.equalize_hist_batch_dev(d, d, 1 << 16, 1 << 16, 1)   # W*H >= 2^31 (OpenCV: int total)
+    assert e.value.status == 2
+    with pytest.raises(mi_lumaeq.MiError) as e:
+        ctx.clahe_batch_dev(d, d, 16, 4, 1, 2.0, 0, 8)           # tile grid 0
+    assert e.value.status == 1
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(mi_lumaeq.MiError) as e:
+        mi_lumaeq.Context(99)                                    # device out of range
+    assert e.value.status == 5
+
+
+def test_unaligned_device_batches(ctx):
+    """Device batches whose planes are not 16-B aligned / not multiples of 16 take the generic path."""
+    w, h, n = 333, 77, 4
+    frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 90 + k) for k in range(n)])
+    fb = frames.shape[1]
+    pad = torch.zeros(n * fb + 5, dtype=torch.uint8, device="cuda:0")
+    d_in = pad[3:3 + n * fb]                                      # misaligned base
+    d_in.copy_(torch.from_numpy(frames.reshape(-1)))
+    d_out = torch.zeros(n * fb + 7, dtype=torch.uint8, device="cuda:0")[7:]
+    for uv_mode in (0, 1):
+        ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode)
+        ctx.synchronize()
+        out = d_out.cpu().numpy().reshape(n, fb)
+        for k in range(n):
+            assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), (k, uv_mode)
+        ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode, 2.0, 8, 8)
+        ctx.synchronize()
+        out = d_out.cpu().numpy().reshape(n, fb)
+        for k in range(n):
+            assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8)), (k, uv_mode)
