@@ -337,12 +337,17 @@ struct FusedJob {
     int T, U;                                       // Y tickets / UV tickets per frame
     int acquire;                                    // 1: consumers issue an agent acquire before reading the LUT
     UVJob uv;
-    unsigned long long* work;                       // ticket dispenser            } all zeroed by the
-    uint32_t* ghist;                                // [n_frames][256]             } host (one memset
-    uint32_t* cnt;                                  // [n_frames][kFlagStride]     } node) before every
-    uint32_t* ready;                                // [n_frames][kFlagStride]     } launch
-    uint32_t* lutpub;                               // [n_frames][kLutPubWords]
-    uint32_t* status;                               // [0] != 0: a bounded wait expired (result invalid)
+    // Hand-off block.  Zeroed once when allocated; every launch leaves it clean again: the ticket counter only
+    // grows (work_base = its value at launch), the last arriver of a frame drains ghist (exchange) and resets cnt,
+    // ready/lutpub are stamped with a per-launch epoch.  No memset node per call.
+    unsigned long long* work;                       // ticket dispenser (monotonic)
+    unsigned long long work_base;
+    uint32_t epoch;                                 // != 0, different for every launch of a context
+    uint32_t* ghist;                                // [cap][256]
+    uint32_t* cnt;                                  // [cap][kFlagStride]
+    uint32_t* ready;                                // [cap][kFlagStride]
+    uint32_t* lutpub;                               // [cap][kLutPubWords]
+    uint32_t* status;                               // [0] != 0: a bounded wait expired (result invalid; sticky)
 };
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
     const unsigned long long total_tickets = P * (unsigned long long)j.n_frames;
     for (;;) {
         __syncthreads();
-        if (t == 0) sh.ticket = __hip_atomic_fetch_add(j.work, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 0) sh.ticket = __hip_atomic_fetch_add(j.work, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - j.work_base;
         __syncthreads();
         unsigned long long k = sh.ticket;                            // make it provably wave-uniform (SGPRs): all the
         k = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 32)) << 32) |   // per-ticket address math then
@@ -454,17 +459,20 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
                 const uint32_t w = sh.lut_words[t];
                 uint32_t* pub = j.lutpub + (size_t)f * kLutPubWords;
                 st_agent(pub + t, w);
-                const uint32_t sum = wave_sum(w) + 0x5EED0001u;
-                if (t == 0) st_agent(pub + 64, sum);
+                const uint32_t sum = wave_sum(w) + 0x5EED0001u + j.epoch;
+                if (t == 0) {
+                    st_agent(pub + 64, sum);
+                    st_agent(j.cnt + (size_t)f * kFlagStride, 0u);  // all T arrivals are in: leave the counter clean for the next launch
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // write-through stores have left this CU
-                if (t == 0) st_agent(j.ready + (size_t)f * kFlagStride, 1u);
+                if (t == 0) st_agent(j.ready + (size_t)f * kFlagStride, j.epoch);
             }
         } else {
             // ---- 4. wait for the frame's LUT
             if (t == 0) {
                 const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
                 const uint32_t* flag = j.ready + (size_t)f * kFlagStride;
-                while (ld_agent(flag) != 1u) {
+                while (ld_agent(flag) != j.epoch) {
                     __builtin_amdgcn_s_sleep(8);
                     if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks || ld_agent(j.status) != 0u) { sh.ok = 0; st_agent(j.status, 1u); break; }
                 }
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
                 for (;;) {
                     const uint32_t w = ld_agent(pub + t);
                     const uint32_t want = ld_agent(pub + 64);
-                    if (wave_sum(w) + 0x5EED0001u == want) { sh.lut_words[t] = w; break; }
+                    if (wave_sum(w) + 0x5EED0001u + j.epoch == want) { sh.lut_words[t] = w; break; }
                     if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) { if (t == 0) { sh.ok = 0; st_agent(j.status, 2u); } break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
@@ -640,6 +648,9 @@ __global__ __launch_bounds__(kThreads) void tile_lut_kernel(const uint32_t* __re
 // Float ops: nine individually rounded f32 ops per pixel, no FMA (App. A.2 step 5).
 // ---------------------------------------------------------------------------------------------
 constexpr int kInterpPx = 16;           // pixels per lane per row
+constexpr int kMaxPairsLdsF32 = 15;     // float tables: (tiles_x + 1) * 4 KiB of LDS (<= 60 KiB)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxPairsLds = 63;        // (tiles_x + 1) KiB of LDS (<= 64 KiB dynamic); wider grids use the global-LUT kernel
 constexpr int kBandMargin = 4;          // rows; covers the f32 rounding of y*inv_th - 0.5 for any height <= 2^24
 
@@ -679,10 +690,44 @@ __device__ __forceinline__ u32x4 clahe_vec16(const uint32_t* quad, u32x4 q, cons
     return o;
 }
 
+// Float-table variant of the 16-pixel body: the LDS entry is {a, c, b, d} as f32, so one ds_read_b128 delivers
+// two register pairs that feed v_pk_mul_f32 / v_pk_add_f32 directly (each lane of a packed op is an ordinary
+// individually rounded f32 op): 4 packed ops + 1 add per pixel, no byte->float converts.
+__device__ __forceinline__ u32x4 clahe_vec16_f32(const f32x4* quadf, u32x4 q, const int* poff, const float* xa, const float* xa1, float ya, float ya1)
+{
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    const f32x2 yv = {ya1, ya};
+    uint32_t ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // the four LDS reads of a dword first (16 VGPRs in flight), then four independent blend chains: keeps
+        // the packed ops of different pixels interleaved instead of one LDS round trip + dependent chain per pixel
+        f32x4 e[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) e[b] = quadf[poff[k * 4 + b] + ((w[k] >> (8 * b)) & 0xffu)];
+        f32x2 tb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = k * 4 + b;
+            const f32x2 ac = {e[b].x, e[b].y}, bd = {e[b].z, e[b].w};
+            const f32x2 x1 = {xa1[j], xa1[j]}, x0v = {xa[j], xa[j]};
+            tb[b] = (ac * x1 + bd * x0v) * yv;                   // -ffp-contract=off: pk_mul, pk_mul, pk_add, pk_mul
+        }
+        uint32_t acc = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__fadd_rn(tb[b].x, tb[b].y)), b, acc);
+        ow[k] = acc;
+    }
+    u32x4 o; o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
+    return o;
+}
+
+template <bool FT>
 __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, ClaheGeom g, const uint8_t* __restrict__ luts,
                                                                int subs, int groups, UVJob uv)
 {
-    extern __shared__ uint32_t quad[];                        // [(tiles_x + 1)][256]
+    extern __shared__ __attribute__((aligned(16))) uint32_t quad[];   // [(tiles_x + 1)][256] u32 quads, or f32x4 when FT
+    f32x4* quadf = reinterpret_cast<f32x4*>(quad);
     const int t = threadIdx.x, f = blockIdx.y;
     const int band = blockIdx.x / subs, sub = blockIdx.x - band * subs;
     const int ty1u = band - 1;                                // unclamped ty1 of every row of the band
@@ -694,8 +739,13 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
     for (int i = t; i < npairs * 256; i += kThreads) {
         const int pr = i >> 8, v = i & 255;
         const int ta = max(pr - 1, 0), tb = min(pr, g.tiles_x - 1);
-        quad[i] = (uint32_t)l1[ta * 256 + v] | ((uint32_t)l1[tb * 256 + v] << 8) |
-                  ((uint32_t)l2[ta * 256 + v] << 16) | ((uint32_t)l2[tb * 256 + v] << 24);
+        if (FT) {
+            const f32x4 e = {(float)l1[ta * 256 + v], (float)l2[ta * 256 + v], (float)l1[tb * 256 + v], (float)l2[tb * 256 + v]};   // {a, c, b, d}
+            quadf[i] = e;
+        } else {
+            quad[i] = (uint32_t)l1[ta * 256 + v] | ((uint32_t)l1[tb * 256 + v] << 8) |
+                      ((uint32_t)l2[ta * 256 + v] << 16) | ((uint32_t)l2[tb * 256 + v] << 24);
+        }
     }
     __syncthreads();
 
@@ -742,7 +792,8 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
                 const u32x4 q = *reinterpret_cast<const u32x4_u*>(src + (long long)y * p.src_step + x0);
                 const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
                 const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
-                *reinterpret_cast<u32x4_u*>(dst + (long long)y * p.dst_step + x0) = clahe_vec16(quad, q, poff, xa, xa1, ya, ya1);
+                *reinterpret_cast<u32x4_u*>(dst + (long long)y * p.dst_step + x0) =
+                    FT ? clahe_vec16_f32(quadf, q, poff, xa, xa1, ya, ya1) : clahe_vec16(quad, q, poff, xa, xa1, ya, ya1);
             }
         } else {
             for (; y < ya_hi; y += phases) {
@@ -752,7 +803,16 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
                 uint8_t* dr = dst + (long long)y * p.dst_step + x0;
 #pragma unroll
                 for (int j = 0; j < kInterpPx; ++j)
-                    if (x0 + j < g.width) dr[j] = (uint8_t)clahe_px(quad[poff[j] + sr[j]], xa[j], xa1[j], ya, ya1);
+                    if (x0 + j < g.width) {
+                        uint32_t e;
+                        if (FT) {
+                            const f32x4 fe = quadf[poff[j] + sr[j]];
+                            e = (uint32_t)fe.x | ((uint32_t)fe.z << 8) | ((uint32_t)fe.y << 16) | ((uint32_t)fe.w << 24);
+                        } else {
+                            e = quad[poff[j] + sr[j]];
+                        }
+                        dr[j] = (uint8_t)clahe_px(e, xa[j], xa1[j], ya, ya1);
+                    }
             }
         }
     }

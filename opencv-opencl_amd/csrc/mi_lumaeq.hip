@@ -37,12 +37,17 @@ struct mi_ctx {
     // device scratch, grown lazily ("allocate once per size", OpenCLequalHist.cpp:175-186)
     uint32_t* d_partial = nullptr; size_t partial_bytes = 0;     // histogram partials
     uint8_t*  d_luts = nullptr;    size_t luts_bytes = 0;        // per-frame / per-tile LUTs
-    uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (zeroed per call)
+    uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (self-cleaning)
+    size_t fused_cap = 0;                                        // frames the block is laid out for
+    unsigned long long fused_work_base = 0;                      // value of the device ticket counter at the next launch
+    uint32_t fused_epoch = 0;
+    bool fused_dirty = true;                                     // block must be zeroed before the next launch
     uint32_t* h_status = nullptr;                                // pinned mirror of the device status word
     int fused_mode = 1;                                          // MI_LUMAEQ_FUSED=0 forces the 3-kernel path
     int fused_wgs_per_cu = 4;                                    // MI_LUMAEQ_FUSED_WGS_PER_CU
     int fused_vpt = kVPT;                                        // MI_LUMAEQ_FUSED_VPT (8, 16, 20, 24)
     int fused_acquire = 1;                                       // MI_LUMAEQ_FUSED_ACQUIRE
+    int clahe_float_tables = 1;                                  // option "clahe_float_tables": f32 pair tables in LDS (tiles_x <= 14)
     uint8_t*  d_stage_in = nullptr;  size_t stage_in_bytes = 0;  // device frame for the host-pointer forms
     uint8_t*  d_stage_out = nullptr; size_t stage_out_bytes = 0;
     uint8_t*  h_pin_in = nullptr;  size_t pin_in_bytes = 0;      // pinned staging
@@ -244,20 +249,36 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     // UV as stand-alone 64 KiB tickets behind each frame's Y tickets: pure streaming work that fills the gaps while
     // other workgroups sit in their hand-off (measured 5 % faster than giving every Y ticket a share of the UV plane)
     if (uv && uv->bytes > 0) { j.uv = *uv; j.U = (int)((uv->bytes + 65535) / 65536); }
-    const size_t nf = (size_t)a.n_frames;
-    const size_t words = 64 + nf * (kFlagStride + kFlagStride + 256 + kLutPubWords);
-    mi_status st = grow_dev(c, &c->d_fused, &c->fused_bytes, words * sizeof(uint32_t));
-    if (st) return st;
-    HIPCHK(c, hipMemsetAsync(c->d_fused, 0, words * sizeof(uint32_t), s));
+    // capacity-based layout so the regions never move between calls with different frame counts
+    if ((size_t)a.n_frames > c->fused_cap) {
+        size_t cap = std::max<size_t>(64, c->fused_cap);
+        while (cap < (size_t)a.n_frames) cap *= 2;
+        const size_t words = 64 + cap * (kFlagStride + kFlagStride + 256 + kLutPubWords);
+        mi_status st = grow_dev(c, &c->d_fused, &c->fused_bytes, words * sizeof(uint32_t));
+        if (st) return st;
+        c->fused_cap = cap;
+        c->fused_dirty = true;
+    }
+    if (c->fused_dirty) {                                    // first use, re-layout, or after a reported device-side failure
+        HIPCHK(c, hipMemsetAsync(c->d_fused, 0, c->fused_bytes, s));
+        c->fused_work_base = 0;
+        c->fused_dirty = false;
+    }
+    const size_t cap = c->fused_cap;
     uint32_t* w = c->d_fused;
     j.work = reinterpret_cast<unsigned long long*>(w);
     j.status = w + 32;
     j.cnt = w + 64;
-    j.ready = j.cnt + nf * kFlagStride;
-    j.ghist = j.ready + nf * kFlagStride;
-    j.lutpub = j.ghist + nf * 256;
+    j.ready = j.cnt + cap * kFlagStride;
+    j.ghist = j.ready + cap * kFlagStride;
+    j.lutpub = j.ghist + cap * 256;
+    if (++c->fused_epoch == 0) c->fused_epoch = 1;
+    j.epoch = c->fused_epoch;
+    j.work_base = c->fused_work_base;
     const long long tickets = (long long)(j.T + j.U) * a.n_frames;
     const long long grid = std::min<long long>(tickets, (long long)c->cu_count * c->fused_wgs_per_cu);
+    c->fused_work_base += (unsigned long long)tickets + (unsigned long long)grid;   // every workgroup draws one ticket past the end
+    c->fused_dirty = true;                                   // cleared below once the launch has been enqueued
     switch (c->fused_vpt) {
         case 8:  LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<8>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
         case 20: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<20>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
@@ -265,6 +286,7 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
         case 16: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<16>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
         default: return fail(c, MI_ERR_BAD_ARG, "bad fused_vpt");
     }
+    c->fused_dirty = false;
     return MI_OK;
 }
 
@@ -354,8 +376,12 @@ mi_status launch_interp(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const Clah
         const int rows_per_band = g.tile_h + 2 * kBandMargin;
         int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, rows_per_band / 8), 64LL}));
         if ((long long)bands * subs > 0x7fffffffLL || segs > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "image too wide");
-        LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_kernel, dim3(bands * subs, nf, segs), dim3(kThreads),
-               (size_t)npairs * 256 * sizeof(uint32_t), p, g, d_luts, subs, groups, uv);
+        if (npairs <= kMaxPairsLdsF32 && c->clahe_float_tables)
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_kernel<true>, dim3(bands * subs, nf, segs), dim3(kThreads),
+                   (size_t)npairs * 256 * 4 * sizeof(float), p, g, d_luts, subs, groups, uv);
+        else
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_kernel<false>, dim3(bands * subs, nf, segs), dim3(kThreads),
+                   (size_t)npairs * 256 * sizeof(uint32_t), p, g, d_luts, subs, groups, uv);
     } else {
         if (a.height > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "height > 65535 with tiles_x > 62");
         LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_global_kernel,
@@ -533,6 +559,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }
     if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
     if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
+    if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
     return fail(c, MI_ERR_BAD_ARG, "unknown option");
 }
 
@@ -546,7 +573,11 @@ mi_status mi_ctx_synchronize(mi_ctx* c, void* stream)
     if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
     HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (*c->h_status != 0) { c->last_hip = 0; return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid"); }
+    if (*c->h_status != 0) {
+        c->fused_dirty = true;                                   // hand-off block is in an unknown state: zero it before the next launch
+        c->last_hip = 0;
+        return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+    }
     return MI_OK;
 }
 
@@ -714,8 +745,10 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     HIPCHK(c, hipStreamSynchronize(s));
-    if (!is_clahe && c->h_status && *c->h_status != 0)
+    if (!is_clahe && c->h_status && *c->h_status != 0) {
+        c->fused_dirty = true;
         return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+    }
     copy_rows(dst, dst_step, c->h_pin_out, (size_t)width, width, height);
     if (uvbytes) memcpy(dst + ybytes, c->h_pin_out + ybytes, uvbytes);
     return MI_OK;
