@@ -57,6 +57,7 @@ struct mi_ctx {
     bool profiling = false;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
+    std::vector<hipEvent_t> chunk_events;                        // D2H chunk completion (host-pointer forms)
     mi_profile prof{};
 };
 
@@ -510,6 +511,7 @@ void mi_ctx_destroy(mi_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
+    for (auto e : c->chunk_events) (void)hipEventDestroy(e);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_luts) (void)hipFree(c->d_luts);
     if (c->d_fused) (void)hipFree(c->d_fused);
@@ -730,27 +732,59 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, frame_bytes))) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, frame_bytes))) return st;
     hipStream_t s = c->stream;
-    copy_rows(c->h_pin_in, (size_t)width, src, src_step, width, height);
-    if (copy_uv_in) memcpy(c->h_pin_in + ybytes, src + ybytes, uvbytes);       // tightly packed NV12 (src_step == width)
-    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, c->h_pin_in, in_bytes, hipMemcpyHostToDevice, s));
+    // Chunked staging: the host copy of chunk i+1 into pinned memory overlaps the DMA of chunk i (and the other
+    // way round on the way back), so a frame costs ~max(memcpy, PCIe) per direction instead of their sum.
+    const int rows_per_chunk = std::max(1, (int)((size_t)(2u << 20) / (size_t)width));
+    for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
+        const int nr = std::min(rows_per_chunk, height - y0);
+        const size_t off = (size_t)y0 * width;
+        copy_rows(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, s));
+    }
+    if (copy_uv_in) {                                           // tightly packed NV12 (src_step == width)
+        memcpy(c->h_pin_in + ybytes, src + ybytes, uvbytes);
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_in + ybytes, c->h_pin_in + ybytes, uvbytes, hipMemcpyHostToDevice, s));
+    }
     PlaneArgs a{c->d_stage_in, (size_t)width, frame_bytes, c->d_stage_out, (size_t)width, frame_bytes, width, height, 1};
     UVJob uv{};
     if (nv12_mode >= 0) uv = nv12_uv(c->d_stage_in, c->d_stage_out, width, height, (mi_uv_mode)nv12_mode);
     st = is_clahe ? clahe_dev(c, s, a, clip_limit, tiles_x, tiles_y, nv12_mode >= 0 ? &uv : nullptr)
                   : equalize_dev(c, s, a, nv12_mode >= 0 ? &uv : nullptr);
     if (st) return st;
-    HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, frame_bytes, hipMemcpyDeviceToHost, s));
-    if (!is_clahe && c->d_fused) {
+    // device -> pinned in chunks, each followed by an event; then drain chunk by chunk into the caller's rows
+    struct Chunk { size_t off, bytes; int y0, nr; };
+    std::vector<Chunk> chunks;
+    for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
+        const int nr = std::min(rows_per_chunk, height - y0);
+        chunks.push_back({(size_t)y0 * width, (size_t)nr * width, y0, nr});
+    }
+    if (uvbytes) chunks.push_back({ybytes, uvbytes, -1, 0});
+    while (c->chunk_events.size() < chunks.size()) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->chunk_events.push_back(e);
+    }
+    const bool check_status = !is_clahe && c->d_fused;
+    if (check_status) {
         if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
         HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (!is_clahe && c->h_status && *c->h_status != 0) {
-        c->fused_dirty = true;
-        return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        HIPCHK(c, hipMemcpyAsync(c->h_pin_out + chunks[i].off, c->d_stage_out + chunks[i].off, chunks[i].bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->chunk_events[i], s));
     }
-    copy_rows(dst, dst_step, c->h_pin_out, (size_t)width, width, height);
-    if (uvbytes) memcpy(dst + ybytes, c->h_pin_out + ybytes, uvbytes);
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        HIPCHK(c, hipEventSynchronize(c->chunk_events[i]));
+        if (i == 0 && check_status && *c->h_status != 0) {
+            c->fused_dirty = true;
+            (void)hipStreamSynchronize(s);
+            return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+        }
+        if (chunks[i].y0 >= 0)
+            copy_rows(dst + (size_t)chunks[i].y0 * dst_step, dst_step, c->h_pin_out + chunks[i].off, (size_t)width, width, chunks[i].nr);
+        else
+            memcpy(dst + ybytes, c->h_pin_out + ybytes, uvbytes);
+    }
     return MI_OK;
 }
 
