@@ -10,6 +10,7 @@
 //                                                                OpenCLequalHist.cpp:439-508
 // New: --op equalize|clahe, --uv fill128|copy (OpenCVequalHist.cpp:160-162 vs
 // ColoropenCVCwqualHist.cpp:165), --frames N, --input/--output raw NV12 files, --paced.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +67,8 @@ int main(int argc, char** argv)
             for (int b = 0; b < 8 && i + b < fb; ++b) f[i + b] = (unsigned char)(64 + ((z >> (8 * b)) & 0x7f));
         }
     };
+    std::vector<std::chrono::steady_clock::time_point> t_submit((size_t)frames);
+    std::vector<float> latency_ms((size_t)frames, -1.f);
     try {
         std::atomic<uint64_t> delivered{0};
         FramePool pool(workers, width, height, op == "clahe" ? FramePool::CLAHE_OP : FramePool::EQUALIZE,
@@ -73,6 +76,8 @@ int main(int argc, char** argv)
                        [&](const FrameJob& j) {
                            if (!j.ok) fprintf(stderr, "frame %llu error: %s\n", (unsigned long long)j.index, j.error.c_str());
                            else if (fout) fwrite(j.out, 1, fb, fout);
+                           if (j.index < latency_ms.size())
+                               latency_ms[j.index] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit[j.index]).count();
                            delivered.fetch_add(1);
                        },
                        clip, Size(tile, tile), ring / (size_t)workers > 2 ? ring / (size_t)workers - 1 : 1);
@@ -88,6 +93,7 @@ int main(int argc, char** argv)
             if (fin) { if (fread(f.data(), 1, fb, fin) != fb) { frames = k; break; } }
             else if (k < ring) synth(f, k);                          // synthetic: reuse the ring's first lap
             if (paced) std::this_thread::sleep_until(t0 + std::chrono::microseconds((int64_t)k * 1000000 / fps));
+            t_submit[k] = std::chrono::steady_clock::now();
             pool.submit(f.data(), out[k % ring].data());
             const auto now = std::chrono::steady_clock::now();
             if (now - last_tick >= std::chrono::seconds(2)) {        // status tick (OpenCVequalHist.cpp:200-234)
@@ -105,6 +111,18 @@ int main(int argc, char** argv)
         printf("done: %llu frames in %.3f s = %.1f frames/s (host NV12 in -> host NV12 out, PCIe inclusive), errors=%llu\n",
                (unsigned long long)pool.stats().frames_out.load(), el, pool.stats().frames_out.load() / el,
                (unsigned long long)pool.stats().processing_errors.load());
+        // submit -> in-order delivery latency (the reference only prints averages: clahevideo.cpp:54-84)
+        std::vector<float> lat;
+        for (int k = 0; k < frames; ++k) if (latency_ms[k] >= 0.f) lat.push_back(latency_ms[k]);
+        if (!lat.empty()) {
+            std::sort(lat.begin(), lat.end());
+            const double budget = 1000.0 / fps;
+            size_t late = 0;
+            for (float v : lat) if (v > budget) ++late;
+            printf("latency ms (submit -> in-order delivery): p50=%.3f p90=%.3f p99=%.3f max=%.3f; frames over the %.2f ms frame budget: %zu%s\n",
+                   lat[lat.size() / 2], lat[lat.size() * 9 / 10], lat[std::min(lat.size() - 1, lat.size() * 99 / 100)], lat.back(), budget, late,
+                   paced ? "" : "  (unpaced: latency includes queueing)");
+        }
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

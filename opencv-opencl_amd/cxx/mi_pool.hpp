@@ -53,6 +53,10 @@ public:
         if (ndev <= 0) MI_CV_ERROR(GpuNotSupported, "no HIP device (this backend has no CPU fallback)");
         queues_.resize(workers);
         for (int w = 0; w < workers; ++w) threads_.emplace_back([this, w, ndev] { run(w, w % ndev); });
+        // wait until every worker has created its context and sized its staging/scratch for W x H, so the first real
+        // frame does not pay ~100 ms of one-time allocation (it would blow a 16.7 ms frame budget)
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return ready_ == (int)threads_.size(); });
     }
     ~FramePool() { finish(); }
 
@@ -94,6 +98,19 @@ private:
     void run(int w, int device)
     {
         setDevice(device);
+        try {                                                   // warm-up: context + allocations for this frame size
+            const size_t fb = (size_t)width_ * height_ + (size_t)width_ * height_ / 2;
+            std::vector<unsigned char> tmp(fb, 128);
+            if (op_ == EQUALIZE) equalizeHistNV12(tmp.data(), tmp.data(), width_, height_, uv_);
+            else claheNV12(tmp.data(), tmp.data(), width_, height_, uv_, clip_, tiles_);
+        } catch (const std::exception&) {
+            // reported per frame later; the pool still comes up so submit()/finish() do not hang
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            ++ready_;
+            cv_done_.notify_all();
+        }
         for (;;) {
             FrameJob j;
             {
@@ -151,6 +168,7 @@ private:
     std::vector<std::thread> threads_;
     uint64_t next_index_ = 0, delivered_ = 0;
     bool stop_ = false, delivering_ = false;
+    int ready_ = 0;
     PoolStats stats_;
 };
 
