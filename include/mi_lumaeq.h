@@ -148,6 +148,28 @@ mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* ctx, const void* d_src, size_t sr
                                        double clip_limit, int tiles_x, int tiles_y,
                                        void* d_luts, void* stream);
 
+/* ---- colour-domain neighbours of the path (parity unpinned, see oracle/color_oracle.c) ------
+ * CV_8UC3 interleaved images, row pitch >= 3*width.
+ * mi_cvt_color_u8c3: cv::cvtColor(src, dst, code) for code = MI_COLOR_BGR2YUV (cv::COLOR_BGR2YUV = 82,
+ *   singlecolor.cpp:39, clahe1frame.cpp:83) or MI_COLOR_YUV2BGR (cv::COLOR_YUV2BGR = 84, singlecolor.cpp:66,
+ *   clahe1frame.cpp:102).  src == dst allowed.
+ * mi_bgr_luma_op_u8c3: the whole image-bench sequence in one call -- cvtColor(BGR2YUV) -> split -> equalizeHist
+ *   (op = MI_OP_EQUALIZE, singlecolor.cpp:39-66) or CLAHE (op = MI_OP_CLAHE, clahe1frame.cpp:83-102) on the Y
+ *   plane -> merge -> cvtColor(YUV2BGR); split/merge are fused into the conversion kernels. */
+enum { MI_COLOR_BGR2YUV = 82, MI_COLOR_YUV2BGR = 84 };
+enum { MI_OP_EQUALIZE = 0, MI_OP_CLAHE = 1 };
+mi_status mi_cvt_color_u8c3(mi_ctx* ctx, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step,
+                            int width, int height, int code);
+mi_status mi_cvt_color_u8c3_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                      void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                      int width, int height, int n_frames, int code, void* stream);
+mi_status mi_bgr_luma_op_u8c3(mi_ctx* ctx, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step,
+                              int width, int height, int op, double clip_limit, int tiles_x, int tiles_y);
+mi_status mi_bgr_luma_op_u8c3_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                        void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                        int width, int height, int n_frames, int op,
+                                        double clip_limit, int tiles_x, int tiles_y, void* stream);
+
 /* ---- stream completion + device-side status -------------------------------------------------------
  * The batched equalizeHist forms normally run as ONE fused launch whose workgroups hand data to each
  * other through bounded waits.  mi_ctx_synchronize() waits for `stream` and returns MI_ERR_HIP if such
@@ -162,7 +184,7 @@ mi_status mi_ctx_set_option(mi_ctx* ctx, const char* name, int value);
  * it is launched on (the reference brackets its kernel with CL profiling events the same way,
  * 1frameMeasure.cpp:77-85).  mi_ctx_profile_read() synchronises those events and accumulates. */
 enum { MI_K_HIST = 0, MI_K_EQ_LUT = 1, MI_K_LUT_APPLY = 2, MI_K_TILE_HIST = 3, MI_K_TILE_LUT = 4,
-       MI_K_CLAHE_INTERP = 5, MI_K_FUSED = 6, MI_K_COUNT = 7 };
+       MI_K_CLAHE_INTERP = 5, MI_K_FUSED = 6, MI_K_COLOR = 7, MI_K_COUNT = 8 };
 typedef struct mi_profile {
     double   total_ms[MI_K_COUNT];   /* summed kernel durations since the last reset */
     uint64_t launches[MI_K_COUNT];

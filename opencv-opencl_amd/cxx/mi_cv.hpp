@@ -37,6 +37,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/mi_lumaeq.h"
 
@@ -258,6 +259,75 @@ private:
 inline Ptr<CLAHE> createCLAHE(double clipLimit = 40.0, Size tileGridSize = Size(8, 8))
 {
     return std::make_shared<detail::CLAHE_Impl>(clipLimit, tileGridSize.width, tileGridSize.height);
+}
+
+// ---- colour-domain neighbours: the calls around the luma op in the reference's image benches ----
+// cv::cvtColor(bgr, yuv, cv::COLOR_BGR2YUV) ... cv::cvtColor(yuv, bgr, cv::COLOR_YUV2BGR)   singlecolor.cpp:39/:66,
+//                                                                                           clahe1frame.cpp:83/:102
+constexpr int COLOR_BGR2YUV = MI_COLOR_BGR2YUV, COLOR_YUV2BGR = MI_COLOR_YUV2BGR;     // OpenCV's numeric values (82, 84)
+
+inline void cvtColor(const Mat& src, Mat& dst, int code)
+{
+    MI_CV_ASSERT(code == COLOR_BGR2YUV || code == COLOR_YUV2BGR);
+    MI_CV_ASSERT(src.type() == CV_8UC3);
+    if (src.empty()) return;
+    const Mat s = src;
+    dst.create(s.rows, s.cols, CV_8UC3);
+    mi_ctx* c = detail::thread_ctx();
+    detail::check(c, mi_cvt_color_u8c3(c, s.data, s.step, dst.data, dst.step, s.cols, s.rows, code), "mi_cvt_color_u8c3");
+}
+
+// cv::split / cv::merge for 8-bit images (singlecolor.cpp:44/:61, clahe1frame.cpp:85/:100).  Pure byte shuffles of
+// host Mats, kept on the host like Mat::clone/copyTo; the GPU pipeline below fuses them into the conversions instead.
+inline void split(const Mat& src, std::vector<Mat>& planes)
+{
+    MI_CV_ASSERT(src.depth() == CV_8U);
+    const int cn = src.channels();
+    planes.resize((size_t)cn);
+    for (int k = 0; k < cn; ++k) planes[(size_t)k].create(src.rows, src.cols, CV_8UC1);
+    for (int y = 0; y < src.rows; ++y) {
+        const unsigned char* s = src.ptr(y);
+        for (int k = 0; k < cn; ++k) {
+            unsigned char* d = planes[(size_t)k].ptr(y);
+            for (int x = 0; x < src.cols; ++x) d[x] = s[(size_t)x * cn + k];
+        }
+    }
+}
+inline void merge(const std::vector<Mat>& planes, Mat& dst)
+{
+    MI_CV_ASSERT(!planes.empty());
+    const int cn = (int)planes.size();
+    for (const Mat& p : planes) MI_CV_ASSERT(p.type() == CV_8UC1 && p.rows == planes[0].rows && p.cols == planes[0].cols);
+    const std::vector<Mat> keep = planes;                         // dst may alias one of the planes' headers
+    dst.create(keep[0].rows, keep[0].cols, makeType(CV_8U, cn));
+    for (int y = 0; y < dst.rows; ++y) {
+        unsigned char* d = dst.ptr(y);
+        for (int k = 0; k < cn; ++k) {
+            const unsigned char* s = keep[(size_t)k].ptr(y);
+            for (int x = 0; x < dst.cols; ++x) d[(size_t)x * cn + k] = s[x];
+        }
+    }
+}
+
+// One call for the whole sequence BGR2YUV -> split -> equalizeHist / CLAHE on Y -> merge -> YUV2BGR
+// (singlecolor.cpp:39-66; clahe1frame.cpp:83-102), entirely on the GPU.
+inline void equalizeHistLumaBGR(const Mat& bgr, Mat& dst)
+{
+    MI_CV_ASSERT(bgr.type() == CV_8UC3);
+    if (bgr.empty()) return;
+    const Mat s = bgr;
+    dst.create(s.rows, s.cols, CV_8UC3);
+    mi_ctx* c = detail::thread_ctx();
+    detail::check(c, mi_bgr_luma_op_u8c3(c, s.data, s.step, dst.data, dst.step, s.cols, s.rows, MI_OP_EQUALIZE, 0.0, 1, 1), "mi_bgr_luma_op_u8c3");
+}
+inline void claheLumaBGR(const Mat& bgr, Mat& dst, double clipLimit, Size tiles)
+{
+    MI_CV_ASSERT(bgr.type() == CV_8UC3);
+    if (bgr.empty()) return;
+    const Mat s = bgr;
+    dst.create(s.rows, s.cols, CV_8UC3);
+    mi_ctx* c = detail::thread_ctx();
+    detail::check(c, mi_bgr_luma_op_u8c3(c, s.data, s.step, dst.data, dst.step, s.cols, s.rows, MI_OP_CLAHE, clipLimit, tiles.width, tiles.height), "mi_bgr_luma_op_u8c3");
 }
 
 // ---- whole NV12 frame helpers (what every caller of the reference does around the call) ----

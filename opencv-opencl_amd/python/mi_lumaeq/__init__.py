@@ -5,8 +5,9 @@ cv::Mat adapter in ../../cxx.  Nothing here computes pixels; there is no CPU fal
 library or a GPU is missing the calls raise.
 """
 from .capi import (Context, MiError, lib, lib_path, device_count, version, status_str,
-                   UV_FILL128, UV_COPY, STREAM_CTX, KERNEL_NAMES, DECLARED_SYMBOLS)
+                   UV_FILL128, UV_COPY, STREAM_CTX, KERNEL_NAMES, DECLARED_SYMBOLS,
+                   COLOR_BGR2YUV, COLOR_YUV2BGR, OP_EQUALIZE, OP_CLAHE)
 from . import synth, shard
 
 __all__ = ["Context", "MiError", "lib", "lib_path", "device_count", "version", "status_str",
-           "UV_FILL128", "UV_COPY", "STREAM_CTX", "KERNEL_NAMES", "DECLARED_SYMBOLS", "synth", "shard"]
+           "UV_FILL128", "UV_COPY", "STREAM_CTX", "KERNEL_NAMES", "DECLARED_SYMBOLS", "COLOR_BGR2YUV", "COLOR_YUV2BGR", "OP_EQUALIZE", "OP_CLAHE", "synth", "shard"]

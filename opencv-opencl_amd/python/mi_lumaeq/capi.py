@@ -13,7 +13,9 @@ _LIB_PATH = _ROOT / "lib" / "libmi_lumaeq.so"
 UV_FILL128, UV_COPY = 0, 1
 STREAM_CTX = C.c_void_p(-1).value      # MI_STREAM_CTX: the context's private stream; 0/None = HIP null stream
 KERNEL_NAMES = ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
-                "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel"]
+                "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel"]
+COLOR_BGR2YUV, COLOR_YUV2BGR = 82, 84
+OP_EQUALIZE, OP_CLAHE = 0, 1
 
 # every extern "C" symbol include/mi_lumaeq.h declares (tests check the .so exports them all)
 DECLARED_SYMBOLS = [
@@ -26,6 +28,7 @@ DECLARED_SYMBOLS = [
     "mi_clahe_tile_luts_batch_dev",
     "mi_ctx_set_profiling", "mi_ctx_profile_read", "mi_kernel_name",
     "mi_ctx_synchronize", "mi_ctx_set_option",
+    "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
 ]
 
 _K = len(KERNEL_NAMES)
@@ -88,6 +91,10 @@ def lib() -> C.CDLL:
     L.mi_equalize_lut_batch_dev.argtypes = [vp, vp, i64, i, vp, vp]
     L.mi_lut_apply_u8_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, vp, vp]
     L.mi_clahe_tile_luts_batch_dev.argtypes = [vp, vp, sz, sz, i, i, i, d, i, i, vp, vp]
+    L.mi_cvt_color_u8c3.argtypes = [vp, vp, sz, vp, sz, i, i, i]
+    L.mi_cvt_color_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, vp]
+    L.mi_bgr_luma_op_u8c3.argtypes = [vp, vp, sz, vp, sz, i, i, i, d, i, i]
+    L.mi_bgr_luma_op_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, d, i, i, vp]
     L.mi_ctx_synchronize.argtypes = [vp, vp]
     L.mi_ctx_set_option.argtypes = [vp, C.c_char_p, i]
     L.mi_ctx_set_profiling.argtypes = [vp, i]
@@ -261,6 +268,45 @@ class Context:
         self._chk(lib().mi_clahe_tile_luts_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
                                                      float(clip_limit), tiles_x, tiles_y, _dptr(d_luts), stream),
                   "mi_clahe_tile_luts_batch_dev")
+
+    # ---- colour-domain neighbours (N3) ----
+    @staticmethod
+    def _host3(a, name):
+        if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+            raise MiError(2, name, "expected an HxWx3 uint8 ndarray (CV_8UC3)")
+        if a.size and (a.strides[2] != 1 or a.strides[1] != 3):
+            raise MiError(1, name, "pixels must be interleaved")
+        return a
+
+    def cvt_color(self, src: np.ndarray, code: int, dst: np.ndarray | None = None) -> np.ndarray:
+        src = self._host3(src, "cvt_color")
+        if dst is None or dst.shape != src.shape:
+            dst = np.empty(src.shape, np.uint8)
+        h, w = src.shape[:2]
+        self._chk(lib().mi_cvt_color_u8c3(self._h, src.ctypes.data, int(src.strides[0]) if h > 1 else w * 3, dst.ctypes.data,
+                                          int(dst.strides[0]) if h > 1 else w * 3, w, h, int(code)), "mi_cvt_color_u8c3")
+        return dst
+
+    def bgr_luma_op(self, src: np.ndarray, op: int = OP_EQUALIZE, clip_limit: float = 3.0, tiles_x: int = 4, tiles_y: int = 4,
+                    dst: np.ndarray | None = None) -> np.ndarray:
+        src = self._host3(src, "bgr_luma_op")
+        if dst is None or dst.shape != src.shape:
+            dst = np.empty(src.shape, np.uint8)
+        h, w = src.shape[:2]
+        self._chk(lib().mi_bgr_luma_op_u8c3(self._h, src.ctypes.data, int(src.strides[0]) if h > 1 else w * 3, dst.ctypes.data,
+                                            int(dst.strides[0]) if h > 1 else w * 3, w, h, int(op), float(clip_limit),
+                                            int(tiles_x), int(tiles_y)), "mi_bgr_luma_op_u8c3")
+        return dst
+
+    def cvt_color_batch_dev(self, src, dst, width, height, n_frames, code, stream=0):
+        self._chk(lib().mi_cvt_color_u8c3_batch_dev(self._h, _dptr(src), width * 3, width * 3 * height, _dptr(dst), width * 3,
+                                                    width * 3 * height, width, height, n_frames, int(code), stream),
+                  "mi_cvt_color_u8c3_batch_dev")
+
+    def bgr_luma_op_batch_dev(self, src, dst, width, height, n_frames, op=OP_EQUALIZE, clip_limit=3.0, tiles_x=4, tiles_y=4, stream=0):
+        self._chk(lib().mi_bgr_luma_op_u8c3_batch_dev(self._h, _dptr(src), width * 3, width * 3 * height, _dptr(dst), width * 3,
+                                                      width * 3 * height, width, height, n_frames, int(op), float(clip_limit),
+                                                      int(tiles_x), int(tiles_y), stream), "mi_bgr_luma_op_u8c3_batch_dev")
 
     def synchronize(self, stream=0):
         """Wait for `stream`; raises if the fused kernel reported an expired inter-workgroup wait."""

@@ -29,8 +29,8 @@ _i32p = ctypes.POINTER(ctypes.c_int32)
 
 def build(force: bool = False) -> Path:
     """Compile the C restatement with gcc (oracle/Makefile)."""
-    src = _HERE / "lumaeq_oracle.c"
-    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+    newest = max((_HERE / n).stat().st_mtime for n in ("lumaeq_oracle.c", "color_oracle.c", "Makefile"))
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < newest:
         subprocess.run(["make", "-C", str(_HERE), "-s"] + (["-B"] if force else []), check=True)
     return _LIB_PATH
 
@@ -54,6 +54,11 @@ def lib() -> ctypes.CDLL:
                                    ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
         L.orc_nv12_frame.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        L.orc_bgr2yuv_u8.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+        L.orc_yuv2bgr_u8.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+        L.orc_bgr_luma_op.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        for f in (L.orc_bgr2yuv_u8, L.orc_yuv2bgr_u8, L.orc_bgr_luma_op):
+            f.restype = ctypes.c_int
         for f in (L.orc_hist_u8, L.orc_equalize_lut, L.orc_lut_apply_u8, L.orc_equalize_hist_u8,
                   L.orc_clahe_tile_luts, L.orc_clahe_u8, L.orc_nv12_frame):
             f.restype = ctypes.c_int
@@ -153,6 +158,41 @@ def nv12_frame(frame: np.ndarray, width: int, height: int, uv_mode: int = 0, op:
     _check(lib().orc_nv12_frame(_ptr(frame), _ptr(out), width, height, uv_mode, op,
                                 float(clip_limit), tiles_x, tiles_y), "nv12_frame")
     return out
+
+
+def _as3(a: np.ndarray) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise TypeError("oracle: expected an HxWx3 uint8 array (CV_8UC3)")
+    if a.size and (a.strides[2] != 1 or a.strides[1] != 3):
+        raise ValueError("oracle: pixels must be interleaved and tightly packed within a row")
+    return a
+
+
+def bgr2yuv(src: np.ndarray) -> np.ndarray:
+    """cv::cvtColor(src, COLOR_BGR2YUV) on CV_8UC3 (SURVEY 8f N3; parity unpinned)."""
+    src = _as3(src)
+    dst = np.empty(src.shape, np.uint8)
+    if src.size:
+        _check(lib().orc_bgr2yuv_u8(_ptr(src), int(src.strides[0]), _ptr(dst), int(dst.strides[0]), src.shape[1], src.shape[0]), "bgr2yuv")
+    return dst
+
+
+def yuv2bgr(src: np.ndarray) -> np.ndarray:
+    src = _as3(src)
+    dst = np.empty(src.shape, np.uint8)
+    if src.size:
+        _check(lib().orc_yuv2bgr_u8(_ptr(src), int(src.strides[0]), _ptr(dst), int(dst.strides[0]), src.shape[1], src.shape[0]), "yuv2bgr")
+    return dst
+
+
+def bgr_luma_op(src: np.ndarray, op: int = 0, clip_limit: float = 3.0, tiles_x: int = 4, tiles_y: int = 4) -> np.ndarray:
+    """BGR2YUV -> split -> equalizeHist (op 0) / CLAHE (op 1) on Y -> merge -> YUV2BGR (singlecolor.cpp:39-66, clahe1frame.cpp:83-102)."""
+    src = np.ascontiguousarray(_as3(src))
+    dst = np.empty(src.shape, np.uint8)
+    if src.size:
+        _check(lib().orc_bgr_luma_op(_ptr(src), _ptr(dst), src.shape[1], src.shape[0], op, float(clip_limit), tiles_x, tiles_y), "bgr_luma_op")
+    return dst
 
 
 from .np_oracle import np_equalize_hist, np_clahe, np_clahe_geometry  # noqa: E402,F401

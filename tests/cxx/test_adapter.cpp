@@ -14,6 +14,8 @@ extern "C" {
 int orc_equalize_hist_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int);
 int orc_clahe_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int, double, int, int);
 int orc_nv12_frame(const uint8_t*, uint8_t*, int, int, int, int, double, int, int);
+int orc_bgr_luma_op(const uint8_t*, uint8_t*, int, int, int, double, int, int);
+int orc_bgr2yuv_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int);
 }
 
 static int failures = 0;
@@ -104,6 +106,39 @@ int main()
         EXPECT(memcmp(odd_out.data, r3.data(), r3.size()) == 0);
         c2->collectGarbage();
         EXPECT(createCLAHE()->getClipLimit() == 40.0 && createCLAHE()->getTilesGridSize() == Size(8, 8));
+    }
+    // --- singlecolor.cpp:39-66 written call for call: cvtColor -> split -> equalizeHist(Y) -> merge -> cvtColor,
+    //     and the one-call GPU form of the same sequence; clahe1frame.cpp:83-102 likewise
+    {
+        const int CW = 321, CH = 199;                                  // odd size: CLAHE padding path
+        std::vector<uint8_t> bgrbuf((size_t)CW * CH * 3), want((size_t)CW * CH * 3);
+        fill(bgrbuf, 7);
+        Mat bgr_image(CH, CW, CV_8UC3, bgrbuf.data());
+        Mat yuv_image;
+        cvtColor(bgr_image, yuv_image, COLOR_BGR2YUV);
+        std::vector<uint8_t> yref((size_t)CW * CH * 3);
+        orc_bgr2yuv_u8(bgrbuf.data(), (size_t)CW * 3, yref.data(), (size_t)CW * 3, CW, CH);
+        EXPECT(memcmp(yuv_image.data, yref.data(), yref.size()) == 0);
+        std::vector<Mat> yuv_channels;
+        split(yuv_image, yuv_channels);
+        Mat y_equalized;
+        equalizeHist(yuv_channels[0], y_equalized);
+        std::vector<Mat> enhanced = {y_equalized, yuv_channels[1], yuv_channels[2]};
+        Mat enhanced_yuv, enhanced_bgr;
+        merge(enhanced, enhanced_yuv);
+        cvtColor(enhanced_yuv, enhanced_bgr, COLOR_YUV2BGR);
+        orc_bgr_luma_op(bgrbuf.data(), want.data(), CW, CH, 0, 0.0, 1, 1);
+        EXPECT(enhanced_bgr.type() == CV_8UC3 && memcmp(enhanced_bgr.data, want.data(), want.size()) == 0);
+        Mat fused;
+        equalizeHistLumaBGR(bgr_image, fused);
+        EXPECT(memcmp(fused.data, want.data(), want.size()) == 0);
+        Mat fused_clahe;
+        claheLumaBGR(bgr_image, fused_clahe, 3.0, Size(4, 4));
+        orc_bgr_luma_op(bgrbuf.data(), want.data(), CW, CH, 1, 3.0, 4, 4);
+        EXPECT(memcmp(fused_clahe.data, want.data(), want.size()) == 0);
+        bool threw = false;
+        try { Mat g(4, 4, CV_8UC1), o; cvtColor(g, o, COLOR_BGR2YUV); } catch (const std::exception&) { threw = true; }
+        EXPECT(threw);
     }
     // --- worker pool: 3 workers, 24 frames, in-order delivery, both UV modes (A7, A8)
     for (int uv = 0; uv < 2; ++uv) {

@@ -322,3 +322,48 @@ def test_unaligned_device_batches(ctx):
         out = d_out.cpu().numpy().reshape(n, fb)
         for k in range(n):
             assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8)), (k, uv_mode)
+
+
+def _bgr(w, h, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    img[: h // 2] = (img[: h // 2] // 3 + 60).astype(np.uint8)      # a low-contrast half
+    return img
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (47, 63), (48, 64), (270, 480), (1079, 1919), (1080, 1920)], ids=str)
+def test_color_neighbours(ctx, shape):
+    """cvtColor BGR2YUV / YUV2BGR and the whole singlecolor.cpp / clahe1frame.cpp sequence."""
+    h, w = shape
+    a = _bgr(w, h, 5)
+    yuv = ctx.cvt_color(a, mi_lumaeq.COLOR_BGR2YUV)
+    assert np.array_equal(yuv, oracle.bgr2yuv(a))
+    assert np.array_equal(ctx.cvt_color(yuv, mi_lumaeq.COLOR_YUV2BGR), oracle.yuv2bgr(yuv))
+    assert np.array_equal(ctx.bgr_luma_op(a, mi_lumaeq.OP_EQUALIZE), oracle.bgr_luma_op(a, 0))
+    assert np.array_equal(ctx.bgr_luma_op(a, mi_lumaeq.OP_CLAHE, 3.0, 4, 4), oracle.bgr_luma_op(a, 1, 3.0, 4, 4))
+    inplace = a.copy()
+    ctx.cvt_color(inplace, mi_lumaeq.COLOR_BGR2YUV, inplace)
+    assert np.array_equal(inplace, yuv)
+
+
+def test_color_strided_and_batch(ctx):
+    big = _bgr(400, 300, 9)
+    view = big[11:289, 7:391]                                    # row pitch 1200 > 3*384, unaligned start
+    assert np.array_equal(ctx.cvt_color(view, mi_lumaeq.COLOR_BGR2YUV), oracle.bgr2yuv(view))
+    assert np.array_equal(ctx.bgr_luma_op(view, mi_lumaeq.OP_EQUALIZE), oracle.bgr_luma_op(np.ascontiguousarray(view), 0))
+    w, h, n = 640, 360, 3
+    frames = np.stack([_bgr(w, h, 20 + k) for k in range(n)])
+    d_in = dev(frames)
+    d_out = torch.empty_like(d_in)
+    ctx.bgr_luma_op_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.OP_EQUALIZE)
+    ctx.synchronize()
+    out = d_out.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(out[k], oracle.bgr_luma_op(frames[k], 0)), k
+    ctx.cvt_color_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.COLOR_BGR2YUV)
+    ctx.synchronize()
+    out = d_out.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(out[k], oracle.bgr2yuv(frames[k])), k
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.cvt_color(frames[0], 4)                              # unsupported conversion code

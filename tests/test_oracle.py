@@ -144,3 +144,34 @@ def test_golden_fixtures():
             clip, tx, ty = z[n + "__cfg"]
             got = oracle.clahe(src, float(clip), int(tx), int(ty))
         assert np.array_equal(got, z[n + "__dst"]), n
+
+
+def test_color_conversion_kats():
+    """SURVEY 8f N3 (parity unpinned): hand-computed BT.601 fixed-point values of COLOR_BGR2YUV / COLOR_YUV2BGR."""
+    px = np.array([[[255, 255, 255], [255, 0, 0], [0, 0, 0], [128, 128, 128], [0, 0, 255]]], np.uint8)   # B,G,R
+    yuv = oracle.bgr2yuv(px).reshape(-1, 3).tolist()
+    assert yuv[0] == [255, 128, 128] and yuv[2] == [0, 128, 128] and yuv[3] == [128, 128, 128]
+    assert yuv[1] == [29, 239, 103]              # pure blue: Y=(255*1868+8192)>>14, U=((226*8061)+(128<<14)+8192)>>14 ...
+    assert yuv[4] == [76, 91, 255]               # pure red: V saturates
+    back = oracle.yuv2bgr(oracle.bgr2yuv(px)).reshape(-1, 3).tolist()
+    assert back[0] == [255, 255, 255] and back[1] == [255, 0, 0] and back[2] == [0, 0, 0] and back[3] == [128, 128, 128]
+    # independent numpy restatement
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    b, g, r = [a[..., i].astype(np.int64) for i in range(3)]
+    Y = (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14
+    U = ((b - Y) * 8061 + (128 << 14) + 8192) >> 14
+    V = ((r - Y) * 14369 + (128 << 14) + 8192) >> 14
+    ref = np.stack([np.clip(Y, 0, 255), np.clip(U, 0, 255), np.clip(V, 0, 255)], -1).astype(np.uint8)
+    assert np.array_equal(oracle.bgr2yuv(a), ref)
+    y, u, v = [ref[..., i].astype(np.int64) for i in range(3)]
+    B = y + (((u - 128) * 33292 + 8192) >> 14)
+    G = y + (((u - 128) * -6472 + (v - 128) * -9519 + 8192) >> 14)
+    R = y + (((v - 128) * 18678 + 8192) >> 14)
+    ref2 = np.stack([np.clip(B, 0, 255), np.clip(G, 0, 255), np.clip(R, 0, 255)], -1).astype(np.uint8)
+    assert np.array_equal(oracle.yuv2bgr(ref), ref2)
+    # composite pipeline = the pieces
+    yuv_img = oracle.bgr2yuv(a)
+    yuv_img2 = yuv_img.copy()
+    yuv_img2[..., 0] = oracle.equalize_hist(np.ascontiguousarray(yuv_img[..., 0]))
+    assert np.array_equal(oracle.bgr_luma_op(a, 0), oracle.yuv2bgr(yuv_img2))

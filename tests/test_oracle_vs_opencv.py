@@ -29,3 +29,11 @@ def test_clahe_matches_cv2(shape, cfg):
         src = synth.y_plane(w, h, dist, 32)
         want = cv2.createCLAHE(clipLimit=clip, tileGridSize=(tx, ty)).apply(src)
         assert np.array_equal(oracle.clahe(src, clip, tx, ty), want), (dist, cv2.__version__)
+
+
+def test_color_conversions_match_cv2():
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    yuv = cv2.cvtColor(a, cv2.COLOR_BGR2YUV)
+    assert np.array_equal(oracle.bgr2yuv(a), yuv)
+    assert np.array_equal(oracle.yuv2bgr(yuv), cv2.cvtColor(yuv, cv2.COLOR_YUV2BGR))
