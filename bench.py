@@ -323,6 +323,17 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     d_out = torch.empty_like(d_in)
     ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 10)
     res["clahe8x8_batch_frames_per_s"] = round(B / (ms * 1e-3), 1)
+    del d_in, d_out
+    # BASELINE.json configs[4] taken literally (parity unpinned): BGR -> YUV -> equalize Y -> BGR on
+    # 3-channel 4K images (the sequence of singlecolor.cpp:39-66); the file that config names,
+    # ColoropenCVCwqualHist.cpp, actually does Y-only + UV passthrough = `--uv copy` of the main metric.
+    Bc = 16
+    bgr = torch.randint(0, 256, (Bc, h, w, 3), dtype=torch.uint8, device="cuda")
+    bgr_out = torch.empty_like(bgr)
+    ms = timeit(lambda: ctx.bgr_luma_op_batch_dev(bgr, bgr_out, w, h, Bc, mi_lumaeq.OP_EQUALIZE, stream=stream), 10)
+    res["bgr_yuv_equalize_bgr_frames_per_s"] = round(Bc / (ms * 1e-3), 1)
+    ms = timeit(lambda: ctx.cvt_color_batch_dev(bgr, bgr_out, w, h, Bc, mi_lumaeq.COLOR_BGR2YUV, stream=stream), 10)
+    res["cvtcolor_bgr2yuv_GBs"] = round(2 * 3 * w * h * Bc / (ms * 1e-3) / 1e9, 1)
     return res
 
 
