@@ -10,6 +10,7 @@
 #include "lumaeq_kernels.hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -26,8 +27,19 @@ struct PendingEvent { hipEvent_t a, b; int kernel; };
 
 }  // namespace
 
+// Concurrency guard for the fused kernel.  Its workgroups wait for each other, so every slice of a frame (T
+// workgroups) must be co-resident.  Several contexts may run fused launches on one GPU at the same time (the
+// worker pool does); each launch is then only guaranteed a share of the chip.  At most kMaxFusedCtxPerDevice live
+// contexts per device get the fused path (later ones use the three-kernel path), and a frame is only fused when
+// T <= (CUs * WGs/CU) / (2 * kMaxFusedCtxPerDevice), i.e. a launch that receives half of its fair share still
+// has all of a frame's slices resident.  (Other processes on the GPU are covered by the bounded waits.)
+constexpr int kMaxDevices = 64;
+constexpr int kMaxFusedCtxPerDevice = 4;
+static std::atomic<int> g_fused_ctx_live[kMaxDevices];
+
 struct mi_ctx {
     int device = -1;
+    bool fused_slot = false;                                     // this context holds one of the per-device fused slots
     hipStream_t stream = nullptr;
     std::mutex mu;
     int last_hip = 0;
@@ -225,14 +237,14 @@ mi_status launch_apply(mi_ctx* c, hipStream_t s, const PlaneArgs& a, int f0, int
 //   [0..31] work counter (u64) | [32..63] status | cnt[nf][32] | ready[nf][32] | ghist[nf][256] | lutpub[nf][128]
 bool fused_applicable(const mi_ctx* c, const PlaneArgs& a, const UVJob* uv)
 {
-    if (!c->fused_mode) return false;
+    if (!c->fused_mode || !c->fused_slot) return false;
     if (a.src_step != (size_t)a.width || a.dst_step != (size_t)a.width) return false;      // contiguous planes only
     const long long ysz = (long long)a.width * a.height;
     if (ysz % 16 != 0) return false;
     if (((uintptr_t)a.src | (uintptr_t)a.dst | a.src_frame | a.dst_frame) & 15) return false;
     const long long slice = (long long)kThreads * c->fused_vpt;
     const long long T = (ysz / 16 + slice - 1) / slice;
-    if (T > c->cu_count) return false;                      // every slice of a frame must be co-resident (see KF): one WG per CU always is
+    if (T > (long long)c->cu_count * c->fused_wgs_per_cu / (2 * kMaxFusedCtxPerDevice)) return false;   // co-residency guard (see g_fused_ctx_live)
     if (a.n_frames > (1 << 20)) return false;
     (void)uv;
     return true;
@@ -497,6 +509,10 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount;
+    if (device < kMaxDevices) {
+        if (g_fused_ctx_live[device].fetch_add(1) < kMaxFusedCtxPerDevice) c->fused_slot = true;
+        else g_fused_ctx_live[device].fetch_sub(1);
+    }
     if (const char* e = getenv("MI_LUMAEQ_FUSED")) c->fused_mode = atoi(e);
     if (const char* e = getenv("MI_LUMAEQ_FUSED_WGS_PER_CU")) c->fused_wgs_per_cu = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("MI_LUMAEQ_FUSED_VPT")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 20 || v == 24) c->fused_vpt = v; }
@@ -508,6 +524,7 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
 void mi_ctx_destroy(mi_ctx* c)
 {
     if (!c) return;
+    if (c->fused_slot && c->device >= 0 && c->device < kMaxDevices) g_fused_ctx_live[c->device].fetch_sub(1);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

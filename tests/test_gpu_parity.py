@@ -367,3 +367,74 @@ def test_color_strided_and_batch(ctx):
         assert np.array_equal(out[k], oracle.bgr2yuv(frames[k])), k
     with pytest.raises(mi_lumaeq.MiError):
         ctx.cvt_color(frames[0], 4)                              # unsupported conversion code
+
+
+def test_randomized_differential(ctx):
+    """Seeded random differential test, HIP vs oracle: random shapes (1..260), row pitches, ROI offsets, in-place,
+    tile grids (1..20), clip limits, distributions -- 160 cases through the host forms, plus random device batches."""
+    rng = np.random.default_rng(20260101)
+    for case in range(160):
+        h = int(rng.integers(1, 261)); w = int(rng.integers(1, 261))
+        pad_l = int(rng.integers(0, 20)); pad_r = int(rng.integers(0, 20)); pad_t = int(rng.integers(0, 3))
+        kind = int(rng.integers(0, 4))
+        big = np.zeros((h + pad_t + 2, w + pad_l + pad_r), np.uint8)
+        view = big[pad_t:pad_t + h, pad_l:pad_l + w]
+        if kind == 0:
+            view[:] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 1:
+            lo = int(rng.integers(0, 200)); hi = lo + int(rng.integers(1, 56))
+            view[:] = rng.integers(lo, hi + 1, (h, w), dtype=np.uint8)
+        elif kind == 2:
+            view[:] = int(rng.integers(0, 256))
+        else:
+            view[:] = (np.add.outer(np.arange(h), np.arange(w)) * int(rng.integers(1, 5)) % 256).astype(np.uint8)
+        want = oracle.equalize_hist(view)
+        got = ctx.equalize_hist(view)
+        assert np.array_equal(got, want), ("equalize", case, h, w, kind)
+        tx = int(rng.integers(1, 21)); ty = int(rng.integers(1, 21))
+        clip = float(rng.choice([0.0, 0.5, 1.0, 2.0, 3.0, 7.5, 40.0]))
+        wantc = oracle.clahe(view, clip, tx, ty)
+        assert np.array_equal(ctx.clahe(view, clip, tx, ty), wantc), ("clahe", case, h, w, kind, clip, tx, ty)
+        if case % 4 == 0:                                       # in place through a strided view
+            buf = big.copy(); v2 = buf[pad_t:pad_t + h, pad_l:pad_l + w]
+            ctx.equalize_hist(v2, v2)
+            assert np.array_equal(v2, want) and buf[:pad_t].sum() == 0, ("inplace", case)
+    for case in range(12):                                      # device NV12 batches of random even sizes
+        w = int(rng.integers(1, 80)) * 2; h = int(rng.integers(1, 60)) * 2; n = int(rng.integers(1, 9))
+        frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[int(rng.integers(0, 5))], 300 + case * 10 + k) for k in range(n)])
+        d_in = dev(frames)
+        d_out = torch.zeros_like(d_in)
+        uv_mode = int(rng.integers(0, 2))
+        ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode)
+        ctx.synchronize()
+        out = d_out.cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), ("nv12", case, w, h, k)
+        tx = int(rng.integers(1, 12)); ty = int(rng.integers(1, 12))
+        ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode, 2.0, tx, ty)
+        ctx.synchronize()
+        out = d_out.cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=1, clip_limit=2.0, tiles_x=tx, tiles_y=ty)), ("nv12-clahe", case, w, h, k)
+
+
+def test_many_contexts_share_one_gpu():
+    """More contexts than fused slots on one device: the extra ones take the three-kernel path; all agree."""
+    w, h, n = 1920, 1080, 4
+    frames = np.stack([synth.nv12_frame(w, h, "D2", 500 + k) for k in range(n)])
+    d_in = dev(frames)
+    want = [oracle.nv12_frame(frames[k], w, h, uv_mode=0, op=0) for k in range(n)]
+    ctxs = [mi_lumaeq.Context(0) for _ in range(7)]
+    try:
+        outs = [torch.zeros_like(d_in) for _ in ctxs]
+        for c, o in zip(ctxs, outs):
+            c.equalize_hist_nv12_batch_dev(d_in, o, w, h, n, 0, stream=mi_lumaeq.STREAM_CTX)   # 7 private streams, concurrently
+        for c in ctxs:
+            c.synchronize(mi_lumaeq.STREAM_CTX)
+        for o in outs:
+            got = o.cpu().numpy()
+            for k in range(n):
+                assert np.array_equal(got[k], want[k])
+    finally:
+        for c in ctxs:
+            c.close()
