@@ -148,6 +148,14 @@ mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* ctx, const void* d_src, size_t sr
                                        double clip_limit, int tiles_x, int tiles_y,
                                        void* d_luts, void* stream);
 
+/* ---- optional: pin caller-owned host buffers ----------------------------------------------------------------
+ * Video pipelines recycle a small pool of frame buffers (GstBufferPool; the reference maps such buffers at
+ * OpenCVequalHist.cpp:115/:158).  Registering a pool's memory once lets the host-pointer forms DMA straight
+ * from / into it instead of staging through the context's pinned buffers (contiguous planes only; anything
+ * else still stages).  Process-wide, thread-safe; the memory must stay valid until mi_host_unregister(). */
+mi_status mi_host_register(void* ptr, size_t bytes);
+mi_status mi_host_unregister(void* ptr);
+
 /* ---- colour-domain neighbours of the path (parity unpinned, see oracle/color_oracle.c) ------
  * CV_8UC3 interleaved images, row pitch >= 3*width.
  * mi_cvt_color_u8c3: cv::cvtColor(src, dst, code) for code = MI_COLOR_BGR2YUV (cv::COLOR_BGR2YUV = 82,

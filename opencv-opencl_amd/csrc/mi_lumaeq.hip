@@ -33,6 +33,19 @@ struct PendingEvent { hipEvent_t a, b; int kernel; };
 // contexts per device get the fused path (later ones use the three-kernel path), and a frame is only fused when
 // T <= (CUs * WGs/CU) / (2 * kMaxFusedCtxPerDevice), i.e. a launch that receives half of its fair share still
 // has all of a frame's slices resident.  (Other processes on the GPU are covered by the bounded waits.)
+// process-wide registry of caller-pinned host ranges (mi_host_register)
+struct PinnedRange { uintptr_t lo, hi; };
+static std::mutex g_pin_mu;
+static std::vector<PinnedRange> g_pinned;
+static bool host_range_pinned(const void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return false;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const auto& r : g_pinned) if (lo >= r.lo && hi <= r.hi) return true;
+    return false;
+}
+
 constexpr int kMaxDevices = 64;
 constexpr int kMaxFusedCtxPerDevice = 4;
 static std::atomic<int> g_fused_ctx_live[kMaxDevices];
@@ -572,6 +585,30 @@ mi_status mi_ctx_profile_read(mi_ctx* c, mi_profile* out, int reset)
     return MI_OK;
 }
 
+mi_status mi_host_register(void* ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0) return MI_ERR_BAD_ARG;
+    if (mi_device_count() <= 0) return MI_ERR_NO_DEVICE;
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinned.push_back({(uintptr_t)ptr, (uintptr_t)ptr + bytes});
+    return MI_OK;
+}
+
+mi_status mi_host_unregister(void* ptr)
+{
+    if (!ptr) return MI_ERR_BAD_ARG;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [&](const PinnedRange& r) { return r.lo == (uintptr_t)ptr; });
+        if (it == g_pinned.end()) return MI_ERR_BAD_ARG;
+        g_pinned.erase(it);
+    }
+    if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return MI_ERR_HIP; }
+    return MI_OK;
+}
+
 mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
 {
     ENTER(c);
@@ -751,18 +788,25 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, frame_bytes))) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, frame_bytes))) return st;
     hipStream_t s = c->stream;
+    // Caller-pinned, contiguous buffers (mi_host_register) are DMA'd directly; everything else is staged.
+    const bool in_direct = src_step == (size_t)width && host_range_pinned(src, in_bytes);
+    const bool out_direct = dst_step == (size_t)width && host_range_pinned(dst, frame_bytes);
     // Chunked staging: the host copy of chunk i+1 into pinned memory overlaps the DMA of chunk i (and the other
     // way round on the way back), so a frame costs ~max(memcpy, PCIe) per direction instead of their sum.
     const int rows_per_chunk = std::max(1, (int)((size_t)(2u << 20) / (size_t)width));
-    for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
-        const int nr = std::min(rows_per_chunk, height - y0);
-        const size_t off = (size_t)y0 * width;
-        copy_rows(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
-        HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, s));
-    }
-    if (copy_uv_in) {                                           // tightly packed NV12 (src_step == width)
-        memcpy(c->h_pin_in + ybytes, src + ybytes, uvbytes);
-        HIPCHK(c, hipMemcpyAsync(c->d_stage_in + ybytes, c->h_pin_in + ybytes, uvbytes, hipMemcpyHostToDevice, s));
+    if (in_direct) {
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_in, src, in_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
+            const int nr = std::min(rows_per_chunk, height - y0);
+            const size_t off = (size_t)y0 * width;
+            copy_rows(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
+            HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, s));
+        }
+        if (copy_uv_in) {                                           // tightly packed NV12 (src_step == width)
+            memcpy(c->h_pin_in + ybytes, src + ybytes, uvbytes);
+            HIPCHK(c, hipMemcpyAsync(c->d_stage_in + ybytes, c->h_pin_in + ybytes, uvbytes, hipMemcpyHostToDevice, s));
+        }
     }
     PlaneArgs a{c->d_stage_in, (size_t)width, frame_bytes, c->d_stage_out, (size_t)width, frame_bytes, width, height, 1};
     UVJob uv{};
@@ -770,6 +814,20 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     st = is_clahe ? clahe_dev(c, s, a, clip_limit, tiles_x, tiles_y, nv12_mode >= 0 ? &uv : nullptr)
                   : equalize_dev(c, s, a, nv12_mode >= 0 ? &uv : nullptr);
     if (st) return st;
+    const bool check_status = !is_clahe && c->d_fused;
+    if (check_status) {
+        if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
+        HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    if (out_direct) {
+        HIPCHK(c, hipMemcpyAsync(dst, c->d_stage_out, frame_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (check_status && *c->h_status != 0) {
+            c->fused_dirty = true;
+            return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+        }
+        return MI_OK;
+    }
     // device -> pinned in chunks, each followed by an event; then drain chunk by chunk into the caller's rows
     struct Chunk { size_t off, bytes; int y0, nr; };
     std::vector<Chunk> chunks;
@@ -782,11 +840,6 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         hipEvent_t e;
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->chunk_events.push_back(e);
-    }
-    const bool check_status = !is_clahe && c->d_fused;
-    if (check_status) {
-        if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
-        HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     for (size_t i = 0; i < chunks.size(); ++i) {
         HIPCHK(c, hipMemcpyAsync(c->h_pin_out + chunks[i].off, c->d_stage_out + chunks[i].off, chunks[i].bytes, hipMemcpyDeviceToHost, s));

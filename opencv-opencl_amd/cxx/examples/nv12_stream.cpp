@@ -34,7 +34,7 @@ int main(int argc, char** argv)
     using namespace micv;
     int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8;
     double clip = 2.0;
-    bool paced = false;
+    bool paced = false, pin = false;
     std::string op = "equalize", uv = "fill128", input, output, v;
     for (int i = 1; i < argc; ++i) {
         if (kv(argv[i], "workers", v, i, argc, argv)) workers = std::max(1, std::min(8, atoi(v.c_str())));
@@ -49,6 +49,7 @@ int main(int argc, char** argv)
         else if (kv(argv[i], "input", v, i, argc, argv)) input = v;
         else if (kv(argv[i], "output", v, i, argc, argv)) output = v;
         else if (strcmp(argv[i], "--paced") == 0) paced = true;
+        else if (strcmp(argv[i], "--pin") == 0) pin = true;          // register the frame ring like a pinned GstBufferPool
         else fprintf(stderr, "Warning: ignoring unknown arg: %s\n", argv[i]);
     }
     if (width <= 0 || height <= 0 || frames <= 0) { fprintf(stderr, "bad size\n"); return 1; }
@@ -70,6 +71,7 @@ int main(int argc, char** argv)
     std::vector<std::chrono::steady_clock::time_point> t_submit((size_t)frames);
     std::vector<float> latency_ms((size_t)frames, -1.f);
     try {
+        if (pin) for (int k = 0; k < ring; ++k) { registerHostBuffer(in[k].data(), fb); registerHostBuffer(out[k].data(), fb); }
         std::atomic<uint64_t> delivered{0};
         FramePool pool(workers, width, height, op == "clahe" ? FramePool::CLAHE_OP : FramePool::EQUALIZE,
                        uv == "copy" ? UV_COPY : UV_FILL128,
@@ -81,8 +83,8 @@ int main(int argc, char** argv)
                            delivered.fetch_add(1);
                        },
                        clip, Size(tile, tile), ring / (size_t)workers > 2 ? ring / (size_t)workers - 1 : 1);
-        printf("nv12_stream: %dx%d %s uv=%s workers=%d gpus=%d frames=%d%s\n", width, height, op.c_str(), uv.c_str(), workers,
-               getDeviceCount(), frames, paced ? " paced" : "");
+        printf("nv12_stream: %dx%d %s uv=%s workers=%d gpus=%d frames=%d%s%s\n", width, height, op.c_str(), uv.c_str(), workers,
+               getDeviceCount(), frames, paced ? " paced" : "", pin ? " pinned-ring" : "");
         const auto t0 = std::chrono::steady_clock::now();
         auto last_tick = t0;
         uint64_t last_out = 0;
@@ -123,6 +125,7 @@ int main(int argc, char** argv)
                    lat[lat.size() / 2], lat[lat.size() * 9 / 10], lat[std::min(lat.size() - 1, lat.size() * 99 / 100)], lat.back(), budget, late,
                    paced ? "" : "  (unpaced: latency includes queueing)");
         }
+        if (pin) for (int k = 0; k < ring; ++k) { unregisterHostBuffer(in[k].data()); unregisterHostBuffer(out[k].data()); }
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

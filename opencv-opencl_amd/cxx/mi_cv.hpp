@@ -330,6 +330,14 @@ inline void claheLumaBGR(const Mat& bgr, Mat& dst, double clipLimit, Size tiles)
     detail::check(c, mi_bgr_luma_op_u8c3(c, s.data, s.step, dst.data, dst.step, s.cols, s.rows, MI_OP_CLAHE, clipLimit, tiles.width, tiles.height), "mi_bgr_luma_op_u8c3");
 }
 
+// Pin a recycled frame-buffer pool once so the host forms DMA straight from / into it (mi_host_register).
+inline void registerHostBuffer(void* ptr, size_t bytes)
+{
+    const mi_status st = mi_host_register(ptr, bytes);
+    if (st != MI_OK) MI_CV_ERROR(st == MI_ERR_NO_DEVICE ? GpuNotSupported : GpuApiCallError, std::string("mi_host_register: ") + mi_status_str(st));
+}
+inline void unregisterHostBuffer(void* ptr) { (void)mi_host_unregister(ptr); }
+
 // ---- whole NV12 frame helpers (what every caller of the reference does around the call) ----
 enum UVMode { UV_FILL128 = MI_UV_FILL128, UV_COPY = MI_UV_COPY };
 

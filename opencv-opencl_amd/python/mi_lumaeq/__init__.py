@@ -4,10 +4,10 @@ This is glue, not the product: the product is the C ABI + HIP kernels in ../../c
 cv::Mat adapter in ../../cxx.  Nothing here computes pixels; there is no CPU fallback -- if the
 library or a GPU is missing the calls raise.
 """
-from .capi import (Context, MiError, lib, lib_path, device_count, version, status_str,
+from .capi import (Context, MiError, host_register, host_unregister, lib, lib_path, device_count, version, status_str,
                    UV_FILL128, UV_COPY, STREAM_CTX, KERNEL_NAMES, DECLARED_SYMBOLS,
                    COLOR_BGR2YUV, COLOR_YUV2BGR, OP_EQUALIZE, OP_CLAHE)
 from . import synth, shard
 
-__all__ = ["Context", "MiError", "lib", "lib_path", "device_count", "version", "status_str",
+__all__ = ["Context", "MiError", "host_register", "host_unregister", "lib", "lib_path", "device_count", "version", "status_str",
            "UV_FILL128", "UV_COPY", "STREAM_CTX", "KERNEL_NAMES", "DECLARED_SYMBOLS", "COLOR_BGR2YUV", "COLOR_YUV2BGR", "OP_EQUALIZE", "OP_CLAHE", "synth", "shard"]

@@ -28,6 +28,7 @@ DECLARED_SYMBOLS = [
     "mi_clahe_tile_luts_batch_dev",
     "mi_ctx_set_profiling", "mi_ctx_profile_read", "mi_kernel_name",
     "mi_ctx_synchronize", "mi_ctx_set_option",
+    "mi_host_register", "mi_host_unregister",
     "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
 ]
 
@@ -95,6 +96,8 @@ def lib() -> C.CDLL:
     L.mi_cvt_color_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, vp]
     L.mi_bgr_luma_op_u8c3.argtypes = [vp, vp, sz, vp, sz, i, i, i, d, i, i]
     L.mi_bgr_luma_op_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, d, i, i, vp]
+    L.mi_host_register.argtypes = [vp, sz]
+    L.mi_host_unregister.argtypes = [vp]
     L.mi_ctx_synchronize.argtypes = [vp, vp]
     L.mi_ctx_set_option.argtypes = [vp, C.c_char_p, i]
     L.mi_ctx_set_profiling.argtypes = [vp, i]
@@ -116,6 +119,19 @@ def version() -> str:
 
 def device_count() -> int:
     return int(lib().mi_device_count())
+
+
+def host_register(a: np.ndarray) -> None:
+    """Pin a caller-owned numpy buffer (mi_host_register); keep `a` alive until host_unregister(a)."""
+    rc = lib().mi_host_register(a.ctypes.data, a.nbytes)
+    if rc != 0:
+        raise MiError(rc, "mi_host_register")
+
+
+def host_unregister(a: np.ndarray) -> None:
+    rc = lib().mi_host_unregister(a.ctypes.data)
+    if rc != 0:
+        raise MiError(rc, "mi_host_unregister")
 
 
 def _host2d(a: np.ndarray, name: str) -> np.ndarray:

@@ -438,3 +438,30 @@ def test_many_contexts_share_one_gpu():
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_registered_host_buffers(ctx):
+    """mi_host_register: caller-pinned contiguous buffers are DMA'd directly; results identical, views still stage."""
+    w, h = 1280, 720
+    frame = synth.nv12_frame(w, h, "D2", 123).copy()
+    out = np.zeros_like(frame)
+    mi_lumaeq.host_register(frame)
+    mi_lumaeq.host_register(out)
+    try:
+        for uv_mode in (0, 1):
+            ctx.equalize_hist_nv12(frame, w, h, uv_mode, out=out)
+            assert np.array_equal(out, oracle.nv12_frame(frame, w, h, uv_mode=uv_mode, op=0))
+            ctx.clahe_nv12(frame, w, h, uv_mode, 2.0, 8, 8, out=out)
+            assert np.array_equal(out, oracle.nv12_frame(frame, w, h, uv_mode=uv_mode, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
+        y = frame[: w * h].reshape(h, w)
+        want = oracle.equalize_hist(y)
+        assert np.array_equal(ctx.equalize_hist(y), want)                       # pinned src, staged dst
+        roi = y[10:700, 16:1200]
+        assert np.array_equal(ctx.equalize_hist(roi), oracle.equalize_hist(roi))   # strided view of pinned memory: staged
+        ctx.equalize_hist(y, y)                                                  # in place in pinned memory
+        assert np.array_equal(y, want)
+    finally:
+        mi_lumaeq.host_unregister(frame)
+        mi_lumaeq.host_unregister(out)
+    with pytest.raises(mi_lumaeq.MiError):
+        mi_lumaeq.host_unregister(out)                                           # not registered any more
