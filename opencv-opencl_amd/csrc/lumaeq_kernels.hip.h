@@ -373,6 +373,13 @@ struct FusedShared {
     int last, ok, timeout;
 };
 
+// Zeroes the hand-off block (a plain kernel instead of hipMemsetAsync: it is captured into HIP graphs like any
+// other launch; a memset node did not re-run on graph replay in testing).
+__global__ __launch_bounds__(kThreads) void zero_words_kernel(uint32_t* p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) p[i] = 0;
+}
+
 template <int VPT>
 __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
 {

@@ -67,6 +67,9 @@ struct mi_ctx {
     unsigned long long fused_work_base = 0;                      // value of the device ticket counter at the next launch
     uint32_t fused_epoch = 0;
     bool fused_dirty = true;                                     // block must be zeroed before the next launch
+    bool fused_capture_safe = false;                             // set once a call was seen inside a stream capture (hipGraph):
+                                                                 // from then on every launch zeroes the block itself and uses
+                                                                 // constant epoch / ticket base, so a captured graph can be replayed
     uint32_t* h_status = nullptr;                                // pinned mirror of the device status word
     int fused_mode = 1;                                          // MI_LUMAEQ_FUSED=0 forces the 3-kernel path
     int fused_wgs_per_cu = 4;                                    // MI_LUMAEQ_FUSED_WGS_PER_CU
@@ -286,10 +289,19 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
         c->fused_cap = cap;
         c->fused_dirty = true;
     }
-    if (c->fused_dirty) {                                    // first use, re-layout, or after a reported device-side failure
-        HIPCHK(c, hipMemsetAsync(c->d_fused, 0, c->fused_bytes, s));
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) c->fused_capture_safe = true;
+        else (void)hipGetLastError();
+    }
+    if (c->fused_dirty || c->fused_capture_safe) {           // first use, re-layout, reported failure, or graph-replayable mode
+        const size_t nwords = c->fused_bytes / sizeof(uint32_t);
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (nwords + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           c->d_fused, nwords);
+        HIPCHK(c, hipGetLastError());
         c->fused_work_base = 0;
         c->fused_dirty = false;
+        if (c->fused_capture_safe) c->fused_epoch = 0;           // -> epoch 1 below, the same for every (re)play
     }
     const size_t cap = c->fused_cap;
     uint32_t* w = c->d_fused;

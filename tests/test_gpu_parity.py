@@ -465,3 +465,39 @@ def test_registered_host_buffers(ctx):
         mi_lumaeq.host_unregister(out)
     with pytest.raises(mi_lumaeq.MiError):
         mi_lumaeq.host_unregister(out)                                           # not registered any more
+
+
+def test_hip_graph_capture_and_replay():
+    """The batched device form can be captured into a HIP graph (after a warm-up call sized the scratch) and the
+    graph replayed on new data: the fused kernel switches to its replay-safe hand-off mode when it sees a capture."""
+    w, h, n = 1920, 1080, 6
+    c = mi_lumaeq.Context(0)
+    try:
+        d_in = synth.nv12_batch_torch(w, h, n, "D2", "cuda:0", seed=11)
+        d_out = torch.zeros_like(d_in)
+        c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 1)            # warm-up: allocations happen here, not in the capture
+        c.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 1, 2.0, 8, 8)
+        c.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 1, stream=torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):
+            d_in.copy_(synth.nv12_batch_torch(w, h, n, synth.DISTS[rep], "cuda:0", seed=100 + rep))
+            d_out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            src, out = d_in.cpu().numpy(), d_out.cpu().numpy()
+            for k in range(n):
+                assert np.array_equal(out[k], oracle.nv12_frame(src[k], w, h, uv_mode=1, op=0)), (rep, k)
+        # eager calls on the same context keep working after replays
+        c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
+        c.synchronize()
+        assert np.array_equal(d_out[0].cpu().numpy(), oracle.nv12_frame(d_in[0].cpu().numpy(), w, h, uv_mode=0, op=0))
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            c.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 0, 2.0, 8, 8, stream=torch.cuda.current_stream().cuda_stream)
+        g2.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out[1].cpu().numpy(), oracle.nv12_frame(d_in[1].cpu().numpy(), w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
+    finally:
+        c.close()
