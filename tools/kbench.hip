@@ -175,6 +175,31 @@ __global__ __launch_bounds__(256) void copy_kernel(const u32x4* __restrict__ src
     for (; i < v1; i += 256) dp[i] = sp[i];
 }
 
+// copy Y + fill UV with the same grid: the HBM-traffic mix of the whole NV12 equalize path at minimum traffic
+// (read W*H, write 1.5*W*H) -- the ceiling the fused kernel is compared with
+__global__ __launch_bounds__(256) void copy_y_fill_uv_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long nvec_y, long long nvec_uv, long long frame_vec_stride)
+{
+    const u32x4* sp = src + (long long)blockIdx.y * frame_vec_stride;
+    u32x4* dp = dst + (long long)blockIdx.y * frame_vec_stride;
+    const long long v0 = nvec_y * blockIdx.x / gridDim.x, v1 = nvec_y * (blockIdx.x + 1) / gridDim.x;
+    long long i = v0 + threadIdx.x;
+    for (; i + 3 * 256 < v1; i += 4 * 256) {
+        const u32x4 a = sp[i], b = sp[i + 256], c = sp[i + 512], d = sp[i + 768];
+        dp[i] = a; dp[i + 256] = b; dp[i + 512] = c; dp[i + 768] = d;
+    }
+    for (; i < v1; i += 256) dp[i] = sp[i];
+    const long long u0 = nvec_uv * blockIdx.x / gridDim.x, u1 = nvec_uv * (blockIdx.x + 1) / gridDim.x;
+    const u32x4 g = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    for (long long k = u0 + threadIdx.x; k < u1; k += 256) dp[nvec_y + k] = g;
+}
+__global__ __launch_bounds__(256) void fill_kernel(u32x4* __restrict__ dst, long long nvec, long long frame_vec_stride)
+{
+    u32x4* dp = dst + (long long)blockIdx.y * frame_vec_stride;
+    const long long v0 = nvec * blockIdx.x / gridDim.x, v1 = nvec * (blockIdx.x + 1) / gridDim.x;
+    const u32x4 g = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    for (long long i = v0 + threadIdx.x; i < v1; i += 256) dp[i] = g;
+}
+
 // ---------------------------------------------------------------- harness
 struct Variant { std::string name; double alg_bytes; std::function<void(hipStream_t)> run; std::vector<float> us; };
 
@@ -238,6 +263,8 @@ int main(int argc, char** argv)
     }
     { const int b = B(2048);
       vs.push_back({"copy Y", 2 * yb, [=](hipStream_t s) { hipLaunchKernelGGL(copy_kernel, dim3(b, nf), dim3(256), 0, s, vin, vout, nvec, fvs); }, {}});
+      vs.push_back({"copy Y + fill UV (min-traffic mix)", 2.5 * yb, [=](hipStream_t s) { hipLaunchKernelGGL(copy_y_fill_uv_kernel, dim3(b, nf), dim3(256), 0, s, vin, vout, nvec, nvec / 2, fvs); }, {}});
+      vs.push_back({"fill whole frame (write only)", 1.5 * yb, [=](hipStream_t s) { hipLaunchKernelGGL(fill_kernel, dim3(b, nf), dim3(256), 0, s, vout, fvs, fvs); }, {}});
       vs.push_back({"apply lut8 (256B LDS)", 2 * yb, [=](hipStream_t s) { hipLaunchKernelGGL((apply_var_kernel<0, false, false>), dim3(b, nf), dim3(256), 0, s, vin, vout, nvec, fvs, d_luts); }, {}});
       vs.push_back({"apply lut32x32 (shipped)", 2 * yb, [=](hipStream_t s) { hipLaunchKernelGGL((apply_var_kernel<1, false, false>), dim3(b, nf), dim3(256), 0, s, vin, vout, nvec, fvs, d_luts); }, {}});
       vs.push_back({"apply bpermute", 2 * yb, [=](hipStream_t s) { hipLaunchKernelGGL((apply_var_kernel<2, false, false>), dim3(b, nf), dim3(256), 0, s, vin, vout, nvec, fvs, d_luts); }, {}});
