@@ -326,7 +326,6 @@ __global__ __launch_bounds__(kThreads) void lut_apply_kernel(PlaneBatch p, const
 constexpr int kVPT = 20;                            // default: 16-byte vectors a thread keeps in registers (80 KiB slices)
 constexpr int kLutPubWords = 128;                   // per frame: 64 LUT dwords + checksum, padded to 512 B
 constexpr int kFlagStride = 32;                     // one 128-B line per frame flag / counter
-constexpr unsigned long long kSpinTimeoutTicks = 200000000ull;   // 2 s of the 100 MHz s_memrealtime clock
 
 struct FusedJob {
     const uint8_t* src; uint8_t* dst;               // Y plane of frame 0 (16-B aligned)
@@ -336,6 +335,8 @@ struct FusedJob {
     int n_frames;
     int T, U;                                       // Y tickets / UV tickets per frame
     int acquire;                                    // 1: consumers issue an agent acquire before reading the LUT
+    int fault_inject;                               // test hook: the last arriver of frame 0 never publishes its LUT
+    unsigned long long timeout_ticks;               // bound of every wait, in 100 MHz ticks
     UVJob uv;
     // Hand-off block.  Zeroed once when allocated; every launch leaves it clean again: the ticket counter only
     // grows (work_base = its value at launch), the last arriver of a frame drains ghist (exchange) and resets cnt,
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
         }
         __syncthreads();
         uint8_t my_lut;
+        if (sh.last && j.fault_inject && f == 0) break;              // test hook: simulate a lost producer (others must time out)
         if (sh.last) {
             // ---- 3. last arriver: collect, verify, compute and publish the LUT
             uint32_t h = 0;
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
                 const uint32_t ws = wave_sum(h);
                 __syncthreads();
                 if ((t & 63) == 0) sh.red[t >> 6] = ws;
-                if (t == 0) sh.timeout = (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks);   // one decision for the block
+                if (t == 0) sh.timeout = (__builtin_amdgcn_s_memrealtime() - t_start > j.timeout_ticks);   // one decision for the block
                 __syncthreads();
                 if (sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3] == (uint32_t)j.total) break;
                 if (sh.timeout) {
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
                 const uint32_t* flag = j.ready + (size_t)f * kFlagStride;
                 while (ld_agent(flag) != j.epoch) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks || ld_agent(j.status) != 0u) { sh.ok = 0; st_agent(j.status, 1u); break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t_start > j.timeout_ticks || ld_agent(j.status) != 0u) { sh.ok = 0; st_agent(j.status, 1u); break; }
                 }
                 if (j.acquire) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
                     const uint32_t w = ld_agent(pub + t);
                     const uint32_t want = ld_agent(pub + 64);
                     if (wave_sum(w) + 0x5EED0001u + j.epoch == want) { sh.lut_words[t] = w; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) { if (t == 0) { sh.ok = 0; st_agent(j.status, 2u); } break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t_start > j.timeout_ticks) { if (t == 0) { sh.ok = 0; st_agent(j.status, 2u); } break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
             }

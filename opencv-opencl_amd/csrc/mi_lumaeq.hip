@@ -75,6 +75,8 @@ struct mi_ctx {
     int fused_wgs_per_cu = 4;                                    // MI_LUMAEQ_FUSED_WGS_PER_CU
     int fused_vpt = kVPT;                                        // MI_LUMAEQ_FUSED_VPT (8, 16, 20, 24)
     int fused_acquire = 1;                                       // MI_LUMAEQ_FUSED_ACQUIRE
+    int fused_fault_inject = 0;                                  // test hook (option "fused_fault_inject")
+    int fused_timeout_ms = 2000;                                 // option "fused_timeout_ms"
     int clahe_float_tables = 1;                                  // option "clahe_float_tables": f32 pair tables in LDS (tiles_x <= 14)
     uint8_t*  d_stage_in = nullptr;  size_t stage_in_bytes = 0;  // device frame for the host-pointer forms
     uint8_t*  d_stage_out = nullptr; size_t stage_out_bytes = 0;
@@ -275,6 +277,8 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     const long long slice = (long long)kThreads * c->fused_vpt;
     j.T = (int)((j.nvec + slice - 1) / slice);
     j.acquire = c->fused_acquire;
+    j.fault_inject = c->fused_fault_inject;
+    j.timeout_ticks = (unsigned long long)std::max(1, c->fused_timeout_ms) * 100000ull;
     j.U = 0;
     // UV as stand-alone 64 KiB tickets behind each frame's Y tickets: pure streaming work that fills the gaps while
     // other workgroups sit in their hand-off (measured 5 % faster than giving every Y ticket a share of the UV plane)
@@ -629,6 +633,8 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }
     if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
     if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
+    if (!strcmp(name, "fused_fault_inject")) { c->fused_fault_inject = value != 0; return MI_OK; }
+    if (!strcmp(name, "fused_timeout_ms")) { c->fused_timeout_ms = std::max(1, value); return MI_OK; }
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
     return fail(c, MI_ERR_BAD_ARG, "unknown option");
 }

@@ -359,8 +359,9 @@ inline void claheNV12(const unsigned char* in, unsigned char* out, int width, in
 
 // ---- real OpenCV front end (only when the including program already uses OpenCV) ----
 #if defined(MI_CV_WITH_OPENCV) && defined(__has_include)
-#if __has_include(<opencv2/core.hpp>)
+#if __has_include(<opencv2/core.hpp>) && __has_include(<opencv2/imgproc.hpp>)
 #include <opencv2/core.hpp>
+#include <opencv2/imgproc.hpp>      // cv::CLAHE
 namespace mi_cv {
 inline void throw_cv(mi_ctx* c, mi_status st, const char* what)
 {

@@ -501,3 +501,39 @@ def test_hip_graph_capture_and_replay():
         assert np.array_equal(d_out[1].cpu().numpy(), oracle.nv12_frame(d_in[1].cpu().numpy(), w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
     finally:
         c.close()
+
+
+def test_fused_bounded_wait_failure_is_reported_and_recoverable():
+    """Failure path of the fused kernel: with a producer knocked out (test hook) the consumers' bounded waits expire,
+    the grid drains, mi_ctx_synchronize reports MI_ERR_HIP, and the next call on the same context works again."""
+    import time
+    w, h, n = 1920, 1080, 3
+    frames = np.stack([synth.nv12_frame(w, h, "D2", 700 + k) for k in range(n)])
+    d_in = dev(frames)
+    d_out = torch.zeros_like(d_in)
+    c = mi_lumaeq.Context(0)
+    try:
+        c.set_option("fused_timeout_ms", 50)
+        c.set_option("fused_fault_inject", 1)
+        t0 = time.perf_counter()
+        c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
+        with pytest.raises(mi_lumaeq.MiError) as e:
+            c.synchronize()
+        assert e.value.status == 3 and "wait expired" in str(e.value)
+        assert time.perf_counter() - t0 < 5.0                      # bounded: the grid drained
+        c.set_option("fused_fault_inject", 0)
+        c.set_option("fused_timeout_ms", 2000)
+        c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)    # hand-off block is re-zeroed, context recovers
+        c.synchronize()
+        out = d_out.cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=0, op=0))
+        y = frames[0][: w * h].reshape(h, w)
+        c.set_option("fused_fault_inject", 1)
+        c.set_option("fused_timeout_ms", 50)
+        with pytest.raises(mi_lumaeq.MiError):                     # host form reports it too
+            c.equalize_hist(y)
+        c.set_option("fused_fault_inject", 0)
+        assert np.array_equal(c.equalize_hist(y), oracle.equalize_hist(y))
+    finally:
+        c.close()
