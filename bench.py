@@ -342,6 +342,20 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     res["bgr_yuv_equalize_bgr_frames_per_s"] = round(Bc / (ms * 1e-3), 1)
     ms = timeit(lambda: ctx.cvt_color_batch_dev(bgr, bgr_out, w, h, Bc, mi_lumaeq.COLOR_BGR2YUV, stream=stream), 10)
     res["cvtcolor_bgr2yuv_GBs"] = round(2 * 3 * w * h * Bc / (ms * 1e-3) / 1e9, 1)
+    del bgr, bgr_out
+    # equalizeHist on a strided ROI (generic path: row by row, unaligned starts) and 16-bit CLAHE
+    Br = 16
+    pitch = w + 64
+    big = torch.randint(0, 256, (Br, h + 8, pitch), dtype=torch.uint8, device="cuda")
+    big_out = torch.zeros_like(big)
+    off = 3 * pitch + 21                                           # ROI origin (row 3, column 21): unaligned
+    ms = timeit(lambda: ctx.equalize_hist_batch_dev(big.data_ptr() + off, big_out.data_ptr() + off, w, h, Br, src_step=pitch,
+                                                    src_frame=(h + 8) * pitch, dst_step=pitch, dst_frame=(h + 8) * pitch, stream=stream), 10)
+    res["strided_roi_equalize_frames_per_s"] = round(Br / (ms * 1e-3), 1)
+    s16 = torch.randint(0, 32768, (4, h, w), dtype=torch.int16, device="cuda")
+    o16 = torch.empty_like(s16)
+    ms = timeit(lambda: ctx.clahe16_batch_dev(s16, o16, w, h, 4, 2.0, 8, 8, stream=stream), 5)
+    res["clahe16_8x8_frames_per_s"] = round(4 / (ms * 1e-3), 1)
     return res
 
 

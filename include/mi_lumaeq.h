@@ -148,6 +148,16 @@ mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* ctx, const void* d_src, size_t sr
                                        double clip_limit, int tiles_x, int tiles_y,
                                        void* d_luts, void* stream);
 
+/* ---- CLAHE on CV_16UC1 (OpenCV surface beyond what the reference uses) ------------------------
+ * cv::createCLAHE(clip, Size(tx,ty))->apply on 16-bit single-channel images: 65 536 bins, ushort LUTs.
+ * Steps / frame strides in BYTES (>= 2*width).  In place allowed. */
+mi_status mi_clahe_u16(mi_ctx* ctx, const uint16_t* src, size_t src_step, uint16_t* dst, size_t dst_step,
+                       int width, int height, double clip_limit, int tiles_x, int tiles_y);
+mi_status mi_clahe_u16_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                 void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                 int width, int height, int n_frames,
+                                 double clip_limit, int tiles_x, int tiles_y, void* stream);
+
 /* ---- optional: pin caller-owned host buffers ----------------------------------------------------------------
  * Video pipelines recycle a small pool of frame buffers (GstBufferPool; the reference maps such buffers at
  * OpenCVequalHist.cpp:115/:158).  Registering a pool's memory once lets the host-pointer forms DMA straight

@@ -862,6 +862,132 @@ __global__ __launch_bounds__(kThreads) void uv_kernel(UVJob uv)
 
 
 // =============================================================================================
+// CLAHE on CV_16UC1 (clahe.cpp CLAHE_CalcLut_Body<ushort,65536,0> / CLAHE_Interpolation_Body<ushort,0>).
+// Not on the reference's path (OpenCV surface beyond it): built for correctness first.  65 536 bins do not fit LDS,
+// so tile histograms live in HBM/L2 (global atomics, with a wave-uniform fast path for flat regions), the clip /
+// redistribute / scan runs one 1024-thread workgroup per tile (64 bins per thread), and the interpolation gathers
+// its four ushort LUT entries from L2.
+// =============================================================================================
+constexpr int kHist16 = 65536;
+
+// grid = (S, tiles, frames); hist[f][tile][65536] must be zero on entry.  steps in BYTES.
+__global__ __launch_bounds__(kThreads) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                              ClaheGeom g, uint32_t* __restrict__ hist)
+{
+    const int t = threadIdx.x;
+    const int S = gridDim.x, s = blockIdx.x, tile = blockIdx.y, f = blockIdx.z;
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    const uint8_t* src = src_base + (long long)f * frame_stride;
+    uint32_t* h = hist + ((size_t)f * gridDim.y + tile) * kHist16;
+    const int r0 = (int)((long long)g.tile_h * s / S), r1 = (int)((long long)g.tile_h * (s + 1) / S);
+    const long long items = (long long)(r1 - r0) * g.tile_w;
+    int row = t / g.tile_w, col = t - row * g.tile_w;
+    const int drow = kThreads / g.tile_w, dcol = kThreads - drow * g.tile_w;
+    for (long long it0 = 0; it0 < items; it0 += kThreads) {
+        const bool active = it0 + t < items;
+        uint32_t v = 0;
+        if (active) {
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            const int x = reflect101(tx * g.tile_w + col, g.width);
+            v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
+        }
+        // flat regions: when the whole wave holds one value, one lane adds the population count
+        const unsigned long long amask = __ballot(active);
+        const uint32_t v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        const bool uniform = amask != 0 && __ballot(active && v == v0) == amask && __ballot(active) == amask;
+        if (uniform && (amask & 1ull)) {                                    // lane 0 active => v0 is an active lane's value
+            if ((t & 63) == 0) __hip_atomic_fetch_add(h + v0, (uint32_t)__popcll(amask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (active) {
+            __hip_atomic_fetch_add(h + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        row += drow; col += dcol;
+        if (col >= g.tile_w) { col -= g.tile_w; ++row; }
+    }
+}
+
+// grid = (tiles, frames), 1024 threads, 64 consecutive bins per thread.
+__global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, ClaheGeom g, float lut_scale16, int clip16,
+                                                         uint16_t* __restrict__ luts)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_total;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const size_t tile_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t* h = hist + tile_id * kHist16 + (size_t)t * 64;
+    uint16_t* lut = luts + tile_id * kHist16 + (size_t)t * 64;
+    auto block_sum_and_prefix = [&](uint32_t v, uint32_t& total) -> uint32_t {   // exclusive prefix of v over the 1024 threads
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        __syncthreads();
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { const uint32_t x = s_w[k]; if (k < w) off += x; tot += x; }
+        total = tot;
+        return off + incl - v;
+    };
+    int batch = 0, residual = 0, rstep = 1;
+    if (clip16 > 0) {
+        uint32_t excess = 0;
+        for (int i = 0; i < 64; ++i) { const int c = (int)h[i]; if (c > clip16) excess += (uint32_t)(c - clip16); }
+        uint32_t clipped;
+        (void)block_sum_and_prefix(excess, clipped);
+        batch = (int)clipped / kHist16;
+        residual = (int)clipped - batch * kHist16;
+        if (residual != 0) { rstep = kHist16 / residual; if (rstep < 1) rstep = 1; }
+    }
+    auto bin_value = [&](int i) -> int {
+        int c = (int)h[i];
+        if (clip16 > 0) {
+            if (c > clip16) c = clip16;
+            c += batch;
+            const int b = t * 64 + i;
+            if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++c;
+        }
+        return c;
+    };
+    uint32_t mine = 0;
+    for (int i = 0; i < 64; ++i) mine += (uint32_t)bin_value(i);
+    uint32_t total;
+    uint32_t run = block_sum_and_prefix(mine, total);
+    (void)total; (void)s_total;
+    for (int i = 0; i < 64; ++i) {
+        run += (uint32_t)bin_value(i);
+        int r = __float2int_rn(__fmul_rn((float)(int)run, lut_scale16));
+        r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
+        lut[i] = (uint16_t)r;
+    }
+}
+
+// grid = (ceil(W/256), H, frames): one pixel per lane, four ushort gathers from the per-tile LUTs (L2).
+__global__ __launch_bounds__(kThreads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
+                                                                 uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
+                                                                 ClaheGeom g, const uint16_t* __restrict__ luts)
+{
+    const int f = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * kThreads + threadIdx.x;
+    if (x >= g.width) return;
+    const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
+    const float txf = __fsub_rn(__fmul_rn((float)x, g.inv_tw), 0.5f);
+    int tx1 = floor_f32_to_int(txf);
+    const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
+    int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
+    const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+    int ty1 = floor_f32_to_int(tyf);
+    const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
+    int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
+    const uint32_t v = *reinterpret_cast<const uint16_t*>(src_base + (long long)f * src_frame + (long long)y * src_step + 2 * (long long)x);
+    const float a = (float)lf[((size_t)ty1 * g.tiles_x + tx1) * kHist16 + v], b = (float)lf[((size_t)ty1 * g.tiles_x + tx2) * kHist16 + v];
+    const float c = (float)lf[((size_t)ty2 * g.tiles_x + tx1) * kHist16 + v], d = (float)lf[((size_t)ty2 * g.tiles_x + tx2) * kHist16 + v];
+    const float top = __fmul_rn(__fadd_rn(__fmul_rn(a, xa1), __fmul_rn(b, xa)), ya1);
+    const float bot = __fmul_rn(__fadd_rn(__fmul_rn(c, xa1), __fmul_rn(d, xa)), ya);
+    int r = __float2int_rn(__fadd_rn(top, bot));
+    r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
+    *reinterpret_cast<uint16_t*>(dst_base + (long long)f * dst_frame + (long long)y * dst_step + 2 * (long long)x) = (uint16_t)r;
+}
+
+// =============================================================================================
 // Colour-domain neighbours of the path: cv::cvtColor(COLOR_BGR2YUV / COLOR_YUV2BGR) on CV_8UC3
 // and the split / merge around the luma op (singlecolor.cpp:39-66, clahe1frame.cpp:83-102).
 // OpenCV 4.4 color_yuv.simd.hpp, 8-bit fixed point (yuv_shift = 14), restated in oracle/color_oracle.c:

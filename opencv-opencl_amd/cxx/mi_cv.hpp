@@ -236,13 +236,17 @@ public:
     CLAHE_Impl(double clip, int tx, int ty) : clip_(clip), tx_(tx), ty_(ty) {}
     void apply(const Mat& src, Mat& dst) override
     {
-        MI_CV_ASSERT(src.type() == CV_8UC1);      // clahe.cpp also accepts CV_16UC1; not on the reference's path
+        MI_CV_ASSERT(src.type() == CV_8UC1 || src.type() == CV_16UC1);     // clahe.cpp: CV_Assert(8UC1 || 16UC1)
         if (src.empty()) return;
         MI_CV_ASSERT(tx_ >= 1 && ty_ >= 1);
         const Mat s = src;
-        dst.create(s.rows, s.cols, CV_8UC1);
+        dst.create(s.rows, s.cols, s.type());
         mi_ctx* c = thread_ctx();
-        check(c, mi_clahe_u8(c, s.data, s.step, dst.data, dst.step, s.cols, s.rows, clip_, tx_, ty_), "mi_clahe_u8");
+        if (s.type() == CV_8UC1)
+            check(c, mi_clahe_u8(c, s.data, s.step, dst.data, dst.step, s.cols, s.rows, clip_, tx_, ty_), "mi_clahe_u8");
+        else                                                          // 65 536-bin path
+            check(c, mi_clahe_u16(c, reinterpret_cast<const uint16_t*>(s.data), s.step, reinterpret_cast<uint16_t*>(dst.data), dst.step,
+                                  s.cols, s.rows, clip_, tx_, ty_), "mi_clahe_u16");
     }
     void setClipLimit(double v) override { clip_ = v; }
     double getClipLimit() const override { return clip_; }

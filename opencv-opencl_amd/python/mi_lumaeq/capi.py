@@ -28,7 +28,7 @@ DECLARED_SYMBOLS = [
     "mi_clahe_tile_luts_batch_dev",
     "mi_ctx_set_profiling", "mi_ctx_profile_read", "mi_kernel_name",
     "mi_ctx_synchronize", "mi_ctx_set_option",
-    "mi_host_register", "mi_host_unregister",
+    "mi_host_register", "mi_host_unregister", "mi_clahe_u16", "mi_clahe_u16_batch_dev",
     "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
 ]
 
@@ -96,6 +96,8 @@ def lib() -> C.CDLL:
     L.mi_cvt_color_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, vp]
     L.mi_bgr_luma_op_u8c3.argtypes = [vp, vp, sz, vp, sz, i, i, i, d, i, i]
     L.mi_bgr_luma_op_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, d, i, i, vp]
+    L.mi_clahe_u16.argtypes = [vp, vp, sz, vp, sz, i, i, d, i, i]
+    L.mi_clahe_u16_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, d, i, i, vp]
     L.mi_host_register.argtypes = [vp, sz]
     L.mi_host_unregister.argtypes = [vp]
     L.mi_ctx_synchronize.argtypes = [vp, vp]
@@ -284,6 +286,24 @@ class Context:
         self._chk(lib().mi_clahe_tile_luts_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
                                                      float(clip_limit), tiles_x, tiles_y, _dptr(d_luts), stream),
                   "mi_clahe_tile_luts_batch_dev")
+
+    # ---- 16-bit CLAHE (N4) ----
+    def clahe16(self, src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_y: int = 8) -> np.ndarray:
+        if not isinstance(src, np.ndarray) or src.dtype != np.uint16 or src.ndim != 2:
+            raise MiError(2, "clahe16", "expected a 2-D uint16 ndarray (CV_16UC1)")
+        if src.size and src.strides[1] != 2:
+            raise MiError(1, "clahe16", "pixel stride must be 2")
+        dst = np.empty(src.shape, np.uint16)
+        h, w = src.shape
+        sstep = int(src.strides[0]) if h > 1 else max(int(src.strides[0]), w * 2)
+        self._chk(lib().mi_clahe_u16(self._h, src.ctypes.data, sstep, dst.ctypes.data, w * 2, w, h, float(clip_limit),
+                                     int(tiles_x), int(tiles_y)), "mi_clahe_u16")
+        return dst
+
+    def clahe16_batch_dev(self, src, dst, width, height, n_frames, clip_limit, tiles_x, tiles_y, stream=0):
+        self._chk(lib().mi_clahe_u16_batch_dev(self._h, _dptr(src), width * 2, width * 2 * height, _dptr(dst), width * 2,
+                                               width * 2 * height, width, height, n_frames, float(clip_limit), tiles_x, tiles_y, stream),
+                  "mi_clahe_u16_batch_dev")
 
     # ---- colour-domain neighbours (N3) ----
     @staticmethod

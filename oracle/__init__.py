@@ -57,6 +57,9 @@ def lib() -> ctypes.CDLL:
         L.orc_bgr2yuv_u8.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
         L.orc_yuv2bgr_u8.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
         L.orc_bgr_luma_op.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        L.orc_clahe_u16.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        L.orc_clahe_u16.restype = ctypes.c_int
         for f in (L.orc_bgr2yuv_u8, L.orc_yuv2bgr_u8, L.orc_bgr_luma_op):
             f.restype = ctypes.c_int
         for f in (L.orc_hist_u8, L.orc_equalize_lut, L.orc_lut_apply_u8, L.orc_equalize_hist_u8,
@@ -158,6 +161,22 @@ def nv12_frame(frame: np.ndarray, width: int, height: int, uv_mode: int = 0, op:
     _check(lib().orc_nv12_frame(_ptr(frame), _ptr(out), width, height, uv_mode, op,
                                 float(clip_limit), tiles_x, tiles_y), "nv12_frame")
     return out
+
+
+def clahe16(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_y: int = 8) -> np.ndarray:
+    """cv::createCLAHE(...)->apply on CV_16UC1 (SURVEY 8f N4)."""
+    src = np.asarray(src)
+    if src.dtype != np.uint16 or src.ndim != 2:
+        raise TypeError("oracle: expected a 2-D uint16 array (CV_16UC1)")
+    if src.size and src.strides[1] != 2:
+        raise ValueError("oracle: pixel stride must be 2")
+    dst = np.empty(src.shape, np.uint16)
+    if src.size == 0:
+        return dst
+    sstep = int(src.strides[0]) if src.shape[0] > 1 else max(int(src.strides[0]), src.shape[1] * 2)
+    _check(lib().orc_clahe_u16(src.ctypes.data, sstep, dst.ctypes.data, dst.shape[1] * 2, src.shape[1], src.shape[0],
+                               float(clip_limit), tiles_x, tiles_y), "clahe16")
+    return dst
 
 
 def _as3(a: np.ndarray) -> np.ndarray:

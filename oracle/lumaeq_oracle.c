@@ -330,6 +330,93 @@ int orc_clahe_u8(const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_s
 }
 
 /* ------------------------------------------------------------------------------------------
+ * CLAHE on CV_16UC1 (clahe.cpp CLAHE_CalcLut_Body<ushort,65536,0>,
+ * CLAHE_Interpolation_Body<ushort,0>): the same algorithm with histSize = 65536, lutScale =
+ * 65535.f/area, clip = max((int)(clipLimit*area/65536), 1), ushort LUTs, saturate_cast<ushort>.
+ * Steps in BYTES.  Not used by the reference (OpenCV surface beyond it).
+ * ---------------------------------------------------------------------------------------- */
+static inline uint16_t orc_sat_u16(int v) { return (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v)); }
+
+int orc_clahe_u16(const uint16_t* src, size_t src_step, uint16_t* dst, size_t dst_step,
+                  int width, int height, double clip_limit, int tiles_x, int tiles_y)
+{
+    enum { HS = 65536 };
+    if (width < 0 || height < 0 || tiles_x <= 0 || tiles_y <= 0) return ORC_BAD_ARG;
+    if (width == 0 || height == 0) return ORC_OK;
+    if (!src || !dst || src_step < (size_t)width * 2 || dst_step < (size_t)width * 2) return ORC_BAD_ARG;
+    int ext_w = width, ext_h = height;
+    if (width % tiles_x != 0 || height % tiles_y != 0) {
+        ext_w = width + (tiles_x - width % tiles_x);
+        ext_h = height + (tiles_y - height % tiles_y);
+    }
+    const int tile_w = ext_w / tiles_x, tile_h = ext_h / tiles_y;
+    const int area = tile_w * tile_h;
+    const float lut_scale = (float)(HS - 1) / (float)area;
+    int clip = 0;
+    if (clip_limit > 0.0) { clip = (int)(clip_limit * area / HS); if (clip < 1) clip = 1; }
+    const int ntiles = tiles_x * tiles_y;
+    uint16_t* luts = (uint16_t*)malloc((size_t)ntiles * HS * sizeof(uint16_t));
+    if (!luts) return ORC_OOM;
+    int oom = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int k = 0; k < ntiles; ++k) {
+        int* h = (int*)calloc(HS, sizeof(int));
+        if (!h) { oom = 1; continue; }
+        const int ty = k / tiles_x, tx = k % tiles_x;
+        for (int yy = 0; yy < tile_h; ++yy) {
+            const int y = orc_reflect101(ty * tile_h + yy, height);
+            const uint16_t* row = (const uint16_t*)((const uint8_t*)src + (size_t)y * src_step);
+            for (int xx = 0; xx < tile_w; ++xx) h[row[orc_reflect101(tx * tile_w + xx, width)]]++;
+        }
+        if (clip > 0) {
+            int clipped = 0;
+            for (int i = 0; i < HS; ++i) if (h[i] > clip) { clipped += h[i] - clip; h[i] = clip; }
+            int batch = clipped / HS, residual = clipped - batch * HS;
+            for (int i = 0; i < HS; ++i) h[i] += batch;
+            if (residual != 0) {
+                int rstep = HS / residual; if (rstep < 1) rstep = 1;
+                for (int i = 0; i < HS && residual > 0; i += rstep, residual--) h[i]++;
+            }
+        }
+        int sum = 0;
+        uint16_t* lut = luts + (size_t)k * HS;
+        for (int i = 0; i < HS; ++i) { sum += h[i]; lut[i] = orc_sat_u16(orc_round((float)sum * lut_scale)); }
+        free(h);
+    }
+    if (oom) { free(luts); return ORC_OOM; }
+    const float inv_tw = 1.0f / (float)tile_w, inv_th = 1.0f / (float)tile_h;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int y = 0; y < height; ++y) {
+        const uint16_t* s = (const uint16_t*)((const uint8_t*)src + (size_t)y * src_step);
+        uint16_t* d = (uint16_t*)((uint8_t*)dst + (size_t)y * dst_step);
+        float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = orc_floor(tyf), ty2 = ty1 + 1;
+        float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > tiles_y - 1) ty2 = tiles_y - 1;
+        const uint16_t* p1 = luts + (size_t)ty1 * tiles_x * HS;
+        const uint16_t* p2 = luts + (size_t)ty2 * tiles_x * HS;
+        for (int x = 0; x < width; ++x) {
+            float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = orc_floor(txf), tx2 = tx1 + 1;
+            float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > tiles_x - 1) tx2 = tiles_x - 1;
+            const int v = s[x];
+            float res = ((float)p1[(size_t)tx1 * HS + v] * xa1 + (float)p1[(size_t)tx2 * HS + v] * xa) * ya1 +
+                        ((float)p2[(size_t)tx1 * HS + v] * xa1 + (float)p2[(size_t)tx2 * HS + v] * xa) * ya;
+            d[x] = orc_sat_u16(orc_round(res));
+        }
+    }
+    free(luts);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
  * A7: whole NV12 frame = op on Y + UV fill(128) (OpenCVequalHist.cpp:160-162,
  * clahevideo.cpp:200-201) or UV passthrough (ColoropenCVCwqualHist.cpp:165, improvement.cpp:163,
  * nextimprovement.cpp:160).  Tightly packed: Y = W*H bytes, UV = W*H/2 bytes (integer division

@@ -60,29 +60,35 @@ def _reflect101_index(n_ext: int, n: int) -> np.ndarray:
 
 
 def np_clahe(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_y: int = 8) -> np.ndarray:
+    """8-bit (histSize 256) or 16-bit (histSize 65536) CLAHE."""
     src = np.asarray(src)
-    assert src.dtype == np.uint8 and src.ndim == 2
+    assert src.dtype in (np.uint8, np.uint16) and src.ndim == 2
+    HS = 256 if src.dtype == np.uint8 else 65536
     H, W = src.shape
     if src.size == 0:
         return src.copy()
     g = np_clahe_geometry(W, H, clip_limit, tiles_x, tiles_y)
+    if HS != 256:
+        area = g["tile_w"] * g["tile_h"]
+        g["clip"] = max(int(float(clip_limit) * area / HS), 1) if clip_limit > 0.0 else 0
+        g["lut_scale"] = F(HS - 1) / F(area)
     ext = src[_reflect101_index(g["ext_h"], H)][:, _reflect101_index(g["ext_w"], W)]
     tw, th, clip = g["tile_w"], g["tile_h"], g["clip"]
-    luts = np.zeros((tiles_y, tiles_x, 256), np.uint8)
+    luts = np.zeros((tiles_y, tiles_x, HS), src.dtype)
     for ty in range(tiles_y):
         for tx in range(tiles_x):
             tile = ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
-            h = np.bincount(tile.reshape(-1), minlength=256).astype(np.int64)
+            h = np.bincount(tile.reshape(-1), minlength=HS).astype(np.int64)
             if clip > 0:
                 clipped = int(np.maximum(h - clip, 0).sum())
                 h = np.minimum(h, clip)
-                batch, resid = divmod(clipped, 256)
+                batch, resid = divmod(clipped, HS)
                 h = h + batch
                 if resid:
-                    step = max(256 // resid, 1)
-                    bins = np.arange(0, 256, step)[:resid]
+                    step = max(HS // resid, 1)
+                    bins = np.arange(0, HS, step)[:resid]
                     h[bins] += 1
-            luts[ty, tx] = np.clip(np.rint(np.cumsum(h).astype(F) * g["lut_scale"]), 0, 255).astype(np.uint8)
+            luts[ty, tx] = np.clip(np.rint(np.cumsum(h).astype(F) * g["lut_scale"]), 0, HS - 1).astype(src.dtype)
 
     def axis_tables(n, tile, ntiles):
         inv = F(1.0) / F(tile)
@@ -103,4 +109,4 @@ def np_clahe(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_
     bot = (C * xa1[None, :] + D * xa[None, :]) * ya[:, None]
     res = top + bot
     assert res.dtype == np.float32
-    return np.clip(np.rint(res), 0, 255).astype(np.uint8)
+    return np.clip(np.rint(res), 0, HS - 1).astype(src.dtype)

@@ -16,6 +16,7 @@ int orc_clahe_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int, double, int
 int orc_nv12_frame(const uint8_t*, uint8_t*, int, int, int, int, double, int, int);
 int orc_bgr_luma_op(const uint8_t*, uint8_t*, int, int, int, double, int, int);
 int orc_bgr2yuv_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int);
+int orc_clahe_u16(const uint16_t*, size_t, uint16_t*, size_t, int, int, double, int, int);
 }
 
 static int failures = 0;
@@ -139,6 +140,19 @@ int main()
         bool threw = false;
         try { Mat g(4, 4, CV_8UC1), o; cvtColor(g, o, COLOR_BGR2YUV); } catch (const std::exception&) { threw = true; }
         EXPECT(threw);
+    }
+    // --- 16-bit CLAHE through the same cv::CLAHE-shaped object
+    {
+        const int CW = 203, CH = 97;
+        std::vector<uint16_t> src16((size_t)CW * CH), ref16((size_t)CW * CH);
+        uint64_t s = 99;
+        for (auto& v : src16) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (uint16_t)(2000 + (s >> 40) % 3000); }
+        Mat m16(CH, CW, CV_16UC1, src16.data());
+        Mat out16;
+        Ptr<CLAHE> c16 = createCLAHE(2.0, Size(8, 8));
+        c16->apply(m16, out16);
+        orc_clahe_u16(src16.data(), (size_t)CW * 2, ref16.data(), (size_t)CW * 2, CW, CH, 2.0, 8, 8);
+        EXPECT(out16.type() == CV_16UC1 && memcmp(out16.data, ref16.data(), ref16.size() * 2) == 0);
     }
     // --- worker pool: 3 workers, 24 frames, in-order delivery, both UV modes (A7, A8)
     for (int uv = 0; uv < 2; ++uv) {

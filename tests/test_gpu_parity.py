@@ -537,3 +537,40 @@ def test_fused_bounded_wait_failure_is_reported_and_recoverable():
         assert np.array_equal(c.equalize_hist(y), oracle.equalize_hist(y))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (15, 16), (47, 63), (270, 480), (1079, 1919)], ids=str)
+@pytest.mark.parametrize("cfg", [(2.0, 8, 8), (3.0, 4, 4), (0.0, 3, 5), (40.0, 1, 1)], ids=str)
+def test_clahe16(ctx, shape, cfg):
+    """CLAHE on CV_16UC1 (65 536 bins) vs the oracle, incl. flat and narrow-range images and strides."""
+    h, w = shape
+    clip, tx, ty = cfg
+    rng = np.random.default_rng(h * 7 + w)
+    for kind in range(4):
+        if kind == 0:
+            s = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+        elif kind == 1:
+            s = rng.integers(1000, 1400, (h, w), dtype=np.uint16)
+        elif kind == 2:
+            s = np.full((h, w), 40000, np.uint16)
+        else:
+            big = rng.integers(0, 4096, (h + 2, w + 5), dtype=np.uint16)
+            s = big[1:h + 1, 3:w + 3]                              # strided view
+        assert np.array_equal(ctx.clahe16(s, clip, tx, ty), oracle.clahe16(s, clip, tx, ty)), kind
+
+
+def test_clahe16_batch_and_errors(ctx):
+    w, h, n = 320, 180, 3
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 65536, (n, h, w), dtype=np.uint16)
+    d_in = torch.from_numpy(frames.view(np.int16)).to("cuda:0")
+    d_out = torch.empty_like(d_in)
+    ctx.clahe16_batch_dev(d_in, d_out, w, h, n, 2.0, 8, 8)
+    ctx.synchronize()
+    out = d_out.cpu().numpy().view(np.uint16)
+    for k in range(n):
+        assert np.array_equal(out[k], oracle.clahe16(frames[k], 2.0, 8, 8)), k
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.clahe16(frames[0].astype(np.uint8))
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.clahe16(frames[0], 2.0, 0, 8)

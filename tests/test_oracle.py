@@ -175,3 +175,20 @@ def test_color_conversion_kats():
     yuv_img2 = yuv_img.copy()
     yuv_img2[..., 0] = oracle.equalize_hist(np.ascontiguousarray(yuv_img[..., 0]))
     assert np.array_equal(oracle.bgr_luma_op(a, 0), oracle.yuv2bgr(yuv_img2))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (15, 16), (47, 63), (64, 48)], ids=str)
+@pytest.mark.parametrize("cfg", [(2.0, 8, 8), (3.0, 4, 4), (0.0, 3, 5), (40.0, 1, 1)], ids=str)
+def test_c_vs_numpy_clahe16(shape, cfg):
+    """16-bit CLAHE (65 536 bins), the two restatements against each other."""
+    h, w = shape
+    clip, tx, ty = cfg
+    rng = np.random.default_rng(h * 131 + w)
+    for kind in range(3):
+        if kind == 0:
+            s = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+        elif kind == 1:
+            s = rng.integers(1000, 1400, (h, w), dtype=np.uint16)
+        else:
+            s = np.full((h, w), 777, np.uint16)
+        assert np.array_equal(oracle.clahe16(s, clip, tx, ty), oracle.np_clahe(s, clip, tx, ty)), kind
