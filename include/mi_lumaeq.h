@@ -192,8 +192,13 @@ mi_status mi_bgr_luma_op_u8c3_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * The batched equalizeHist forms normally run as ONE fused launch whose workgroups hand data to each
  * other through bounded waits.  mi_ctx_synchronize() waits for `stream` and returns MI_ERR_HIP if such
  * a wait ever expired (the output of that call is then invalid).  The host-pointer forms check this
- * themselves.  Options: "fused" (1/0: single-read fused kernel vs the three-kernel path),
- * "fused_wgs_per_cu" (persistent workgroups per CU, default 4). */
+ * themselves.  A batched call issued inside a stream capture switches the context to a replay-safe mode, so
+ * the captured hipGraph can be replayed (size the scratch with one eager call first: allocations are not
+ * capturable).
+ * Options (mi_ctx_set_option): "fused" (1/0: single-read fused kernel vs the three-kernel path),
+ * "fused_wgs_per_cu" (persistent workgroups per CU, default 4), "fused_vpt" (8/16/20/24 16-byte vectors a
+ * thread keeps in registers, default 20), "fused_acquire" (1/0), "fused_timeout_ms" (bound of every
+ * inter-workgroup wait, default 2000), "fused_fault_inject" (test hook), "clahe_float_tables" (1/0). */
 mi_status mi_ctx_synchronize(mi_ctx* ctx, void* stream);
 mi_status mi_ctx_set_option(mi_ctx* ctx, const char* name, int value);
 
