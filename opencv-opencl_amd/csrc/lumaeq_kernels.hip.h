@@ -863,59 +863,56 @@ __global__ __launch_bounds__(kThreads) void uv_kernel(UVJob uv)
 
 // =============================================================================================
 // CLAHE on CV_16UC1 (clahe.cpp CLAHE_CalcLut_Body<ushort,65536,0> / CLAHE_Interpolation_Body<ushort,0>).
-// Not on the reference's path (OpenCV surface beyond it): built for correctness first.  65 536 bins do not fit LDS,
-// so tile histograms live in HBM/L2 (global atomics, with a wave-uniform fast path for flat regions), the clip /
-// redistribute / scan runs one 1024-thread workgroup per tile (64 bins per thread), and the interpolation gathers
-// its four ushort LUT entries from L2.
+// Not on the reference's path (OpenCV surface beyond it).  65 536 u32 bins do not fit LDS but half of them do, so a
+// tile's histogram is built in two LDS passes by one workgroup; the clip / redistribute / scan walks the bins in
+// coalesced chunks of 1024; the interpolation gathers its four ushort LUT entries from L2.
 // =============================================================================================
 constexpr int kHist16 = 65536;
 
-// grid = (S, tiles, frames); hist[f][tile][65536] must be zero on entry.  steps in BYTES.
-__global__ __launch_bounds__(kThreads) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                              ClaheGeom g, uint32_t* __restrict__ hist)
+// grid = (tiles, frames), 1024 threads, one workgroup per tile.  65 536 u32 counters do not fit LDS, half of them do:
+// two passes over the tile (the second one is served by L2), each histogramming one half of the value range in
+// 128 KiB of LDS and storing it -- no global atomics, no zeroing of the output.  steps in BYTES.
+constexpr int kHalf16 = 32768;
+__global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                          ClaheGeom g, uint32_t* __restrict__ hist)
 {
+    extern __shared__ uint32_t h16[];                            // [32768]
     const int t = threadIdx.x;
-    const int S = gridDim.x, s = blockIdx.x, tile = blockIdx.y, f = blockIdx.z;
+    const int tile = blockIdx.x, f = blockIdx.y;
     const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const uint8_t* src = src_base + (long long)f * frame_stride;
-    uint32_t* h = hist + ((size_t)f * gridDim.y + tile) * kHist16;
-    const int r0 = (int)((long long)g.tile_h * s / S), r1 = (int)((long long)g.tile_h * (s + 1) / S);
-    const long long items = (long long)(r1 - r0) * g.tile_w;
-    int row = t / g.tile_w, col = t - row * g.tile_w;
-    const int drow = kThreads / g.tile_w, dcol = kThreads - drow * g.tile_w;
-    for (long long it0 = 0; it0 < items; it0 += kThreads) {
-        const bool active = it0 + t < items;
-        uint32_t v = 0;
-        if (active) {
-            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+    uint32_t* out = hist + ((size_t)f * gridDim.x + tile) * kHist16;
+    const long long items = (long long)g.tile_h * g.tile_w;
+    const int drow = 1024 / g.tile_w, dcol = 1024 - drow * g.tile_w;
+    for (int half = 0; half < 2; ++half) {
+        for (int i = t; i < kHalf16; i += 1024) h16[i] = 0;
+        __syncthreads();
+        int row = t / g.tile_w, col = t - row * g.tile_w;
+        for (long long it = t; it < items; it += 1024) {
+            const int y = reflect101(ty * g.tile_h + row, g.height);
             const int x = reflect101(tx * g.tile_w + col, g.width);
-            v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
+            const uint32_t v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
+            if ((int)(v >> 15) == half) lds_inc(h16, v & (kHalf16 - 1));
+            row += drow; col += dcol;
+            if (col >= g.tile_w) { col -= g.tile_w; ++row; }
         }
-        // flat regions: when the whole wave holds one value, one lane adds the population count
-        const unsigned long long amask = __ballot(active);
-        const uint32_t v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-        const bool uniform = amask != 0 && __ballot(active && v == v0) == amask && __ballot(active) == amask;
-        if (uniform && (amask & 1ull)) {                                    // lane 0 active => v0 is an active lane's value
-            if ((t & 63) == 0) __hip_atomic_fetch_add(h + v0, (uint32_t)__popcll(amask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (active) {
-            __hip_atomic_fetch_add(h + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        row += drow; col += dcol;
-        if (col >= g.tile_w) { col -= g.tile_w; ++row; }
+        __syncthreads();
+        for (int i = t; i < kHalf16; i += 1024) out[half * kHalf16 + i] = h16[i];
+        __syncthreads();
     }
 }
 
-// grid = (tiles, frames), 1024 threads, 64 consecutive bins per thread.
+// grid = (tiles, frames), 1024 threads.  The 65 536 bins are walked in 64 chunks of 1024 (coalesced): a first sweep
+// sums the clipped excess, a second applies clip + redistribute and scans (block scan per chunk + running offset).
 __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, ClaheGeom g, float lut_scale16, int clip16,
                                                          uint16_t* __restrict__ luts)
 {
     __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_total;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const size_t tile_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t* h = hist + tile_id * kHist16 + (size_t)t * 64;
-    uint16_t* lut = luts + tile_id * kHist16 + (size_t)t * 64;
-    auto block_sum_and_prefix = [&](uint32_t v, uint32_t& total) -> uint32_t {   // exclusive prefix of v over the 1024 threads
+    const uint32_t* h = hist + tile_id * kHist16;
+    uint16_t* lut = luts + tile_id * kHist16;
+    auto block_scan = [&](uint32_t v, uint32_t& total) -> uint32_t {     // inclusive prefix of v over the 1024 threads
         uint32_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
@@ -925,38 +922,33 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
         uint32_t off = 0, tot = 0;
         for (int k = 0; k < 16; ++k) { const uint32_t x = s_w[k]; if (k < w) off += x; tot += x; }
         total = tot;
-        return off + incl - v;
+        return off + incl;
     };
     int batch = 0, residual = 0, rstep = 1;
     if (clip16 > 0) {
         uint32_t excess = 0;
-        for (int i = 0; i < 64; ++i) { const int c = (int)h[i]; if (c > clip16) excess += (uint32_t)(c - clip16); }
+        for (int c = 0; c < 64; ++c) { const int v = (int)h[c * 1024 + t]; if (v > clip16) excess += (uint32_t)(v - clip16); }
         uint32_t clipped;
-        (void)block_sum_and_prefix(excess, clipped);
+        (void)block_scan(excess, clipped);
         batch = (int)clipped / kHist16;
         residual = (int)clipped - batch * kHist16;
         if (residual != 0) { rstep = kHist16 / residual; if (rstep < 1) rstep = 1; }
     }
-    auto bin_value = [&](int i) -> int {
-        int c = (int)h[i];
+    uint32_t running = 0;
+    for (int c = 0; c < 64; ++c) {
+        const int b = c * 1024 + t;
+        int v = (int)h[b];
         if (clip16 > 0) {
-            if (c > clip16) c = clip16;
-            c += batch;
-            const int b = t * 64 + i;
-            if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++c;
+            if (v > clip16) v = clip16;
+            v += batch;
+            if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++v;
         }
-        return c;
-    };
-    uint32_t mine = 0;
-    for (int i = 0; i < 64; ++i) mine += (uint32_t)bin_value(i);
-    uint32_t total;
-    uint32_t run = block_sum_and_prefix(mine, total);
-    (void)total; (void)s_total;
-    for (int i = 0; i < 64; ++i) {
-        run += (uint32_t)bin_value(i);
-        int r = __float2int_rn(__fmul_rn((float)(int)run, lut_scale16));
+        uint32_t total;
+        const uint32_t sum = running + block_scan((uint32_t)v, total);
+        running += total;
+        int r = __float2int_rn(__fmul_rn((float)(int)sum, lut_scale16));
         r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
-        lut[i] = (uint16_t)r;
+        lut[b] = (uint16_t)r;
     }
 }
 

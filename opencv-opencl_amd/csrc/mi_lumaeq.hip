@@ -537,6 +537,8 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
         delete c;
         return MI_ERR_HIP;
     }
+    // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount;
     if (device < kMaxDevices) {
@@ -1112,12 +1114,7 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         const int nf = std::min(chunk, n_frames - f0);
         uint32_t* hist = reinterpret_cast<uint32_t*>(c->d_c16);
         uint16_t* luts = reinterpret_cast<uint16_t*>(c->d_c16 + (size_t)nf * tiles * kHist16 * sizeof(uint32_t));
-        const size_t nwords = (size_t)nf * tiles * kHist16;
-        hipLaunchKernelGGL(zero_words_kernel, dim3(2048), dim3(kThreads), 0, s, hist, nwords);
-        HIPCHK(c, hipGetLastError());
-        const long long want = ((long long)c->cu_count * 8 + (long long)tiles * nf - 1) / ((long long)tiles * nf);
-        const int S = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 4), 64LL}));
-        LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(S, tiles, nf), dim3(kThreads), 0,
+        LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
                src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, g, lut_scale16, clip16, luts);
         LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
