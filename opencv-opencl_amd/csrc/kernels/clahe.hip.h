@@ -1,0 +1,344 @@
+// clahe.hip.h -- K4 tile histograms, K5 clip/redistribute/LUT, K6 bilinear LUT interpolation (8-bit CLAHE)
+// Part of the gfx950 kernel set of libmi_lumaeq (see ../lumaeq_kernels.hip.h for the design notes).
+#pragma once
+#include "common.hip.h"
+#include "equalize.hip.h"
+
+namespace mi {
+// =============================================================================================
+// CLAHE  (oracle: orc_clahe_tile_luts / orc_clahe_interpolate)
+// =============================================================================================
+struct ClaheGeom {
+    int width, height;          // unpadded image
+    int tiles_x, tiles_y;
+    int tile_w, tile_h;         // tile size on the REFLECT_101-extended image
+    int clip;                   // integer clip limit (0 = off)
+    float lut_scale;            // 255.f / (tile_w*tile_h), computed on the host (IEEE division)
+    float inv_tw, inv_th;       // 1.f/tile_w, 1.f/tile_h, computed on the host
+};
+
+// core/src/copy.cpp borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4  per-tile histogram partials.  grid = (S, tiles, n_frames); partial[f][tile][s][256].
+// The padded image is never materialised: rows/columns beyond the frame are read by index
+// reflection.  Work items are (row, 16-byte slot) pairs walked incrementally so short tile rows
+// (480 B at 4K 8x8) still give every lane a vector load.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                            ClaheGeom g, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[256 * kCopies];
+    lds_hist_zero(h);
+    const int t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    const int S = gridDim.x, s = blockIdx.x, tile = blockIdx.y, f = blockIdx.z;
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    const uint8_t* src = src_base + (long long)f * frame_stride;
+    const int r0 = (int)((long long)g.tile_h * s / S), r1 = (int)((long long)g.tile_h * (s + 1) / S);
+    const int x0 = tx * g.tile_w;
+    const int in_w = max(0, min(g.tile_w, g.width - x0));     // columns of this tile that lie inside the frame
+    const int slots = in_w >> 4;                               // full 16-byte slots per row
+    if (slots > 0) {
+        const int rows = r1 - r0;
+        const long long items = (long long)rows * slots;
+        int row = t / slots, slot = t - row * slots;
+        const int drow = kThreads / slots, dslot = kThreads - drow * slots;
+        auto item_ptr = [&]() -> const u32x4_u* {             // address of the current (row, slot), then advance by 256 items
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            const u32x4_u* p = reinterpret_cast<const u32x4_u*>(src + (long long)y * step + x0 + (slot << 4));
+            row += drow; slot += dslot;
+            if (slot >= slots) { slot -= slots; ++row; }
+            return p;
+        };
+        long long it = t;
+        for (; it + 3 * kThreads < items; it += 4 * kThreads) {          // 4 x 16 B in flight per lane
+            const u32x4_u* p0 = item_ptr(); const u32x4_u* p1 = item_ptr(); const u32x4_u* p2 = item_ptr(); const u32x4_u* p3 = item_ptr();
+            const u32x4 a = *p0, b = *p1, c = *p2, d = *p3;
+            hist_add_vec(h, a, copy); hist_add_vec(h, b, copy); hist_add_vec(h, c, copy); hist_add_vec(h, d, copy);
+        }
+        for (; it < items; it += kThreads) hist_add_vec(h, *item_ptr(), copy);
+    }
+    if ((in_w & 15) != 0) {                                     // ragged right edge of the in-frame part: byte loads
+        const int pw = in_w & 15, xs = x0 + (slots << 4);
+        const long long items = (long long)(r1 - r0) * pw;
+        for (long long it = t; it < items; it += kThreads) {
+            const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            lds_inc(h, ((uint32_t)src[(long long)y * step + xs + c] << kCopyShift) + copy);
+        }
+    }
+    if (in_w < g.tile_w) {                                      // reflected columns (right border tiles only)
+        const int pw = g.tile_w - in_w;
+        const long long items = (long long)(r1 - r0) * pw;
+        for (long long it = t; it < items; it += kThreads) {
+            const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            const int x = reflect101(x0 + in_w + c, g.width);
+            lds_inc(h, ((uint32_t)src[(long long)y * step + x] << kCopyShift) + copy);
+        }
+    }
+    __syncthreads();
+    partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = lds_hist_bin(h, t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5  per-tile clip + redistribute + CDF -> uchar LUT.  grid = (tiles, n_frames), 256 threads = bins.
+// clahe.cpp CLAHE_CalcLut_Body: the sequential residual loop
+//     for (i = 0; i < 256 && residual > 0; i += step, --residual) ++h[i];
+// increments bin b iff b % step == 0 and b / step < residual.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void tile_lut_kernel(const uint32_t* __restrict__ partial, int S, ClaheGeom g,
+                                                           uint8_t* __restrict__ luts)
+{
+    __shared__ uint32_t s_wave[4];
+    const int t = threadIdx.x;
+    const size_t tile_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t* pp = partial + tile_id * S * 256 + t;
+    uint32_t c = 0;
+    for (int s = 0; s < S; ++s) c += pp[(size_t)s * 256];
+    int hv = (int)c;
+    if (g.clip > 0) {
+        const uint32_t excess = hv > g.clip ? (uint32_t)(hv - g.clip) : 0u;
+        uint32_t clipped;
+        block_incl_scan(excess, s_wave, &clipped);
+        if (hv > g.clip) hv = g.clip;
+        const int batch = (int)clipped / 256;
+        int residual = (int)clipped - batch * 256;
+        hv += batch;
+        if (residual != 0) {
+            int rstep = 256 / residual; if (rstep < 1) rstep = 1;
+            if (t % rstep == 0 && t / rstep < residual) ++hv;
+        }
+    }
+    const uint32_t sum = block_incl_scan((uint32_t)hv, s_wave, nullptr);
+    int r = __float2int_rn(__fmul_rn((float)(int)sum, g.lut_scale));
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    luts[tile_id * 256 + t] = (uint8_t)r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6  bilinear interpolation of the four neighbouring tile LUTs (clahe.cpp CLAHE_Interpolation_Body).
+// grid = (bands*subs, n_frames, col_segments).  A "band" is the set of rows with the same unclamped
+// ty1 (= band-1), so the two LUT rows a workgroup needs are fixed; it stages, for every
+// horizontal tile pair p (unclamped tx1 = p-1), quad[p][v] = {LUT[ty1][tx1][v], LUT[ty1][tx2][v],
+// LUT[ty2][tx1][v], LUT[ty2][tx2][v]} as one dword in LDS, so a pixel costs ONE ds_read_b32.
+// A lane owns 16 fixed columns (their xa/xa1/pair are lane constants) and walks down the rows.
+// Float ops: nine individually rounded f32 ops per pixel, no FMA (App. A.2 step 5).
+// ---------------------------------------------------------------------------------------------
+constexpr int kInterpPx = 16;           // pixels per lane per row
+constexpr int kMaxPairsLdsF32 = 15;     // float tables: (tiles_x + 1) * 4 KiB of LDS (<= 60 KiB)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxPairsLds = 63;        // (tiles_x + 1) KiB of LDS (<= 64 KiB dynamic); wider grids use the global-LUT kernel
+constexpr int kBandMargin = 4;          // rows; covers the f32 rounding of y*inv_th - 0.5 for any height <= 2^24
+
+__device__ __forceinline__ int floor_f32_to_int(float v) { const int i = (int)v; return i - ((float)i > v); }   // cvFloor
+
+// res = (a*xa1 + b*xa)*ya1 + (c*xa1 + d*xa)*ya, nine individually rounded f32 ops, then round half to even.
+__device__ __forceinline__ float clahe_blend(uint32_t q, float xa, float xa1, float ya, float ya1)
+{
+    const float a = (float)(q & 0xffu), b = (float)((q >> 8) & 0xffu), c = (float)((q >> 16) & 0xffu), d = (float)(q >> 24);
+    const float top = __fmul_rn(__fadd_rn(__fmul_rn(a, xa1), __fmul_rn(b, xa)), ya1);
+    const float bot = __fmul_rn(__fadd_rn(__fmul_rn(c, xa1), __fmul_rn(d, xa)), ya);
+    return rintf(__fadd_rn(top, bot));                               // v_rndne_f32: cvRound
+}
+__device__ __forceinline__ uint32_t clahe_px(uint32_t q, float xa, float xa1, float ya, float ya1)
+{
+    int r = (int)clahe_blend(q, xa, xa1, ya, ya1);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);                             // saturate_cast<uchar>
+    return (uint32_t)r;
+}
+// 16 pixels of one row: one ds_read_b32 per pixel, v_cvt_pk_u8_f32 (saturating, input already integral) packs the bytes
+__device__ __forceinline__ u32x4 clahe_vec16(const uint32_t* quad, u32x4 q, const int* poff, const float* xa, const float* xa1, float ya, float ya1)
+{
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = k * 4 + b;
+            const uint32_t v = (w[k] >> (8 * b)) & 0xffu;
+            acc = __builtin_amdgcn_cvt_pk_u8_f32(clahe_blend(quad[poff[j] + v], xa[j], xa1[j], ya, ya1), b, acc);
+        }
+        ow[k] = acc;
+    }
+    u32x4 o; o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
+    return o;
+}
+
+// Float-table variant of the 16-pixel body: the LDS entry is {a, c, b, d} as f32, so one ds_read_b128 delivers
+// two register pairs that feed v_pk_mul_f32 / v_pk_add_f32 directly (each lane of a packed op is an ordinary
+// individually rounded f32 op): 4 packed ops + 1 add per pixel, no byte->float converts.
+__device__ __forceinline__ u32x4 clahe_vec16_f32(const f32x4* quadf, u32x4 q, const int* poff, const float* xa, const float* xa1, float ya, float ya1)
+{
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    const f32x2 yv = {ya1, ya};
+    uint32_t ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // the four LDS reads of a dword first (16 VGPRs in flight), then four independent blend chains: keeps
+        // the packed ops of different pixels interleaved instead of one LDS round trip + dependent chain per pixel
+        f32x4 e[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) e[b] = quadf[poff[k * 4 + b] + ((w[k] >> (8 * b)) & 0xffu)];
+        f32x2 tb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = k * 4 + b;
+            const f32x2 ac = {e[b].x, e[b].y}, bd = {e[b].z, e[b].w};
+            const f32x2 x1 = {xa1[j], xa1[j]}, x0v = {xa[j], xa[j]};
+            tb[b] = (ac * x1 + bd * x0v) * yv;                   // -ffp-contract=off: pk_mul, pk_mul, pk_add, pk_mul
+        }
+        uint32_t acc = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__fadd_rn(tb[b].x, tb[b].y)), b, acc);
+        ow[k] = acc;
+    }
+    u32x4 o; o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
+    return o;
+}
+
+template <bool FT>
+__global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, ClaheGeom g, const uint8_t* __restrict__ luts,
+                                                               int subs, int groups, UVJob uv)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t quad[];   // [(tiles_x + 1)][256] u32 quads, or f32x4 when FT
+    f32x4* quadf = reinterpret_cast<f32x4*>(quad);
+    const int t = threadIdx.x, f = blockIdx.y;
+    const int band = blockIdx.x / subs, sub = blockIdx.x - band * subs;
+    const int ty1u = band - 1;                                // unclamped ty1 of every row of the band
+    const int ty1 = max(ty1u, 0), ty2 = min(ty1u + 1, g.tiles_y - 1);
+    const uint8_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * 256;
+    const uint8_t* l1 = lf + (size_t)ty1 * g.tiles_x * 256;
+    const uint8_t* l2 = lf + (size_t)ty2 * g.tiles_x * 256;
+    const int npairs = g.tiles_x + 1;
+    for (int i = t; i < npairs * 256; i += kThreads) {
+        const int pr = i >> 8, v = i & 255;
+        const int ta = max(pr - 1, 0), tb = min(pr, g.tiles_x - 1);
+        if (FT) {
+            const f32x4 e = {(float)l1[ta * 256 + v], (float)l2[ta * 256 + v], (float)l1[tb * 256 + v], (float)l2[tb * 256 + v]};   // {a, c, b, d}
+            quadf[i] = e;
+        } else {
+            quad[i] = (uint32_t)l1[ta * 256 + v] | ((uint32_t)l1[tb * 256 + v] << 8) |
+                      ((uint32_t)l2[ta * 256 + v] << 16) | ((uint32_t)l2[tb * 256 + v] << 24);
+        }
+    }
+    __syncthreads();
+
+    // rows of this band: ideal range [(band-0.5)*th, (band+0.5)*th), widened by kBandMargin rows each side and
+    // filtered by the float-computed ty1 so the decision is exactly the reference's.
+    const int y_lo_band = (int)max(0LL, ((long long)(2 * band - 1) * g.tile_h) / 2 - kBandMargin);
+    const int y_hi_band = (int)min((long long)g.height, ((long long)(2 * band + 1) * g.tile_h + 1) / 2 + kBandMargin);
+    const int nrows = max(0, y_hi_band - y_lo_band);
+    const int y_lo = y_lo_band + (int)((long long)nrows * sub / subs);
+    const int y_hi = y_lo_band + (int)((long long)nrows * (sub + 1) / subs);
+
+    const int phases = kThreads / groups;
+    const int grp = t % groups, phase = t / groups;
+    const int x0 = (blockIdx.z * groups + grp) * kInterpPx;
+    if (phase < phases && x0 < g.width) {
+        float xa[kInterpPx], xa1[kInterpPx];
+        int poff[kInterpPx];
+#pragma unroll
+        for (int j = 0; j < kInterpPx; ++j) {
+            const float txf = __fsub_rn(__fmul_rn((float)(x0 + j), g.inv_tw), 0.5f);
+            const int tx1 = floor_f32_to_int(txf);
+            xa[j] = __fsub_rn(txf, (float)tx1);
+            xa1[j] = __fsub_rn(1.0f, xa[j]);
+            int pr = tx1 + 1;                                  // pair index; columns beyond the frame are never used
+            pr = pr < 0 ? 0 : (pr > g.tiles_x ? g.tiles_x : pr);
+            poff[j] = pr << 8;
+        }
+        const uint8_t* src = p.src + (long long)f * p.src_frame;
+        uint8_t* dst = p.dst + (long long)f * p.dst_frame;
+        const bool full = x0 + kInterpPx <= g.width;
+        // ty1 is monotone in y: trim the widened range to the rows that really belong to this band, using the
+        // reference's own float expression (at most kBandMargin+1 steps per end)
+        auto ty1_of = [&](int y) { return floor_f32_to_int(__fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f)); };
+        int ya_lo = y_lo, ya_hi = y_hi;
+        while (ya_lo < ya_hi && ty1_of(ya_lo) != ty1u) ++ya_lo;
+        while (ya_hi > ya_lo && ty1_of(ya_hi - 1) != ty1u) --ya_hi;
+        // rows of this lane: ya_lo + phase, + phases, ...  (sub-ranges are contiguous per block, phases interleave inside)
+        int y = ya_lo + ((phase - (ya_lo - y_lo) % phases) % phases + phases) % phases;
+        if (full) {
+            // The loop is VALU-issue bound (~290 instructions per 16 pixels: 64 byte->float converts, 144 blend
+            // flops, 16 LDS reads); an explicit 2-row software pipeline measured 11 % SLOWER than letting the
+            // other resident waves cover the load latency, so the row loop stays simple.
+            for (; y < ya_hi; y += phases) {
+                const u32x4 q = *reinterpret_cast<const u32x4_u*>(src + (long long)y * p.src_step + x0);
+                const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+                const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
+                *reinterpret_cast<u32x4_u*>(dst + (long long)y * p.dst_step + x0) =
+                    FT ? clahe_vec16_f32(quadf, q, poff, xa, xa1, ya, ya1) : clahe_vec16(quad, q, poff, xa, xa1, ya, ya1);
+            }
+        } else {
+            for (; y < ya_hi; y += phases) {
+                const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+                const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
+                const uint8_t* sr = src + (long long)y * p.src_step + x0;
+                uint8_t* dr = dst + (long long)y * p.dst_step + x0;
+#pragma unroll
+                for (int j = 0; j < kInterpPx; ++j)
+                    if (x0 + j < g.width) {
+                        uint32_t e;
+                        if (FT) {
+                            const f32x4 fe = quadf[poff[j] + sr[j]];
+                            e = (uint32_t)fe.x | ((uint32_t)fe.z << 8) | ((uint32_t)fe.y << 16) | ((uint32_t)fe.w << 24);
+                        } else {
+                            e = quad[poff[j] + sr[j]];
+                        }
+                        dr[j] = (uint8_t)clahe_px(e, xa[j], xa1[j], ya, ya1);
+                    }
+            }
+        }
+    }
+    if (uv.bytes > 0 && blockIdx.z == 0)
+        uv_flat(uv.src + (long long)f * uv.src_frame, uv.dst + (long long)f * uv.dst_frame, uv.bytes, uv.mode, blockIdx.x, gridDim.x);
+}
+
+// Fallback for tile grids too wide for the LDS pair table: LUTs gathered from global memory (L2).
+__global__ __launch_bounds__(kThreads) void clahe_interp_global_kernel(PlaneBatch p, ClaheGeom g, const uint8_t* __restrict__ luts)
+{
+    const int f = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * kThreads + threadIdx.x;
+    if (x >= g.width) return;
+    const uint8_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * 256;
+    const float txf = __fsub_rn(__fmul_rn((float)x, g.inv_tw), 0.5f);
+    int tx1 = floor_f32_to_int(txf);
+    const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
+    int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
+    const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+    int ty1 = floor_f32_to_int(tyf);
+    const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
+    int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
+    const uint32_t v = p.src[(long long)f * p.src_frame + (long long)y * p.src_step + x];
+    const uint32_t q = (uint32_t)lf[((size_t)ty1 * g.tiles_x + tx1) * 256 + v] |
+                       ((uint32_t)lf[((size_t)ty1 * g.tiles_x + tx2) * 256 + v] << 8) |
+                       ((uint32_t)lf[((size_t)ty2 * g.tiles_x + tx1) * 256 + v] << 16) |
+                       ((uint32_t)lf[((size_t)ty2 * g.tiles_x + tx2) * 256 + v] << 24);
+    p.dst[(long long)f * p.dst_frame + (long long)y * p.dst_step + x] = (uint8_t)clahe_px(q, xa, xa1, ya, ya1);
+}
+
+// UV-only launch (used when the Y kernel cannot carry the UV job).
+__global__ __launch_bounds__(kThreads) void uv_kernel(UVJob uv)
+{
+    const int f = blockIdx.y;
+    uv_flat(uv.src + (long long)f * uv.src_frame, uv.dst + (long long)f * uv.dst_frame, uv.bytes, uv.mode, blockIdx.x, gridDim.x);
+}
+
+
+}  // namespace mi

@@ -1,0 +1,128 @@
+// color.hip.h -- cvtColor BGR2YUV / YUV2BGR and fused split/merge
+// Part of the gfx950 kernel set of libmi_lumaeq (see ../lumaeq_kernels.hip.h for the design notes).
+#pragma once
+#include "common.hip.h"
+
+namespace mi {
+// =============================================================================================
+// Colour-domain neighbours of the path: cv::cvtColor(COLOR_BGR2YUV / COLOR_YUV2BGR) on CV_8UC3
+// and the split / merge around the luma op (singlecolor.cpp:39-66, clahe1frame.cpp:83-102).
+// OpenCV 4.4 color_yuv.simd.hpp, 8-bit fixed point (yuv_shift = 14), restated in oracle/color_oracle.c:
+//   Y = DESCALE(B*1868 + G*9617 + R*4899), U = DESCALE((B-Y)*8061 + (128<<14)), V = DESCALE((R-Y)*14369 + (128<<14))
+//   B = Y + DESCALE((U-128)*33292), G = Y + DESCALE((U-128)*-6472 + (V-128)*-9519), R = Y + DESCALE((V-128)*18678)
+// Pure integer work, 3 B/px streams: bound by HBM.  A lane handles 16 pixels = 3 x 16 B of interleaved data.
+// =============================================================================================
+struct ColorJob {
+    const uint8_t* src; uint8_t* dst;        // interleaved CV_8UC3 side (src for MODE 0/1/2, dst for 0/1/3)
+    long long src_step, dst_step;            // bytes between rows (interleaved side(s))
+    long long src_frame, dst_frame;
+    uint8_t* p0; uint8_t* p1; uint8_t* p2;   // planes (MODE 2: outputs Y,U,V; MODE 3: inputs Y,U,V), tightly packed W*H each
+    long long plane_frame;                   // bytes between frames of each plane
+    long long row_px;                        // pixels per row (contiguous images: W*H with rows == 1)
+    int rows;
+};
+
+// CV_DESCALE(x, 14).  The empty asm keeps the shifted value opaque: hipcc (ROCm 7.2) otherwise folds pairs of
+// "arithmetic shift right -> clamp to [0,255] -> pack" into gfx950's v_ashr_pk_u8_i32, and that lowering produced
+// wrong bytes for the V plane here (tools/dbg_color.hip reproduces it: neighbouring bytes get OR-ed together).
+__device__ __forceinline__ int yuv_descale(int x) { int r = (x + (1 << 13)) >> 14; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ uint32_t sat_u8(int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+__device__ __forceinline__ void px_bgr2yuv(uint32_t b, uint32_t g, uint32_t r, uint32_t& Y, uint32_t& U, uint32_t& V)
+{
+    const int y = yuv_descale((int)b * 1868 + (int)g * 9617 + (int)r * 4899);
+    V = sat_u8(yuv_descale(((int)r - y) * 14369 + (128 << 14)));
+    U = sat_u8(yuv_descale(((int)b - y) * 8061 + (128 << 14)));
+    Y = sat_u8(y);
+}
+__device__ __forceinline__ void px_yuv2bgr(uint32_t Y, uint32_t U, uint32_t V, uint32_t& b, uint32_t& g, uint32_t& r)
+{
+    const int u = (int)U - 128, v = (int)V - 128;
+    b = sat_u8((int)Y + yuv_descale(u * 33292));
+    g = sat_u8((int)Y + yuv_descale(u * -6472 + v * -9519));
+    r = sat_u8((int)Y + yuv_descale(v * 18678));
+}
+
+// MODE 0: BGR -> YUV interleaved.  1: YUV -> BGR interleaved.  2: BGR -> planes Y,U,V (cvtColor + split).
+// 3: planes Y,U,V -> BGR (merge + cvtColor).   grid = (blocks, min(rows, 65535), frames)
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void color_kernel(ColorJob j)
+{
+    const int f = blockIdx.z;
+    for (int row = blockIdx.y; row < j.rows; row += gridDim.y) {
+        const uint8_t* s3 = MODE != 3 ? j.src + (long long)f * j.src_frame + (long long)row * j.src_step : nullptr;
+        uint8_t* d3 = MODE != 2 ? j.dst + (long long)f * j.dst_frame + (long long)row * j.dst_step : nullptr;
+        const long long poff = (long long)f * j.plane_frame + (long long)row * j.row_px;
+        const long long groups = j.row_px >> 4;
+        const bool a3s = MODE == 3 || (((uintptr_t)s3 & 15) == 0), a3d = MODE == 2 || (((uintptr_t)d3 & 15) == 0);
+        const bool ap = MODE < 2 || ((((uintptr_t)j.p0 | (uintptr_t)j.p1 | (uintptr_t)j.p2 | (uintptr_t)poff) & 15) == 0);
+        if (a3s && a3d && ap) {
+            for (long long gidx = (long long)blockIdx.x * kThreads + threadIdx.x; gidx < groups; gidx += (long long)gridDim.x * kThreads) {
+                uint32_t c0[16], c1[16], c2[16];            // channel values of 16 pixels
+                if (MODE != 3) {
+                    const u32x4* sp = reinterpret_cast<const u32x4*>(s3 + gidx * 48);
+                    const u32x4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+                    const uint32_t w[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        c0[p] = (w[(3 * p) >> 2] >> (8 * ((3 * p) & 3))) & 0xffu;
+                        c1[p] = (w[(3 * p + 1) >> 2] >> (8 * ((3 * p + 1) & 3))) & 0xffu;
+                        c2[p] = (w[(3 * p + 2) >> 2] >> (8 * ((3 * p + 2) & 3))) & 0xffu;
+                    }
+                } else {
+                    const u32x4 y = *reinterpret_cast<const u32x4*>(j.p0 + poff + gidx * 16);
+                    const u32x4 u = *reinterpret_cast<const u32x4*>(j.p1 + poff + gidx * 16);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(j.p2 + poff + gidx * 16);
+                    const uint32_t wy[4] = {y.x, y.y, y.z, y.w}, wu[4] = {u.x, u.y, u.z, u.w}, wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        c0[p] = (wy[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                        c1[p] = (wu[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                        c2[p] = (wv[p >> 2] >> (8 * (p & 3))) & 0xffu;
+                    }
+                }
+                uint32_t o0[16], o1[16], o2[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    if (MODE == 0 || MODE == 2) px_bgr2yuv(c0[p], c1[p], c2[p], o0[p], o1[p], o2[p]);
+                    else px_yuv2bgr(c0[p], c1[p], c2[p], o0[p], o1[p], o2[p]);
+                }
+                if (MODE != 2) {
+                    uint32_t w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        w[(3 * p) >> 2] |= o0[p] << (8 * ((3 * p) & 3));
+                        w[(3 * p + 1) >> 2] |= o1[p] << (8 * ((3 * p + 1) & 3));
+                        w[(3 * p + 2) >> 2] |= o2[p] << (8 * ((3 * p + 2) & 3));
+                    }
+                    u32x4* dp = reinterpret_cast<u32x4*>(d3 + gidx * 48);
+                    const u32x4 r0 = {w[0], w[1], w[2], w[3]}, r1 = {w[4], w[5], w[6], w[7]}, r2 = {w[8], w[9], w[10], w[11]};
+                    dp[0] = r0; dp[1] = r1; dp[2] = r2;
+                } else {
+                    uint32_t wy[4], wu[4], wv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        wy[k] = o0[4 * k] | (o0[4 * k + 1] << 8) | (o0[4 * k + 2] << 16) | (o0[4 * k + 3] << 24);
+                        wu[k] = o1[4 * k] | (o1[4 * k + 1] << 8) | (o1[4 * k + 2] << 16) | (o1[4 * k + 3] << 24);
+                        wv[k] = o2[4 * k] | (o2[4 * k + 1] << 8) | (o2[4 * k + 2] << 16) | (o2[4 * k + 3] << 24);
+                    }
+                    const u32x4 ry = {wy[0], wy[1], wy[2], wy[3]}, ru = {wu[0], wu[1], wu[2], wu[3]}, rv = {wv[0], wv[1], wv[2], wv[3]};
+                    *reinterpret_cast<u32x4*>(j.p0 + poff + gidx * 16) = ry;
+                    *reinterpret_cast<u32x4*>(j.p1 + poff + gidx * 16) = ru;
+                    *reinterpret_cast<u32x4*>(j.p2 + poff + gidx * 16) = rv;
+                }
+            }
+        }
+        // ragged tail of the row (or the whole row when something is not 16-B aligned): one pixel per lane
+        const long long first = (a3s && a3d && ap) ? (groups << 4) : 0;
+        for (long long x = first + (long long)blockIdx.x * kThreads + threadIdx.x; x < j.row_px; x += (long long)gridDim.x * kThreads) {
+            uint32_t a, b, c, o0, o1, o2;
+            if (MODE != 3) { a = s3[3 * x]; b = s3[3 * x + 1]; c = s3[3 * x + 2]; }
+            else { a = j.p0[poff + x]; b = j.p1[poff + x]; c = j.p2[poff + x]; }
+            if (MODE == 0 || MODE == 2) px_bgr2yuv(a, b, c, o0, o1, o2); else px_yuv2bgr(a, b, c, o0, o1, o2);
+            if (MODE != 2) { d3[3 * x] = (uint8_t)o0; d3[3 * x + 1] = (uint8_t)o1; d3[3 * x + 2] = (uint8_t)o2; }
+            else { j.p0[poff + x] = (uint8_t)o0; j.p1[poff + x] = (uint8_t)o1; j.p2[poff + x] = (uint8_t)o2; }
+        }
+    }
+}
+
+}  // namespace mi

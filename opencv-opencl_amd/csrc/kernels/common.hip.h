@@ -1,0 +1,128 @@
+// common.hip.h -- shared types and device helpers (vector types, batch descriptors, bank-replicated LDS
+// histogram primitives, wave/block scans).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));   // gfx950 global_load/store_dwordx4 accept any alignment
+
+constexpr int kThreads = 256;        // 4 waves of 64
+constexpr int kCopies = 32;          // LDS replication = number of ds_*_b32 banks
+constexpr int kCopyShift = 5;
+
+// A batch of strided 8-bit planes. "rows == 1" means the plane is contiguous and row_bytes = W*H.
+struct PlaneBatch {
+    const uint8_t* src;
+    uint8_t* dst;
+    long long src_step, dst_step;     // bytes between rows
+    long long src_frame, dst_frame;   // bytes between frames
+    long long row_bytes;              // bytes per row
+    int rows;
+};
+
+// Trailing UV job of an NV12 frame fused into the apply launch.
+struct UVJob {
+    const uint8_t* src;
+    uint8_t* dst;
+    long long src_frame, dst_frame;
+    long long bytes;                  // 0 = none
+    int mode;                         // 0 = fill 128, 1 = copy
+};
+
+struct Split16 { long long head, nvec, tail; };
+
+__device__ __forceinline__ Split16 split16(const void* p, long long n)
+{
+    Split16 s;
+    s.head = (16 - (long long)((uintptr_t)p & 15)) & 15;
+    if (s.head > n) s.head = n;
+    s.nvec = (n - s.head) >> 4;
+    s.tail = n - s.head - (s.nvec << 4);
+    return s;
+}
+
+__device__ __forceinline__ void lds_inc(uint32_t* h, uint32_t idx)
+{
+    __hip_atomic_fetch_add(h + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32
+}
+
+__device__ __forceinline__ void hist_add_dword(uint32_t* h, uint32_t w, uint32_t copy)
+{
+    lds_inc(h, ((w & 0xffu) << kCopyShift) + copy);
+    lds_inc(h, (((w >> 8) & 0xffu) << kCopyShift) + copy);
+    lds_inc(h, (((w >> 16) & 0xffu) << kCopyShift) + copy);
+    lds_inc(h, ((w >> 24) << kCopyShift) + copy);
+}
+
+__device__ __forceinline__ void hist_add_vec(uint32_t* h, u32x4 q, uint32_t copy)
+{
+    hist_add_dword(h, q.x, copy);
+    hist_add_dword(h, q.y, copy);
+    hist_add_dword(h, q.z, copy);
+    hist_add_dword(h, q.w, copy);
+}
+
+// Histogram of the bytes [p, p+n) shared between `nparts` workgroups; this one is `part`.
+__device__ __forceinline__ void hist_flat(uint32_t* h, const uint8_t* p, long long n, int part, int nparts)
+{
+    const int t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    const Split16 s = split16(p, n);
+    if (part == 0 && t < s.head) lds_inc(h, ((uint32_t)p[t] << kCopyShift) + copy);
+    if (part == nparts - 1 && t < s.tail) lds_inc(h, ((uint32_t)p[s.head + (s.nvec << 4) + t] << kCopyShift) + copy);
+    const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
+    const u32x4* vp = reinterpret_cast<const u32x4*>(p + s.head);
+    long long i = v0 + t;
+    for (; i + 3 * kThreads < v1; i += 4 * kThreads) {      // 4 x 16 B in flight per lane
+        const u32x4 a = vp[i], b = vp[i + kThreads], c = vp[i + 2 * kThreads], d = vp[i + 3 * kThreads];
+        hist_add_vec(h, a, copy); hist_add_vec(h, b, copy); hist_add_vec(h, c, copy); hist_add_vec(h, d, copy);
+    }
+    for (; i < v1; i += kThreads) hist_add_vec(h, vp[i], copy);
+}
+
+__device__ __forceinline__ void lds_hist_zero(uint32_t* h)
+{
+    for (int i = threadIdx.x; i < 256 * kCopies; i += kThreads) h[i] = 0;
+    __syncthreads();
+}
+
+// Sum of the 32 copies of bin `t` (skewed so that the 64 lanes of a wave hit 32 different banks).
+__device__ __forceinline__ uint32_t lds_hist_bin(const uint32_t* h, int t)
+{
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kCopies; ++k) s += h[(t << kCopyShift) + ((k + t) & (kCopies - 1))];
+    return s;
+}
+
+// Block-wide helpers for 256 threads = 4 waves ------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// inclusive scan over the 256 threads of the block; *block_total receives the grand total.
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* block_total)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t incl = wave_incl_scan(v);
+    __syncthreads();                               // s_wave may be in use by a previous call
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t x = s_wave[k]; if (k < w) off += x; tot += x; }
+    if (block_total) *block_total = tot;
+    return incl + off;
+}
+
+}  // namespace mi

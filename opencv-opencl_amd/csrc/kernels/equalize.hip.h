@@ -1,0 +1,168 @@
+// equalize.hip.h -- K1 histogram partials, K2 CDF->LUT, K3 LUT apply (+UV): the three-kernel equalizeHist path
+// Part of the gfx950 kernel set of libmi_lumaeq (see ../lumaeq_kernels.hip.h for the design notes).
+#pragma once
+#include "common.hip.h"
+
+namespace mi {
+// ---------------------------------------------------------------------------------------------
+// K1  histogram partials.  grid = (B, n_frames); partial[f][b][256].
+// Reads W*H bytes per frame once; writes B KiB per frame.  Bound: HBM read.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void hist_partial_kernel(PlaneBatch p, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[256 * kCopies];
+    lds_hist_zero(h);
+    const uint8_t* base = p.src + (long long)blockIdx.y * p.src_frame;
+    if (p.rows == 1) {
+        hist_flat(h, base, p.row_bytes, blockIdx.x, gridDim.x);
+    } else {
+        for (int r = blockIdx.x; r < p.rows; r += gridDim.x) hist_flat(h, base + (long long)r * p.src_step, p.row_bytes, 0, 1);
+    }
+    __syncthreads();
+    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = lds_hist_bin(h, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  CDF -> LUT (oracle: orc_equalize_lut).  grid = n_frames, 256 threads = bins.
+// partial[f][b][256] summed over b (b = 1 turns it into "LUT from a finished histogram").
+// ---------------------------------------------------------------------------------------------
+// The CDF -> LUT arithmetic for bin t = threadIdx.x given this bin's count c (all 256 threads call it).
+// histogram.cpp cv::equalizeHist after the histogram: first non-zero bin i, constant-image shortcut,
+// scale = 255.f/(total - hist[i]), lut[j] = saturate_cast<uchar>(sum_j * scale) with cvRound.
+struct EqLutShared { uint32_t wave[4]; int first[4]; uint32_t hfirst; };
+
+__device__ __forceinline__ uint8_t equalize_lut_value(uint32_t c, int total, EqLutShared* sh)
+{
+    const int t = threadIdx.x;
+    const unsigned long long nz = __ballot(c != 0);
+    __syncthreads();                                               // sh may still be read from a previous use
+    if ((t & 63) == 0) sh->first[t >> 6] = nz ? (t + __builtin_ctzll(nz)) : 256;
+    const uint32_t cdf = block_incl_scan(c, sh->wave, nullptr);    // contains the barriers that publish first[]
+    const int first = min(min(sh->first[0], sh->first[1]), min(sh->first[2], sh->first[3]));
+    if (t == first) sh->hfirst = c;
+    __syncthreads();
+    const uint32_t hfirst = sh->hfirst;
+    if ((int)hfirst == total) return (uint8_t)first;                // dst.setTo(i)
+    if (t <= first) return 0;
+    const float scale = __fdiv_rn(255.0f, (float)(total - (int)hfirst));
+    const int sum = (int)(cdf - hfirst);                            // bins first+1 .. t
+    int r = __float2int_rn(__fmul_rn((float)sum, scale));           // cvRound: nearest, ties to even
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    return (uint8_t)r;
+}
+
+__global__ __launch_bounds__(kThreads) void equalize_lut_kernel(const uint32_t* __restrict__ partial, int nparts, int total,
+                                                               uint8_t* __restrict__ lut_out, int32_t* __restrict__ hist_out)
+{
+    __shared__ EqLutShared sh;
+    const int t = threadIdx.x, f = blockIdx.x;
+    const uint32_t* pp = partial + (size_t)f * nparts * 256 + t;
+    uint32_t c = 0;
+    int b = 0;
+    for (; b + 4 <= nparts; b += 4) {
+        const uint32_t c0 = pp[(size_t)b * 256], c1 = pp[(size_t)(b + 1) * 256], c2 = pp[(size_t)(b + 2) * 256], c3 = pp[(size_t)(b + 3) * 256];
+        c += c0 + c1 + c2 + c3;
+    }
+    for (; b < nparts; ++b) c += pp[(size_t)b * 256];
+    if (hist_out) hist_out[(size_t)f * 256 + t] = (int32_t)c;
+    if (!lut_out) return;
+    lut_out[(size_t)f * 256 + t] = equalize_lut_value(c, total, &sh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  LUT apply (+ fused NV12 UV fill/copy)  (SURVEY 8a rows A4, A7).  grid = (B, n_frames).
+// Reads W*H, writes W*H (plus UV: writes W*H/2, reads W*H/2 when copying).  Bound: HBM.
+// LDS: lut[value][32] replicated -> conflict-free ds_read per pixel.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lut_dword(const uint32_t* lut, uint32_t w, uint32_t copy)
+{
+    const uint32_t a = lut[((w & 0xffu) << kCopyShift) + copy];
+    const uint32_t b = lut[(((w >> 8) & 0xffu) << kCopyShift) + copy];
+    const uint32_t c = lut[(((w >> 16) & 0xffu) << kCopyShift) + copy];
+    const uint32_t d = lut[((w >> 24) << kCopyShift) + copy];
+    return a | (b << 8) | (c << 16) | (d << 24);
+}
+
+__device__ __forceinline__ u32x4 lut_vec(const uint32_t* lut, u32x4 q, uint32_t copy)
+{
+    u32x4 r;
+    r.x = lut_dword(lut, q.x, copy); r.y = lut_dword(lut, q.y, copy);
+    r.z = lut_dword(lut, q.z, copy); r.w = lut_dword(lut, q.w, copy);
+    return r;
+}
+
+// dst[i] = lut[src[i]] for i in [0,n), vector body aligned on dst (src loads may be unaligned).
+__device__ __forceinline__ void lut_flat(const uint32_t* lut, const uint8_t* src, uint8_t* dst, long long n, int part, int nparts)
+{
+    const int t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    const Split16 s = split16(dst, n);
+    if (part == 0 && t < s.head) dst[t] = (uint8_t)lut[((uint32_t)src[t] << kCopyShift) + copy];
+    if (part == nparts - 1 && t < s.tail) {
+        const long long o = s.head + (s.nvec << 4) + t;
+        dst[o] = (uint8_t)lut[((uint32_t)src[o] << kCopyShift) + copy];
+    }
+    const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
+    const u32x4_u* sp = reinterpret_cast<const u32x4_u*>(src + s.head);
+    u32x4* dp = reinterpret_cast<u32x4*>(dst + s.head);
+    long long i = v0 + t;
+    for (; i + 3 * kThreads < v1; i += 4 * kThreads) {
+        const u32x4 a = sp[i], b = sp[i + kThreads], c = sp[i + 2 * kThreads], d = sp[i + 3 * kThreads];
+        dp[i] = lut_vec(lut, a, copy);
+        dp[i + kThreads] = lut_vec(lut, b, copy);
+        dp[i + 2 * kThreads] = lut_vec(lut, c, copy);
+        dp[i + 3 * kThreads] = lut_vec(lut, d, copy);
+    }
+    for (; i < v1; i += kThreads) dp[i] = lut_vec(lut, sp[i], copy);
+}
+
+// UV plane: fill with 128 or copy, dst aligned stores.
+__device__ __forceinline__ void uv_flat(const uint8_t* src, uint8_t* dst, long long n, int mode, int part, int nparts)
+{
+    const int t = threadIdx.x;
+    const Split16 s = split16(dst, n);
+    if (part == 0 && t < s.head) dst[t] = mode ? src[t] : (uint8_t)128;
+    if (part == nparts - 1 && t < s.tail) {
+        const long long o = s.head + (s.nvec << 4) + t;
+        dst[o] = mode ? src[o] : (uint8_t)128;
+    }
+    const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
+    u32x4* dp = reinterpret_cast<u32x4*>(dst + s.head);
+    if (mode == 0) {
+        const u32x4 g = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+        for (long long i = v0 + t; i < v1; i += kThreads) dp[i] = g;
+    } else {
+        const u32x4_u* sp = reinterpret_cast<const u32x4_u*>(src + s.head);
+        long long i = v0 + t;
+        for (; i + 3 * kThreads < v1; i += 4 * kThreads) {
+            const u32x4 a = sp[i], b = sp[i + kThreads], c = sp[i + 2 * kThreads], d = sp[i + 3 * kThreads];
+            dp[i] = a; dp[i + kThreads] = b; dp[i + 2 * kThreads] = c; dp[i + 3 * kThreads] = d;
+        }
+        for (; i < v1; i += kThreads) dp[i] = sp[i];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void lut_apply_kernel(PlaneBatch p, const uint8_t* __restrict__ luts, UVJob uv)
+{
+    __shared__ uint32_t lut[256 * kCopies];
+    const int t = threadIdx.x, f = blockIdx.y;
+    {
+        const uint32_t v = luts[(size_t)f * 256 + t];
+#pragma unroll
+        for (int k = 0; k < kCopies; ++k) lut[(t << kCopyShift) + ((k + t) & (kCopies - 1))] = v;
+    }
+    __syncthreads();
+    const uint8_t* src = p.src + (long long)f * p.src_frame;
+    uint8_t* dst = p.dst + (long long)f * p.dst_frame;
+    if (p.rows == 1) {
+        lut_flat(lut, src, dst, p.row_bytes, blockIdx.x, gridDim.x);
+    } else {
+        for (int r = blockIdx.x; r < p.rows; r += gridDim.x)
+            lut_flat(lut, src + (long long)r * p.src_step, dst + (long long)r * p.dst_step, p.row_bytes, 0, 1);
+    }
+    if (uv.bytes > 0)
+        uv_flat(uv.src + (long long)f * uv.src_frame, uv.dst + (long long)f * uv.dst_frame, uv.bytes, uv.mode, blockIdx.x, gridDim.x);
+}
+
+
+}  // namespace mi

@@ -1,0 +1,234 @@
+// equalize_fused.hip.h -- KF fused single-read equalizeHist (persistent, ticketed, register-resident slices)
+// Part of the gfx950 kernel set of libmi_lumaeq (see ../lumaeq_kernels.hip.h for the design notes).
+#pragma once
+#include "common.hip.h"
+#include "equalize.hip.h"
+
+namespace mi {
+// =============================================================================================
+// KF  fused single-read equalizeHist (+ NV12 UV): histogram, CDF/LUT and LUT apply in ONE launch,
+// the Y plane read from HBM once.  (SURVEY 8a rows A2+A3+A4+A7.)
+//
+// MI355X-first design: a 4K Y plane (8.3 MB) does not fit a CU, but it fits the chip: the frame is
+// cut into 64 KiB slices, a workgroup keeps its slice in REGISTERS (256 threads x 16 x 16 B) from the
+// histogram pass to the apply pass, and the ~127 workgroups holding one frame's slices meet once:
+//   1. ticket = atomicAdd(work) -- persistent workgroups take (frame, slice) tickets in order, so the
+//      slices of the oldest unfinished frame are always held by running workgroups (no deadlock for
+//      any dispatch order as long as >= T workgroups are co-resident; the host guarantees T <= CUs/2);
+//   2. slice histogram in LDS (bank-replicated, as K1) -> non-zero bins added to ghist[frame] with
+//      agent-scope atomics; every wave waits vmcnt(0); one lane takes an arrival number;
+//   3. the LAST arriver exchanges the 256 counts out (returning atomics: coherent by construction),
+//      checks sum == W*H (an exact integrity test of the hand-off; retried, bounded), computes the LUT,
+//      publishes it with write-through (sc1) stores + checksum, then sets ready[frame];
+//   4. the others poll ready[frame] from one lane (relaxed sc1 loads + s_sleep), then ONE agent acquire,
+//      then load the 256-byte LUT with sc1 loads and verify the checksum (cdna_hip_programming.md
+//      Guideline 16: release on the producer side is replaced by write-through stores drained with
+//      vmcnt(0); the consumer keeps the acquire);
+//   5. everybody applies the LUT to its registers and streams the result out.
+// UV planes are extra tickets (pure fill / copy).  HBM traffic per NV12 frame: read W*H, write
+// W*H (+ UV) instead of reading W*H twice.  Every spin is bounded (s_memrealtime): on a timeout the
+// workgroup sets *status and leaves, so the grid always drains.
+// =============================================================================================
+constexpr int kVPT = 20;                            // default: 16-byte vectors a thread keeps in registers (80 KiB slices)
+constexpr int kLutPubWords = 128;                   // per frame: 64 LUT dwords + checksum, padded to 512 B
+constexpr int kFlagStride = 32;                     // one 128-B line per frame flag / counter
+
+struct FusedJob {
+    const uint8_t* src; uint8_t* dst;               // Y plane of frame 0 (16-B aligned)
+    long long src_frame, dst_frame;                 // bytes between frames (multiples of 16)
+    long long nvec;                                 // W*H / 16 (exact)
+    int total;                                      // W*H
+    int n_frames;
+    int T, U;                                       // Y tickets / UV tickets per frame
+    int acquire;                                    // 1: consumers issue an agent acquire before reading the LUT
+    int fault_inject;                               // test hook: the last arriver of frame 0 never publishes its LUT
+    unsigned long long timeout_ticks;               // bound of every wait, in 100 MHz ticks
+    UVJob uv;
+    // Hand-off block.  Zeroed once when allocated; every launch leaves it clean again: the ticket counter only
+    // grows (work_base = its value at launch), the last arriver of a frame drains ghist (exchange) and resets cnt,
+    // ready/lutpub are stamped with a per-launch epoch.  No memset node per call.
+    unsigned long long* work;                       // ticket dispenser (monotonic)
+    unsigned long long work_base;
+    uint32_t epoch;                                 // != 0, different for every launch of a context
+    uint32_t* ghist;                                // [cap][256]
+    uint32_t* cnt;                                  // [cap][kFlagStride]
+    uint32_t* ready;                                // [cap][kFlagStride]
+    uint32_t* lutpub;                               // [cap][kLutPubWords]
+    uint32_t* status;                               // [0] != 0: a bounded wait expired (result invalid; sticky)
+};
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Opaque identity: stops LICM/CSE from keeping hundreds of derived values (LDS addresses, extracted pixel
+// bytes) alive across the phases of the persistent loop -- without it the kernel spills ~200 VGPRs.
+__device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ void launder(u32x4& v) { asm volatile("" : "+v"(v)); }
+
+struct FusedShared {
+    EqLutShared eq;
+    unsigned long long ticket;
+    uint32_t lut_words[64];
+    uint32_t red[4];
+    int last, ok, timeout;
+};
+
+// Zeroes the hand-off block (a plain kernel instead of hipMemsetAsync: it is captured into HIP graphs like any
+// other launch; a memset node did not re-run on graph replay in testing).
+__global__ __launch_bounds__(kThreads) void zero_words_kernel(uint32_t* p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) p[i] = 0;
+}
+
+template <int VPT>
+__global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
+{
+    constexpr int kSliceVecs = kThreads * VPT;
+    __shared__ uint32_t lds[256 * kCopies];          // slice histogram, then the replicated LUT
+    __shared__ FusedShared sh;
+    const int t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    const unsigned long long P = (unsigned long long)(j.T + j.U);
+    const unsigned long long total_tickets = P * (unsigned long long)j.n_frames;
+    for (;;) {
+        __syncthreads();
+        if (t == 0) sh.ticket = __hip_atomic_fetch_add(j.work, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - j.work_base;
+        __syncthreads();
+        unsigned long long k = sh.ticket;                            // make it provably wave-uniform (SGPRs): all the
+        k = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 32)) << 32) |   // per-ticket address math then
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)k);                              // stays scalar (guide T20)
+        if (k >= total_tickets) break;
+        const int f = (int)(k / P);
+        const int r = (int)(k - (unsigned long long)f * P);
+        if (r >= j.T) {                               // UV ticket (A7): 64 KiB of plain fill / copy
+            uv_flat(j.uv.src ? j.uv.src + (long long)f * j.uv.src_frame : nullptr, j.uv.dst + (long long)f * j.uv.dst_frame,
+                    j.uv.bytes, j.uv.mode, r - j.T, j.U);
+            continue;
+        }
+        // ---- 1. slice -> registers (loads issued first, LDS zeroing overlaps their latency)
+        const long long v0 = (long long)r * kSliceVecs;
+        const long long rem = j.nvec - v0;            // vectors of this slice that exist (> 0)
+        const int rem32 = (int)(rem < (long long)kSliceVecs ? rem : (long long)kSliceVecs);
+        // buffer descriptors over exactly this slice: 32-bit lane offset + scalar offset, and the hardware range
+        // check drops the lanes beyond a short last slice (loads return 0, stores are discarded) -- no predicates
+        const auto srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(j.src + (long long)f * j.src_frame + v0 * 16), 0, rem32 * 16, 0x00020000);
+        const auto drsrc = __builtin_amdgcn_make_buffer_rsrc(j.dst + (long long)f * j.dst_frame + v0 * 16, 0, rem32 * 16, 0x00020000);
+        const int toff = t * 16;
+        u32x4 q[VPT];
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) q[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, toff, i * (kThreads * 16), 0);
+        for (int i = t; i < 256 * kCopies; i += kThreads) lds[i] = 0;
+        __syncthreads();
+        // ---- 2. slice histogram, publish with agent-scope atomics
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            if (i * kThreads + t < rem32) hist_add_vec(lds, q[i], copy);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        {
+            const uint32_t c = lds_hist_bin(lds, launder(t));
+            if (c) __hip_atomic_fetch_add(j.ghist + (size_t)f * 256 + t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's atomics have been performed
+        __syncthreads();
+        if (t == 0) {
+            const uint32_t arrived = __hip_atomic_fetch_add(j.cnt + (size_t)f * kFlagStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh.last = (arrived == (uint32_t)(j.T - 1));
+            sh.ok = 1;
+        }
+        __syncthreads();
+        uint8_t my_lut;
+        if (sh.last && j.fault_inject && f == 0) break;              // test hook: simulate a lost producer (others must time out)
+        if (sh.last) {
+            // ---- 3. last arriver: collect, verify, compute and publish the LUT
+            uint32_t h = 0;
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                h += __hip_atomic_exchange(j.ghist + (size_t)f * 256 + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t ws = wave_sum(h);
+                __syncthreads();
+                if ((t & 63) == 0) sh.red[t >> 6] = ws;
+                if (t == 0) sh.timeout = (__builtin_amdgcn_s_memrealtime() - t_start > j.timeout_ticks);   // one decision for the block
+                __syncthreads();
+                if (sh.red[0] + sh.red[1] + sh.red[2] + sh.red[3] == (uint32_t)j.total) break;
+                if (sh.timeout) {
+                    if (t == 0) { sh.ok = 0; st_agent(j.status, 1u); }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            __syncthreads();
+            if (!sh.ok) break;
+            my_lut = equalize_lut_value(h, j.total, &sh.eq);
+            reinterpret_cast<uint8_t*>(sh.lut_words)[t] = my_lut;
+            __syncthreads();
+            if (t < 64) {
+                const uint32_t w = sh.lut_words[t];
+                uint32_t* pub = j.lutpub + (size_t)f * kLutPubWords;
+                st_agent(pub + t, w);
+                const uint32_t sum = wave_sum(w) + 0x5EED0001u + j.epoch;
+                if (t == 0) {
+                    st_agent(pub + 64, sum);
+                    st_agent(j.cnt + (size_t)f * kFlagStride, 0u);  // all T arrivals are in: leave the counter clean for the next launch
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // write-through stores have left this CU
+                if (t == 0) st_agent(j.ready + (size_t)f * kFlagStride, j.epoch);
+            }
+        } else {
+            // ---- 4. wait for the frame's LUT
+            if (t == 0) {
+                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                const uint32_t* flag = j.ready + (size_t)f * kFlagStride;
+                while (ld_agent(flag) != j.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (__builtin_amdgcn_s_memrealtime() - t_start > j.timeout_ticks || ld_agent(j.status) != 0u) { sh.ok = 0; st_agent(j.status, 1u); break; }
+                }
+                if (j.acquire) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __syncthreads();
+            if (!sh.ok) break;
+            if (t < 64) {
+                const uint32_t* pub = j.lutpub + (size_t)f * kLutPubWords;
+                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    const uint32_t w = ld_agent(pub + t);
+                    const uint32_t want = ld_agent(pub + 64);
+                    if (wave_sum(w) + 0x5EED0001u + j.epoch == want) { sh.lut_words[t] = w; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t_start > j.timeout_ticks) { if (t == 0) { sh.ok = 0; st_agent(j.status, 2u); } break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+            if (!sh.ok) break;
+            my_lut = reinterpret_cast<const uint8_t*>(sh.lut_words)[t];
+        }
+        // ---- 5. replicated LUT in LDS, apply to the registers, stream out
+        __syncthreads();                                            // everyone is done with the histogram in lds[]
+        {
+            const uint32_t v = my_lut;
+            const int tl = launder(t);
+#pragma unroll
+            for (int c = 0; c < kCopies; ++c) lds[(tl << kCopyShift) + ((c + tl) & (kCopies - 1))] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            launder(q[i]);                                          // re-extract the bytes here instead of keeping 256 of them live
+            __builtin_amdgcn_raw_buffer_store_b128(lut_vec(lds, q[i], copy), drsrc, toff, i * (kThreads * 16), 0);
+            __builtin_amdgcn_sched_barrier(0);                      // keep the bodies apart: the slice already owns 4*VPT VGPRs
+        }
+    }
+}
+
+}  // namespace mi
