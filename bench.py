@@ -304,6 +304,22 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
                                      "frac_of_8TBs": round((2 * ysz + uvb) * Bq / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "hist_partial_kernel": {"avg_ms": round(h_ms, 5), "alg_GBs": round(ysz * Bq / (h_ms * 1e-3) / 1e9, 1)}}
         del q_in, q_out
+    # north star: throughput on 1920x1080 as well as 3840x2160 (same path, 256-frame batches = the same bytes per step)
+    if (w, h) == (3840, 2160) and args.op == "equalize":
+        hw, hh, hb = 1920, 1080, 4 * args.batch
+        hd_in = synth.nv12_batch_torch(hw, hh, hb, args.dist, "cuda", seed=17)
+        hd_out = torch.empty_like(hd_in)
+        uvm = mi_lumaeq.UV_COPY if args.uv == "copy" else mi_lumaeq.UV_FILL128
+        sm = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            ctx.equalize_hist_nv12_batch_dev(hd_in, hd_out, hw, hh, hb, uvm, stream=sm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            ctx.equalize_hist_nv12_batch_dev(hd_in, hd_out, hw, hh, hb, uvm, stream=sm)
+        torch.cuda.synchronize()
+        res["nv12_1080p_equalize_frames_per_s"] = round(50 * hb / (time.perf_counter() - t0), 1)
+        del hd_in, hd_out
     frame = synth.nv12_batch_torch(w, h, 1, args.dist, "cuda", seed=99)
     outb = torch.empty_like(frame)
     stream = torch.cuda.current_stream().cuda_stream

@@ -574,3 +574,34 @@ def test_clahe16_batch_and_errors(ctx):
         ctx.clahe16(frames[0].astype(np.uint8))
     with pytest.raises(mi_lumaeq.MiError):
         ctx.clahe16(frames[0], 2.0, 0, 8)
+
+
+def test_more_frames_than_grid_limit(ctx):
+    """70 000 tiny frames in one call: the fused path's ticket space and the three-kernel path's 65 535-frame chunks."""
+    w, h, n = 4, 4, 70000
+    rng = np.random.default_rng(2)
+    frames = rng.integers(0, 256, (n, w * h + w * h // 2), dtype=np.uint8)
+    d_in = dev(frames)
+    ys = frames[:, : w * h].reshape(n, h, w)
+    check = [0, 1, 65534, 65535, 65536, 69999]
+    try:
+        for fused in (1, 0):
+            ctx.set_option("fused", fused)
+            d_out = torch.zeros_like(d_in)
+            ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 1)
+            ctx.synchronize()
+            out = d_out.cpu().numpy()
+            for k in check:
+                assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=1, op=0)), (fused, k)
+            # every frame: compare against a vectorised numpy equalize of all 70k frames
+            srt = np.sort(ys.reshape(n, -1), axis=1)
+            assert np.array_equal(out[:, w * h:], frames[:, w * h:])
+            assert (out[:, : w * h].min(axis=1) == np.where(srt[:, 0] == srt[:, -1], srt[:, 0], 0)).all()
+        d_out = torch.zeros_like(d_in)
+        ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 0, 2.0, 2, 2)
+        ctx.synchronize()
+        out = d_out.cpu().numpy()
+        for k in check:
+            assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=2, tiles_y=2)), k
+    finally:
+        ctx.set_option("fused", 1)
