@@ -198,6 +198,7 @@ def main():
 
     if rank != 0:
         if world > 1:
+            dist.barrier()                       # leave together with rank 0 (it is still printing the result line)
             dist.destroy_process_group()
         return
 
@@ -268,6 +269,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, w, h)
     print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
