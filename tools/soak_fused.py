@@ -1,0 +1,39 @@
+"""Soak test of the fused kernel's inter-workgroup hand-off: random batch shapes, two contexts running concurrently
+on private streams (uneven load), every output byte compared with the three-kernel path on the GPU.
+    python tools/soak_fused.py [seconds]"""
+import sys, time, random
+sys.path.insert(0, "opencv-opencl_amd/python"); sys.path.insert(0, ".")
+import torch, mi_lumaeq
+from mi_lumaeq import synth
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+random.seed(7)
+fused_a, fused_b, ref = mi_lumaeq.Context(0), mi_lumaeq.Context(0), mi_lumaeq.Context(0)
+ref.set_option("fused", 0)
+shapes = [(3840, 2160), (1920, 1080), (1280, 720), (640, 360), (256, 64), (3840, 1088), (2560, 1440)]
+t0 = time.time(); launches = frames = mismatches = errors = 0
+while time.time() - t0 < budget:
+    w, h = random.choice(shapes)
+    n = random.choice([1, 2, 3, 5, 8, 13, 32]) if w * h > 2_000_000 else random.choice([1, 7, 64, 200])
+    uv = random.choice([0, 1])
+    dist = random.choice(["D1", "D2", "D3", "D4", "D5"])
+    d_in = synth.nv12_batch_torch(w, h, n, dist, "cuda", seed=random.randrange(1 << 30))
+    want = torch.empty_like(d_in)
+    ref.equalize_hist_nv12_batch_dev(d_in, want, w, h, n, uv)
+    ref.synchronize()
+    outs = []
+    for rep in range(random.choice([1, 3])):
+        oa, ob = torch.zeros_like(d_in), torch.zeros_like(d_in)
+        torch.cuda.synchronize()                 # the private streams below do not order against torch's stream
+        fused_a.equalize_hist_nv12_batch_dev(d_in, oa, w, h, n, uv, stream=mi_lumaeq.STREAM_CTX)
+        fused_b.equalize_hist_nv12_batch_dev(d_in, ob, w, h, n, uv, stream=mi_lumaeq.STREAM_CTX)   # concurrent with a
+        for c in (fused_a, fused_b):
+            try:
+                c.synchronize(mi_lumaeq.STREAM_CTX)
+            except mi_lumaeq.MiError as e:
+                errors += 1; print("ERROR", e, (w, h, n, uv, dist))
+        launches += 2; frames += 2 * n
+        for o in (oa, ob):
+            if not torch.equal(o, want):
+                mismatches += 1; print("MISMATCH", (w, h, n, uv, dist))
+print(f"soak: {launches} fused launches, {frames} frames in {time.time() - t0:.1f} s; mismatches={mismatches} errors={errors}")
+sys.exit(1 if (mismatches or errors) else 0)
