@@ -1,0 +1,29 @@
+#!/usr/bin/env bash
+# Re-creates the files under profiles/ on a GPU box (run from the repo root through gpurun).
+#   tools/collect_profiles.sh <tag>        e.g.  tools/collect_profiles.sh r02_a
+# Counter passes are separate runs with --kernel-trace only (never combined with trace domains), FETCH_SIZE and
+# WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes; the program after `--` is python3 itself.
+set -euo pipefail
+TAG=${1:-rXX}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_$c.err"
+done
+python3 tools/pmc_summary.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$OUT/pmc_summary.json" > /dev/null
+python3 - "$OUT" <<'PY'
+import csv, glob, sys
+out = sys.argv[1]
+rows = list(csv.DictReader(open(glob.glob(out + "/stats/**/*_kernel_stats.csv", recursive=True)[0])))
+with open(out + "/kernel_stats_mi.csv", "w") as f:
+    w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader()
+    for r in rows:
+        if "mi::" in r["Name"]:
+            w.writerow(r)
+print(open(out + "/kernel_stats_mi.csv").read())
+PY
+cat "$OUT/bench_n1.json"
+echo "copy $OUT/{bench_n1.json,kernel_stats_mi.csv,pmc_summary.json} into profiles/ (named per round) and update profiles/traffic.json"
