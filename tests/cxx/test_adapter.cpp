@@ -173,6 +173,23 @@ int main()
             EXPECT(memcmp(out[k].data(), ref.data(), ysz + uvsz) == 0);
         }
     }
+    // --- per-frame error handling of the pool (drop-and-count, OpenCVequalHist.cpp:117/:135/:189): a frame that cannot be
+    //     processed (null buffer) is reported through the sink with ok == false, counted, and the stream goes on in order
+    {
+        const int N = 6;
+        std::vector<std::vector<uint8_t>> in(N, std::vector<uint8_t>(ysz + uvsz)), out(N, std::vector<uint8_t>(ysz + uvsz));
+        for (int k = 0; k < N; ++k) fill(in[k], 300 + k);
+        std::vector<int> oks;
+        {
+            FramePool pool(2, W, H, FramePool::EQUALIZE, UV_FILL128, [&](const FrameJob& j) { oks.push_back(j.ok ? 1 : 0); EXPECT(j.index == oks.size() - 1); });
+            for (int k = 0; k < N; ++k) pool.submit(k == 2 ? nullptr : in[k].data(), out[k].data());
+            pool.finish();
+            EXPECT(pool.stats().processing_errors.load() == 1 && pool.stats().frames_out.load() == (uint64_t)N);
+        }
+        EXPECT(oks.size() == (size_t)N && oks[2] == 0 && oks[0] == 1 && oks[5] == 1);
+        orc_nv12_frame(in[5].data(), ref.data(), W, H, 0, 0, 0.0, 0, 0);
+        EXPECT(memcmp(out[5].data(), ref.data(), ysz + uvsz) == 0);
+    }
     printf(failures ? "test_adapter: %d FAILURES\n" : "test_adapter: all checks passed\n", failures);
     return failures ? 1 : 0;
 }
