@@ -1,0 +1,441 @@
+// capi.inc.hpp -- extern "C": context management, options, profiling, device-resident, stage-level and host-pointer entry points
+// Included by ../mi_lumaeq.hip (one translation unit; not a stand-alone header).
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* mi_version(void) { return "mi_lumaeq 0.1 (gfx950)"; }
+
+const char* mi_status_str(mi_status s)
+{
+    switch (s) {
+        case MI_OK: return "MI_OK";
+        case MI_ERR_BAD_ARG: return "MI_ERR_BAD_ARG";
+        case MI_ERR_UNSUPPORTED: return "MI_ERR_UNSUPPORTED";
+        case MI_ERR_HIP: return "MI_ERR_HIP";
+        case MI_ERR_OOM: return "MI_ERR_OOM";
+        case MI_ERR_NO_DEVICE: return "MI_ERR_NO_DEVICE";
+    }
+    return "MI_ERR_?";
+}
+
+const char* mi_kernel_name(int k)
+{
+    static const char* names[MI_K_COUNT] = {"hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
+                                            "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel"};
+    return (k >= 0 && k < MI_K_COUNT) ? names[k] : "?";
+}
+
+int mi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+mi_status mi_ctx_create(int device, mi_ctx** out)
+{
+    if (!out) return MI_ERR_BAD_ARG;
+    *out = nullptr;
+    const int n = mi_device_count();
+    if (n <= 0 || device < 0 || device >= n) return MI_ERR_NO_DEVICE;
+    mi_ctx* c = new (std::nothrow) mi_ctx();
+    if (!c) return MI_ERR_OOM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return MI_ERR_HIP;
+    }
+    // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount;
+    if (device < kMaxDevices) {
+        if (g_fused_ctx_live[device].fetch_add(1) < kMaxFusedCtxPerDevice) c->fused_slot = true;
+        else g_fused_ctx_live[device].fetch_sub(1);
+    }
+    if (const char* e = getenv("MI_LUMAEQ_FUSED")) c->fused_mode = atoi(e);
+    if (const char* e = getenv("MI_LUMAEQ_FUSED_WGS_PER_CU")) c->fused_wgs_per_cu = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("MI_LUMAEQ_FUSED_VPT")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 20 || v == 24) c->fused_vpt = v; }
+    if (const char* e = getenv("MI_LUMAEQ_FUSED_ACQUIRE")) c->fused_acquire = atoi(e) != 0;
+    *out = c;
+    return MI_OK;
+}
+
+void mi_ctx_destroy(mi_ctx* c)
+{
+    if (!c) return;
+    if (c->fused_slot && c->device >= 0 && c->device < kMaxDevices) g_fused_ctx_live[c->device].fetch_sub(1);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    for (auto e : c->chunk_events) (void)hipEventDestroy(e);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_luts) (void)hipFree(c->d_luts);
+    if (c->d_fused) (void)hipFree(c->d_fused);
+    if (c->d_planes) (void)hipFree(c->d_planes);
+    if (c->d_c16) (void)hipFree(c->d_c16);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->d_stage_in) (void)hipFree(c->d_stage_in);
+    if (c->d_stage_out) (void)hipFree(c->d_stage_out);
+    if (c->h_pin_in) (void)hipHostFree(c->h_pin_in);
+    if (c->h_pin_out) (void)hipHostFree(c->h_pin_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mi_ctx_device(const mi_ctx* c) { return c ? c->device : -1; }
+int mi_ctx_last_hip_error(const mi_ctx* c) { return c ? c->last_hip : 0; }
+const char* mi_ctx_last_error_msg(const mi_ctx* c) { return c ? c->last_msg.c_str() : "null context"; }
+
+mi_status mi_ctx_set_profiling(mi_ctx* c, int enabled)
+{
+    ENTER(c);
+    c->profiling = enabled != 0;
+    return MI_OK;
+}
+
+mi_status mi_ctx_profile_read(mi_ctx* c, mi_profile* out, int reset)
+{
+    ENTER(c);
+    for (auto& p : c->pending) {
+        HIPCHK(c, hipEventSynchronize(p.b));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, p.a, p.b));
+        c->prof.total_ms[p.kernel] += ms;
+        c->prof.launches[p.kernel] += 1;
+        c->free_events.push_back(p.a);
+        c->free_events.push_back(p.b);
+    }
+    c->pending.clear();
+    if (out) *out = c->prof;
+    if (reset) c->prof = mi_profile{};
+    return MI_OK;
+}
+
+mi_status mi_host_register(void* ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0) return MI_ERR_BAD_ARG;
+    if (mi_device_count() <= 0) return MI_ERR_NO_DEVICE;
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinned.push_back({(uintptr_t)ptr, (uintptr_t)ptr + bytes});
+    return MI_OK;
+}
+
+mi_status mi_host_unregister(void* ptr)
+{
+    if (!ptr) return MI_ERR_BAD_ARG;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [&](const PinnedRange& r) { return r.lo == (uintptr_t)ptr; });
+        if (it == g_pinned.end()) return MI_ERR_BAD_ARG;
+        g_pinned.erase(it);
+    }
+    if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return MI_ERR_HIP; }
+    return MI_OK;
+}
+
+mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
+{
+    ENTER(c);
+    if (!name) return fail(c, MI_ERR_BAD_ARG, "null option name");
+    if (!strcmp(name, "fused")) { c->fused_mode = value; return MI_OK; }
+    if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }
+    if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
+    if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
+    if (!strcmp(name, "fused_fault_inject")) { c->fused_fault_inject = value != 0; return MI_OK; }
+    if (!strcmp(name, "fused_timeout_ms")) { c->fused_timeout_ms = std::max(1, value); return MI_OK; }
+    if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
+    return fail(c, MI_ERR_BAD_ARG, "unknown option");
+}
+
+// Waits for `stream` and reports a device-side failure of the fused kernel's bounded waits.
+mi_status mi_ctx_synchronize(mi_ctx* c, void* stream)
+{
+    ENTER(c);
+    hipStream_t s = pick_stream(c, stream);
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (!c->d_fused) return MI_OK;
+    if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
+    HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (*c->h_status != 0) {
+        c->fused_dirty = true;                                   // hand-off block is in an unknown state: zero it before the next launch
+        c->last_hip = 0;
+        return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+    }
+    return MI_OK;
+}
+
+// ---- device-resident batched forms ------------------------------------------------------------------
+mi_status mi_equalize_hist_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                        void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                        int width, int height, int n_frames, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    return equalize_dev(c, pick_stream(c, stream), a, nullptr);
+}
+
+mi_status mi_equalize_hist_nv12_batch_dev(mi_ctx* c, const void* d_in, void* d_out, int width, int height, int n_frames,
+                                          mi_uv_mode uv_mode, void* stream)
+{
+    ENTER(c);
+    if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    const size_t frame = (size_t)width * height + ((size_t)width * height) / 2;
+    PlaneArgs a{(const uint8_t*)d_in, (size_t)width, frame, (uint8_t*)d_out, (size_t)width, frame, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    UVJob uv = nv12_uv((const uint8_t*)d_in, (uint8_t*)d_out, width, height, uv_mode);
+    return equalize_dev(c, pick_stream(c, stream), a, &uv);
+}
+
+mi_status mi_clahe_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    return clahe_dev(c, pick_stream(c, stream), a, clip_limit, tiles_x, tiles_y, nullptr);
+}
+
+mi_status mi_clahe_nv12_batch_dev(mi_ctx* c, const void* d_in, void* d_out, int width, int height, int n_frames,
+                                  mi_uv_mode uv_mode, double clip_limit, int tiles_x, int tiles_y, void* stream)
+{
+    ENTER(c);
+    if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    const size_t frame = (size_t)width * height + ((size_t)width * height) / 2;
+    PlaneArgs a{(const uint8_t*)d_in, (size_t)width, frame, (uint8_t*)d_out, (size_t)width, frame, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    UVJob uv = nv12_uv((const uint8_t*)d_in, (uint8_t*)d_out, width, height, uv_mode);
+    return clahe_dev(c, pick_stream(c, stream), a, clip_limit, tiles_x, tiles_y, &uv);
+}
+
+// ---- stage-level forms ---------------------------------------------------------------------------------
+mi_status mi_hist_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                               int width, int height, int n_frames, void* d_hist, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, nullptr, 0, 0, width, height, n_frames};
+    mi_status st = check_plane(c, a, false);
+    if (st) return st;
+    if (!d_hist) return fail(c, MI_ERR_BAD_ARG, "null d_hist");
+    hipStream_t s = pick_stream(c, stream);
+    if (n_frames == 0) return MI_OK;
+    if (width == 0 || height == 0) { HIPCHK(c, hipMemsetAsync(d_hist, 0, (size_t)n_frames * 1024, s)); return MI_OK; }
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        int nparts = 0;
+        st = launch_hist_partials(c, s, a, f0, nf, &nparts);
+        if (st) return st;
+        LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf), dim3(kThreads), 0,
+               (const uint32_t*)c->d_partial, nparts, 0, (uint8_t*)nullptr, (int32_t*)d_hist + (size_t)f0 * 256);
+    }
+    return MI_OK;
+}
+
+mi_status mi_equalize_lut_batch_dev(mi_ctx* c, const void* d_hist, int64_t total, int n_frames, void* d_lut, void* stream)
+{
+    ENTER(c);
+    if (!d_hist || !d_lut || n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "null pointer / negative count");
+    if (total <= 0 || total > 0x7fffffffLL) return fail(c, MI_ERR_BAD_ARG, "total must be in [1, 2^31)");
+    hipStream_t s = pick_stream(c, stream);
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf), dim3(kThreads), 0,
+               (const uint32_t*)d_hist + (size_t)f0 * 256, 1, (int)total, (uint8_t*)d_lut + (size_t)f0 * 256, (int32_t*)nullptr);
+    }
+    return MI_OK;
+}
+
+mi_status mi_lut_apply_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                    void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                    int width, int height, int n_frames, const void* d_lut, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    if (!d_lut) return fail(c, MI_ERR_BAD_ARG, "null d_lut");
+    hipStream_t s = pick_stream(c, stream);
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        st = launch_apply(c, s, a, f0, nf, (const uint8_t*)d_lut + (size_t)f0 * 256, nullptr);
+        if (st) return st;
+    }
+    return MI_OK;
+}
+
+mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                       int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y,
+                                       void* d_luts, void* stream)
+{
+    ENTER(c);
+    PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, nullptr, 0, 0, width, height, n_frames};
+    mi_status st = check_plane(c, a, false);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    if (!d_luts) return fail(c, MI_ERR_BAD_ARG, "null d_luts");
+    ClaheGeom g;
+    st = clahe_geometry(c, width, height, clip_limit, tiles_x, tiles_y, &g);
+    if (st) return st;
+    hipStream_t s = pick_stream(c, stream);
+    const size_t per_frame = (size_t)tiles_x * tiles_y * 256;
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        st = launch_tile_luts(c, s, a, g, f0, nf, (uint8_t*)d_luts + (size_t)f0 * per_frame);
+        if (st) return st;
+    }
+    return MI_OK;
+}
+
+// ---- host-pointer forms (the cv::Mat boundary) -----------------------------------------------------------
+// Host rows -> pinned staging -> H2D -> kernels -> D2H -> pinned -> host rows, all on the context's
+// stream, synchronous on return.  `nv12_mode` < 0: plain Y plane; otherwise whole NV12 frame.
+static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step,
+                         int width, int height, int nv12_mode, bool is_clahe, double clip_limit, int tiles_x, int tiles_y)
+{
+    const size_t ybytes = (size_t)width * height;
+    const size_t uvbytes = nv12_mode >= 0 ? ybytes / 2 : 0;
+    const bool copy_uv_in = nv12_mode == MI_UV_COPY;
+    const size_t in_bytes = ybytes + (copy_uv_in ? uvbytes : 0);
+    const size_t frame_bytes = ybytes + uvbytes;
+    mi_status st;
+    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, in_bytes))) return st;
+    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, frame_bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, frame_bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, frame_bytes))) return st;
+    hipStream_t s = c->stream;
+    // Caller-pinned, contiguous buffers (mi_host_register) are DMA'd directly; everything else is staged.
+    const bool in_direct = src_step == (size_t)width && host_range_pinned(src, in_bytes);
+    const bool out_direct = dst_step == (size_t)width && host_range_pinned(dst, frame_bytes);
+    // Chunked staging: the host copy of chunk i+1 into pinned memory overlaps the DMA of chunk i (and the other
+    // way round on the way back), so a frame costs ~max(memcpy, PCIe) per direction instead of their sum.
+    const int rows_per_chunk = std::max(1, (int)((size_t)(2u << 20) / (size_t)width));
+    if (in_direct) {
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_in, src, in_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
+            const int nr = std::min(rows_per_chunk, height - y0);
+            const size_t off = (size_t)y0 * width;
+            copy_rows(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
+            HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, s));
+        }
+        if (copy_uv_in) {                                           // tightly packed NV12 (src_step == width)
+            memcpy(c->h_pin_in + ybytes, src + ybytes, uvbytes);
+            HIPCHK(c, hipMemcpyAsync(c->d_stage_in + ybytes, c->h_pin_in + ybytes, uvbytes, hipMemcpyHostToDevice, s));
+        }
+    }
+    PlaneArgs a{c->d_stage_in, (size_t)width, frame_bytes, c->d_stage_out, (size_t)width, frame_bytes, width, height, 1};
+    UVJob uv{};
+    if (nv12_mode >= 0) uv = nv12_uv(c->d_stage_in, c->d_stage_out, width, height, (mi_uv_mode)nv12_mode);
+    st = is_clahe ? clahe_dev(c, s, a, clip_limit, tiles_x, tiles_y, nv12_mode >= 0 ? &uv : nullptr)
+                  : equalize_dev(c, s, a, nv12_mode >= 0 ? &uv : nullptr);
+    if (st) return st;
+    const bool check_status = !is_clahe && c->d_fused;
+    if (check_status) {
+        if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
+        HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    if (out_direct) {
+        HIPCHK(c, hipMemcpyAsync(dst, c->d_stage_out, frame_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (check_status && *c->h_status != 0) {
+            c->fused_dirty = true;
+            return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+        }
+        return MI_OK;
+    }
+    // device -> pinned in chunks, each followed by an event; then drain chunk by chunk into the caller's rows
+    struct Chunk { size_t off, bytes; int y0, nr; };
+    std::vector<Chunk> chunks;
+    for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
+        const int nr = std::min(rows_per_chunk, height - y0);
+        chunks.push_back({(size_t)y0 * width, (size_t)nr * width, y0, nr});
+    }
+    if (uvbytes) chunks.push_back({ybytes, uvbytes, -1, 0});
+    while (c->chunk_events.size() < chunks.size()) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->chunk_events.push_back(e);
+    }
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        HIPCHK(c, hipMemcpyAsync(c->h_pin_out + chunks[i].off, c->d_stage_out + chunks[i].off, chunks[i].bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->chunk_events[i], s));
+    }
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        HIPCHK(c, hipEventSynchronize(c->chunk_events[i]));
+        if (i == 0 && check_status && *c->h_status != 0) {
+            c->fused_dirty = true;
+            (void)hipStreamSynchronize(s);
+            return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+        }
+        if (chunks[i].y0 >= 0)
+            copy_rows(dst + (size_t)chunks[i].y0 * dst_step, dst_step, c->h_pin_out + chunks[i].off, (size_t)width, width, chunks[i].nr);
+        else
+            memcpy(dst + ybytes, c->h_pin_out + ybytes, uvbytes);
+    }
+    return MI_OK;
+}
+
+mi_status mi_equalize_hist_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height)
+{
+    ENTER(c);
+    PlaneArgs a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0) return st;
+    return host_op(c, src, src_step, dst, dst_step, width, height, -1, false, 0.0, 0, 0);
+}
+
+mi_status mi_clahe_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height,
+                      double clip_limit, int tiles_x, int tiles_y)
+{
+    ENTER(c);
+    PlaneArgs a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
+    mi_status st = check_plane(c, a, true);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0) return MI_OK;
+    return host_op(c, src, src_step, dst, dst_step, width, height, -1, true, clip_limit, tiles_x, tiles_y);
+}
+
+mi_status mi_equalize_hist_nv12(mi_ctx* c, const uint8_t* in, uint8_t* out, int width, int height, mi_uv_mode uv_mode)
+{
+    ENTER(c);
+    if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    PlaneArgs a{in, (size_t)std::max(width, 0), 0, out, (size_t)std::max(width, 0), 0, width, height, 1};
+    mi_status st = check_plane(c, a, true);
+    if (st || width == 0 || height == 0) return st;
+    return host_op(c, in, (size_t)width, out, (size_t)width, width, height, (int)uv_mode, false, 0.0, 0, 0);
+}
+
+mi_status mi_clahe_nv12(mi_ctx* c, const uint8_t* in, uint8_t* out, int width, int height, mi_uv_mode uv_mode,
+                        double clip_limit, int tiles_x, int tiles_y)
+{
+    ENTER(c);
+    if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    PlaneArgs a{in, (size_t)std::max(width, 0), 0, out, (size_t)std::max(width, 0), 0, width, height, 1};
+    mi_status st = check_plane(c, a, true);
+    if (st) return st;
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0) return MI_OK;
+    return host_op(c, in, (size_t)width, out, (size_t)width, width, height, (int)uv_mode, true, clip_limit, tiles_x, tiles_y);
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// clahe.inc.hpp -- CLAHE geometry and launch sequence (8-bit)
+// Included by ../mi_lumaeq.hip (one translation unit; not a stand-alone header).
+
+// ---- CLAHE ----------------------------------------------------------------------------------------
+mi_status clahe_geometry(mi_ctx* c, int width, int height, double clip_limit, int tiles_x, int tiles_y, ClaheGeom* g)
+{
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if ((long long)tiles_x * tiles_y > (1 << 20)) return fail(c, MI_ERR_UNSUPPORTED, "tile grid too large");
+    g->width = width; g->height = height; g->tiles_x = tiles_x; g->tiles_y = tiles_y;
+    long long ew = width, eh = height;
+    if (width % tiles_x != 0 || height % tiles_y != 0) {          // clahe.cpp: BOTH pads whenever EITHER is indivisible
+        ew = (long long)width + (tiles_x - width % tiles_x);
+        eh = (long long)height + (tiles_y - height % tiles_y);
+    }
+    g->tile_w = (int)(ew / tiles_x); g->tile_h = (int)(eh / tiles_y);
+    const long long area = (long long)g->tile_w * g->tile_h;
+    if (area > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "tile area must be < 2^31");
+    g->lut_scale = 255.0f / (float)(int)area;
+    int clip = 0;
+    if (clip_limit > 0.0) {
+        clip = (int)(clip_limit * (int)area / 256);                // double math, truncation (clahe.cpp)
+        clip = std::max(clip, 1);
+    }
+    g->clip = clip;
+    g->inv_tw = 1.0f / (float)g->tile_w;
+    g->inv_th = 1.0f / (float)g->tile_h;
+    return MI_OK;
+}
+
+mi_status launch_tile_luts(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const ClaheGeom& g, int f0, int nf, uint8_t* d_luts_out)
+{
+    const int tiles = g.tiles_x * g.tiles_y;
+    // splits per tile: enough workgroups to fill the chip, at least ~8 rows of work each
+    long long want = ((long long)c->cu_count * 8 + (long long)tiles * nf - 1) / ((long long)tiles * nf);
+    int S = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 8), 64LL}));
+    mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * tiles * S * 256 * sizeof(uint32_t));
+    if (st) return st;
+    const uint8_t* src = a.src + (size_t)f0 * a.src_frame;
+    // grid.y = tiles, grid.z = frames
+    if (tiles > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "more than 65535 tiles per frame");
+    LAUNCH(c, s, MI_K_TILE_HIST, tile_hist_kernel, dim3(S, tiles, nf), dim3(kThreads), 0,
+           src, (long long)a.src_step, (long long)a.src_frame, g, c->d_partial);
+    LAUNCH(c, s, MI_K_TILE_LUT, tile_lut_kernel, dim3(tiles, nf), dim3(kThreads), 0,
+           (const uint32_t*)c->d_partial, S, g, d_luts_out);
+    return MI_OK;
+}
+
+mi_status launch_interp(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const ClaheGeom& g, int f0, int nf,
+                        const uint8_t* d_luts, const UVJob* uv_all)
+{
+    PlaneBatch p;
+    p.src = a.src + (size_t)f0 * a.src_frame; p.dst = a.dst + (size_t)f0 * a.dst_frame;
+    p.src_step = (long long)a.src_step; p.dst_step = (long long)a.dst_step;
+    p.src_frame = (long long)a.src_frame; p.dst_frame = (long long)a.dst_frame;
+    p.row_bytes = a.width; p.rows = a.height;
+    UVJob uv{};
+    if (uv_all && uv_all->bytes > 0) {
+        uv = *uv_all;
+        uv.src = uv_all->src ? uv_all->src + (long long)f0 * uv_all->src_frame : nullptr;
+        uv.dst = uv_all->dst + (long long)f0 * uv_all->dst_frame;
+    }
+    const int npairs = g.tiles_x + 1;
+    if (npairs <= kMaxPairsLds) {
+        const int ngroups = (a.width + kInterpPx - 1) / kInterpPx;
+        const int groups = std::min(ngroups, kThreads);
+        const int segs = (ngroups + groups - 1) / groups;
+        const int bands = g.tiles_y + 1;
+        long long want = ((long long)c->cu_count * 8 + (long long)bands * nf * segs - 1) / ((long long)bands * nf * segs);
+        const int rows_per_band = g.tile_h + 2 * kBandMargin;
+        int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, rows_per_band / 8), 64LL}));
+        if ((long long)bands * subs > 0x7fffffffLL || segs > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "image too wide");
+        if (npairs <= kMaxPairsLdsF32 && c->clahe_float_tables)
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_kernel<true>, dim3(bands * subs, nf, segs), dim3(kThreads),
+                   (size_t)npairs * 256 * 4 * sizeof(float), p, g, d_luts, subs, groups, uv);
+        else
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_kernel<false>, dim3(bands * subs, nf, segs), dim3(kThreads),
+                   (size_t)npairs * 256 * sizeof(uint32_t), p, g, d_luts, subs, groups, uv);
+    } else {
+        if (a.height > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "height > 65535 with tiles_x > 62");
+        LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_global_kernel,
+               dim3((a.width + kThreads - 1) / kThreads, a.height, nf), dim3(kThreads), 0, p, g, d_luts);
+        if (uv.bytes > 0) {
+            const int B = blocks_per_frame(c, uv.bytes, 1, nf, 2048);
+            LAUNCH(c, s, MI_K_LUT_APPLY, uv_kernel, dim3(B, nf), dim3(kThreads), 0, uv);
+        }
+    }
+    return MI_OK;
+}
+
+mi_status clahe_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, double clip_limit, int tiles_x, int tiles_y, const UVJob* uv)
+{
+    ClaheGeom g;
+    mi_status st = clahe_geometry(c, a.width, a.height, clip_limit, tiles_x, tiles_y, &g);
+    if (st) return st;
+    const int tiles = tiles_x * tiles_y;
+    const int chunk = std::min(kMaxGridY, 65535);
+    for (int f0 = 0; f0 < a.n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, a.n_frames - f0);
+        st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * tiles * 256);
+        if (st) return st;
+        st = launch_tile_luts(c, s, a, g, f0, nf, c->d_luts);
+        if (st) return st;
+        st = launch_interp(c, s, a, g, f0, nf, c->d_luts, uv);
+        if (st) return st;
+    }
+    return MI_OK;
+}

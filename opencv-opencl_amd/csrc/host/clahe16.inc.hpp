@@ -1,0 +1,89 @@
+// clahe16.inc.hpp -- CLAHE on CV_16UC1: launcher + extern "C" entry points
+// Included by ../mi_lumaeq.hip (one translation unit; not a stand-alone header).
+
+// ---- CLAHE on CV_16UC1 ----------------------------------------------------------------------
+namespace {
+
+mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_step, size_t src_frame, uint8_t* dst, size_t dst_step,
+                      size_t dst_frame, int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y)
+{
+    ClaheGeom g;
+    mi_status st = clahe_geometry(c, width, height, clip_limit, tiles_x, tiles_y, &g);
+    if (st) return st;
+    const int tiles = tiles_x * tiles_y;
+    if (tiles > kMaxGridY || height > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "16-bit CLAHE: more than 65535 tiles or rows");
+    const long long area = (long long)g.tile_w * g.tile_h;
+    const float lut_scale16 = 65535.0f / (float)(int)area;
+    int clip16 = 0;
+    if (clip_limit > 0.0) { clip16 = (int)(clip_limit * (int)area / 65536); clip16 = std::max(clip16, 1); }
+    // scratch per frame: tile histograms (u32) + ushort LUTs; frames are processed in chunks that keep it <= ~256 MiB
+    const size_t per_frame = (size_t)tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t));
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)256 << 20) / per_frame));
+    st = grow_dev(c, &c->d_c16, &c->c16_bytes, per_frame * (size_t)chunk);
+    if (st) return st;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, n_frames - f0);
+        uint32_t* hist = reinterpret_cast<uint32_t*>(c->d_c16);
+        uint16_t* luts = reinterpret_cast<uint16_t*>(c->d_c16 + (size_t)nf * tiles * kHist16 * sizeof(uint32_t));
+        LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
+               src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist);
+        LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, g, lut_scale16, clip16, luts);
+        LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
+               src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
+               dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts);
+    }
+    return MI_OK;
+}
+
+mi_status check_u16(mi_ctx* c, const void* src, size_t src_step, const void* dst, size_t dst_step, int width, int height, int n_frames,
+                    int tiles_x, int tiles_y)
+{
+    if (width < 0 || height < 0 || n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "negative size");
+    if (tiles_x <= 0 || tiles_y <= 0) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    if (!src || !dst) return fail(c, MI_ERR_BAD_ARG, "null plane pointer");
+    if (src_step < (size_t)width * 2 || dst_step < (size_t)width * 2) return fail(c, MI_ERR_BAD_ARG, "step < 2*width");
+    if ((src_step | dst_step | (uintptr_t)src | (uintptr_t)dst) & 1) return fail(c, MI_ERR_BAD_ARG, "16-bit planes must be 2-byte aligned");
+    if ((long long)width * height > 0x3fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "image too large");
+    if (width > (1 << 24) || height > (1 << 24)) return fail(c, MI_ERR_UNSUPPORTED, "width/height must be <= 2^24");
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+mi_status mi_clahe_u16_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                 void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                 int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y, void* stream)
+{
+    ENTER(c);
+    mi_status st = check_u16(c, d_src, src_step, d_dst, dst_step, width, height, n_frames, tiles_x, tiles_y);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    return clahe16_dev(c, pick_stream(c, stream), (const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride,
+                       width, height, n_frames, clip_limit, tiles_x, tiles_y);
+}
+
+mi_status mi_clahe_u16(mi_ctx* c, const uint16_t* src, size_t src_step, uint16_t* dst, size_t dst_step, int width, int height,
+                       double clip_limit, int tiles_x, int tiles_y)
+{
+    ENTER(c);
+    mi_status st = check_u16(c, src, src_step, dst, dst_step, width, height, 1, tiles_x, tiles_y);
+    if (st || width == 0 || height == 0) return st;
+    const size_t row = (size_t)width * 2, bytes = row * height;
+    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, bytes))) return st;
+    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
+    hipStream_t s = c->stream;
+    for (int y = 0; y < height; ++y) memcpy(c->h_pin_in + (size_t)y * row, (const uint8_t*)src + (size_t)y * src_step, row);
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, c->h_pin_in, bytes, hipMemcpyHostToDevice, s));
+    st = clahe16_dev(c, s, c->d_stage_in, row, bytes, c->d_stage_out, row, bytes, width, height, 1, clip_limit, tiles_x, tiles_y);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int y = 0; y < height; ++y) memcpy((uint8_t*)dst + (size_t)y * dst_step, c->h_pin_out + (size_t)y * row, row);
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// color.inc.hpp -- colour-domain neighbours: launchers + extern "C" entry points
+// Included by ../mi_lumaeq.hip (one translation unit; not a stand-alone header).
+
+// ---- colour-domain neighbours ---------------------------------------------------------------
+namespace {
+
+struct Color3Args {
+    const uint8_t* src; size_t src_step, src_frame;
+    uint8_t* dst; size_t dst_step, dst_frame;
+    int width, height, n_frames;
+};
+
+mi_status check_color3(mi_ctx* c, const Color3Args& a)
+{
+    if (a.width < 0 || a.height < 0 || a.n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "negative size");
+    if (a.width == 0 || a.height == 0 || a.n_frames == 0) return MI_OK;
+    if (!a.src || !a.dst) return fail(c, MI_ERR_BAD_ARG, "null image pointer");
+    if (a.src_step < (size_t)a.width * 3 || a.dst_step < (size_t)a.width * 3) return fail(c, MI_ERR_BAD_ARG, "step < 3*width");
+    if ((long long)a.width * a.height > 0x7fffffffLL / 3) return fail(c, MI_ERR_UNSUPPORTED, "image too large");
+    return MI_OK;
+}
+
+template <int MODE>
+mi_status launch_color(mi_ctx* c, hipStream_t s, ColorJob j, int n_frames)
+{
+    const long long px = j.row_px * (long long)j.rows;
+    const int gy = std::min(j.rows, 65535);
+    long long bx = ((long long)c->cu_count * 8 + (long long)gy * n_frames - 1) / ((long long)gy * n_frames);
+    bx = std::max<long long>(1, std::min<long long>(bx, (j.row_px / 16 + kThreads - 1) / kThreads + 1));
+    (void)px;
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        ColorJob q = j;
+        if (q.src) q.src += (long long)f0 * j.src_frame;
+        if (q.dst) q.dst += (long long)f0 * j.dst_frame;
+        if (q.p0) { q.p0 += (long long)f0 * j.plane_frame; q.p1 += (long long)f0 * j.plane_frame; q.p2 += (long long)f0 * j.plane_frame; }
+        LAUNCH(c, s, MI_K_COLOR, color_kernel<MODE>, dim3((unsigned)bx, gy, nf), dim3(kThreads), 0, q);
+    }
+    return MI_OK;
+}
+
+ColorJob color_job(const Color3Args& a)
+{
+    ColorJob j{};
+    j.src = a.src; j.dst = a.dst;
+    j.src_frame = (long long)a.src_frame; j.dst_frame = (long long)a.dst_frame;
+    const bool contiguous = (!a.src || a.src_step == (size_t)a.width * 3) && (!a.dst || a.dst_step == (size_t)a.width * 3);
+    if (contiguous || a.height == 1) { j.rows = 1; j.row_px = (long long)a.width * a.height; j.src_step = j.dst_step = j.row_px * 3; }
+    else { j.rows = a.height; j.row_px = a.width; j.src_step = (long long)a.src_step; j.dst_step = (long long)a.dst_step; }
+    return j;
+}
+
+mi_status cvt_color_dev(mi_ctx* c, hipStream_t s, const Color3Args& a, int code)
+{
+    ColorJob j = color_job(a);
+    if (code == MI_COLOR_BGR2YUV) return launch_color<0>(c, s, j, a.n_frames);
+    if (code == MI_COLOR_YUV2BGR) return launch_color<1>(c, s, j, a.n_frames);
+    return fail(c, MI_ERR_UNSUPPORTED, "colour code must be MI_COLOR_BGR2YUV (82) or MI_COLOR_YUV2BGR (84)");
+}
+
+mi_status bgr_luma_dev(mi_ctx* c, hipStream_t s, const Color3Args& a, int op, double clip, int tx, int ty)
+{
+    if (op != MI_OP_EQUALIZE && op != MI_OP_CLAHE) return fail(c, MI_ERR_BAD_ARG, "op must be MI_OP_EQUALIZE or MI_OP_CLAHE");
+    if (op == MI_OP_CLAHE && (tx <= 0 || ty <= 0)) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    const size_t plane = ((size_t)a.width * a.height + 15) & ~(size_t)15;           // keep every plane 16-B aligned
+    const size_t per_frame = plane * 4;                                             // Y, U, V, Y'
+    mi_status st = grow_dev(c, &c->d_planes, &c->planes_bytes, per_frame * (size_t)a.n_frames);
+    if (st) return st;
+    uint8_t* Y = c->d_planes; uint8_t* U = Y + plane; uint8_t* V = U + plane; uint8_t* Y2 = V + plane;
+    // cvtColor(BGR2YUV) + split
+    Color3Args in = a; in.dst = nullptr;
+    ColorJob j = color_job(in);
+    j.dst = nullptr; j.p0 = Y; j.p1 = U; j.p2 = V; j.plane_frame = (long long)per_frame;
+    // planes are written tightly (row pitch = width), so plane offsets use row*width even for strided sources
+    if ((st = launch_color<2>(c, s, j, a.n_frames))) return st;
+    // the luma op on the Y planes
+    PlaneArgs pa{Y, (size_t)a.width, per_frame, Y2, (size_t)a.width, per_frame, a.width, a.height, a.n_frames};
+    st = op == MI_OP_EQUALIZE ? equalize_dev(c, s, pa, nullptr) : clahe_dev(c, s, pa, clip, tx, ty, nullptr);
+    if (st) return st;
+    // merge + cvtColor(YUV2BGR)
+    Color3Args out = a; out.src = nullptr;
+    ColorJob k = color_job(out);
+    k.src = nullptr; k.p0 = Y2; k.p1 = U; k.p2 = V; k.plane_frame = (long long)per_frame;
+    return launch_color<3>(c, s, k, a.n_frames);
+}
+
+// host images staged like host_op(): rows -> pinned -> device (tight) -> op -> pinned -> rows
+mi_status color_host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height,
+                        bool luma, int code_or_op, double clip, int tx, int ty)
+{
+    const size_t row = (size_t)width * 3, bytes = row * height;
+    mi_status st;
+    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, bytes))) return st;
+    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
+    hipStream_t s = c->stream;
+    for (int y = 0; y < height; ++y) memcpy(c->h_pin_in + (size_t)y * row, src + (size_t)y * src_step, row);
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, c->h_pin_in, bytes, hipMemcpyHostToDevice, s));
+    Color3Args a{c->d_stage_in, row, bytes, c->d_stage_out, row, bytes, width, height, 1};
+    st = luma ? bgr_luma_dev(c, s, a, code_or_op, clip, tx, ty) : cvt_color_dev(c, s, a, code_or_op);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * dst_step, c->h_pin_out + (size_t)y * row, row);
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+mi_status mi_cvt_color_u8c3_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                      void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                      int width, int height, int n_frames, int code, void* stream)
+{
+    ENTER(c);
+    Color3Args a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
+    mi_status st = check_color3(c, a);
+    if (st) return st;
+    if (code != MI_COLOR_BGR2YUV && code != MI_COLOR_YUV2BGR) return fail(c, MI_ERR_UNSUPPORTED, "colour code must be 82 (BGR2YUV) or 84 (YUV2BGR)");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    return cvt_color_dev(c, pick_stream(c, stream), a, code);
+}
+
+mi_status mi_bgr_luma_op_u8c3_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                        void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                        int width, int height, int n_frames, int op, double clip_limit, int tiles_x, int tiles_y, void* stream)
+{
+    ENTER(c);
+    Color3Args a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
+    mi_status st = check_color3(c, a);
+    if (st) return st;
+    if (op != MI_OP_EQUALIZE && op != MI_OP_CLAHE) return fail(c, MI_ERR_BAD_ARG, "op must be MI_OP_EQUALIZE or MI_OP_CLAHE");
+    if (op == MI_OP_CLAHE && (tiles_x <= 0 || tiles_y <= 0)) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    return bgr_luma_dev(c, pick_stream(c, stream), a, op, clip_limit, tiles_x, tiles_y);
+}
+
+mi_status mi_cvt_color_u8c3(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height, int code)
+{
+    ENTER(c);
+    Color3Args a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
+    mi_status st = check_color3(c, a);
+    if (st) return st;
+    if (code != MI_COLOR_BGR2YUV && code != MI_COLOR_YUV2BGR) return fail(c, MI_ERR_UNSUPPORTED, "colour code must be 82 (BGR2YUV) or 84 (YUV2BGR)");
+    if (width == 0 || height == 0) return MI_OK;
+    return color_host_op(c, src, src_step, dst, dst_step, width, height, false, code, 0.0, 0, 0);
+}
+
+mi_status mi_bgr_luma_op_u8c3(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height,
+                              int op, double clip_limit, int tiles_x, int tiles_y)
+{
+    ENTER(c);
+    Color3Args a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
+    mi_status st = check_color3(c, a);
+    if (st) return st;
+    if (op != MI_OP_EQUALIZE && op != MI_OP_CLAHE) return fail(c, MI_ERR_BAD_ARG, "op must be MI_OP_EQUALIZE or MI_OP_CLAHE");
+    if (op == MI_OP_CLAHE && (tiles_x <= 0 || tiles_y <= 0)) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (width == 0 || height == 0) return MI_OK;
+    return color_host_op(c, src, src_step, dst, dst_step, width, height, true, op, clip_limit, tiles_x, tiles_y);
+}
+
+}  // extern "C"

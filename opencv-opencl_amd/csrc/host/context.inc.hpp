@@ -1,0 +1,232 @@
+// context.inc.hpp -- mi_ctx, error helpers, scratch growth, kernel launch bracket, grid heuristics, stage launchers (K1-K3)
+// Included by ../mi_lumaeq.hip (one translation unit; not a stand-alone header).
+
+namespace {
+
+struct PendingEvent { hipEvent_t a, b; int kernel; };
+
+}  // namespace
+
+// Concurrency guard for the fused kernel.  Its workgroups wait for each other, so every slice of a frame (T
+// workgroups) must be co-resident.  Several contexts may run fused launches on one GPU at the same time (the
+// worker pool does); each launch is then only guaranteed a share of the chip.  At most kMaxFusedCtxPerDevice live
+// contexts per device get the fused path (later ones use the three-kernel path), and a frame is only fused when
+// T <= (CUs * WGs/CU) / (2 * kMaxFusedCtxPerDevice), i.e. a launch that receives half of its fair share still
+// has all of a frame's slices resident.  (Other processes on the GPU are covered by the bounded waits.)
+// process-wide registry of caller-pinned host ranges (mi_host_register)
+struct PinnedRange { uintptr_t lo, hi; };
+static std::mutex g_pin_mu;
+static std::vector<PinnedRange> g_pinned;
+static bool host_range_pinned(const void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return false;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const auto& r : g_pinned) if (lo >= r.lo && hi <= r.hi) return true;
+    return false;
+}
+
+constexpr int kMaxDevices = 64;
+constexpr int kMaxFusedCtxPerDevice = 4;
+static std::atomic<int> g_fused_ctx_live[kMaxDevices];
+
+struct mi_ctx {
+    int device = -1;
+    bool fused_slot = false;                                     // this context holds one of the per-device fused slots
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    int last_hip = 0;
+    std::string last_msg = "ok";
+    int cu_count = 256;
+
+    // device scratch, grown lazily ("allocate once per size", OpenCLequalHist.cpp:175-186)
+    uint32_t* d_partial = nullptr; size_t partial_bytes = 0;     // histogram partials
+    uint8_t*  d_luts = nullptr;    size_t luts_bytes = 0;        // per-frame / per-tile LUTs
+    uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (self-cleaning)
+    size_t fused_cap = 0;                                        // frames the block is laid out for
+    unsigned long long fused_work_base = 0;                      // value of the device ticket counter at the next launch
+    uint32_t fused_epoch = 0;
+    bool fused_dirty = true;                                     // block must be zeroed before the next launch
+    bool fused_capture_safe = false;                             // set once a call was seen inside a stream capture (hipGraph):
+                                                                 // from then on every launch zeroes the block itself and uses
+                                                                 // constant epoch / ticket base, so a captured graph can be replayed
+    uint32_t* h_status = nullptr;                                // pinned mirror of the device status word
+    int fused_mode = 1;                                          // MI_LUMAEQ_FUSED=0 forces the 3-kernel path
+    int fused_wgs_per_cu = 4;                                    // MI_LUMAEQ_FUSED_WGS_PER_CU
+    int fused_vpt = kVPT;                                        // MI_LUMAEQ_FUSED_VPT (8, 16, 20, 24)
+    int fused_acquire = 1;                                       // MI_LUMAEQ_FUSED_ACQUIRE
+    int fused_fault_inject = 0;                                  // test hook (option "fused_fault_inject")
+    int fused_timeout_ms = 2000;                                 // option "fused_timeout_ms"
+    int clahe_float_tables = 1;                                  // option "clahe_float_tables": f32 pair tables in LDS (tiles_x <= 14)
+    uint8_t*  d_stage_in = nullptr;  size_t stage_in_bytes = 0;  // device frame for the host-pointer forms
+    uint8_t*  d_stage_out = nullptr; size_t stage_out_bytes = 0;
+    uint8_t*  d_c16 = nullptr;     size_t c16_bytes = 0;         // 16-bit CLAHE: tile histograms + ushort LUTs (N4)
+    uint8_t*  d_planes = nullptr;  size_t planes_bytes = 0;      // Y,U,V,Y' planes of the BGR luma pipeline (N3)
+    uint8_t*  h_pin_in = nullptr;  size_t pin_in_bytes = 0;      // pinned staging
+    uint8_t*  h_pin_out = nullptr; size_t pin_out_bytes = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> free_events;
+    std::vector<hipEvent_t> chunk_events;                        // D2H chunk completion (host-pointer forms)
+    mi_profile prof{};
+};
+
+namespace {
+
+mi_status fail_hip(mi_ctx* c, hipError_t e, const char* what)
+{
+    c->last_hip = (int)e;
+    c->last_msg = std::string(what) + ": " + hipGetErrorString(e);
+    return MI_ERR_HIP;
+}
+mi_status fail(mi_ctx* c, mi_status s, const char* msg)
+{
+    if (c) c->last_msg = msg;
+    return s;
+}
+
+#define HIPCHK(c, expr)                                         \
+    do {                                                        \
+        hipError_t e__ = (expr);                                \
+        if (e__ != hipSuccess) return fail_hip((c), e__, #expr); \
+    } while (0)
+
+template <class T>
+mi_status grow_dev(mi_ctx* c, T** p, size_t* have, size_t need)
+{
+    if (need <= *have) return MI_OK;
+    if (*p) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(*p)); *p = nullptr; *have = 0; }   // rare: scratch may be in use on a caller stream
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, need);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(c, MI_ERR_OOM, "device allocation failed"); }
+    if (e != hipSuccess) return fail_hip(c, e, "hipMalloc");
+    *p = (T*)q; *have = need;
+    return MI_OK;
+}
+
+mi_status grow_pinned(mi_ctx* c, uint8_t** p, size_t* have, size_t need)
+{
+    if (need <= *have) return MI_OK;
+    if (*p) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipHostFree(*p)); *p = nullptr; *have = 0; }
+    void* q = nullptr;
+    hipError_t e = hipHostMalloc(&q, need, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(c, MI_ERR_OOM, "pinned allocation failed"); }
+    if (e != hipSuccess) return fail_hip(c, e, "hipHostMalloc");
+    *p = (uint8_t*)q; *have = need;
+    return MI_OK;
+}
+
+// ---- kernel launch with optional event bracketing ---------------------------------------------
+struct Bracket {
+    mi_ctx* c; hipStream_t s; int kernel; hipEvent_t a = nullptr, b = nullptr; bool on;
+    Bracket(mi_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kernel(k), on(c_->profiling) {}
+    hipError_t begin()
+    {
+        if (!on) return hipSuccess;
+        for (hipEvent_t* e : {&a, &b}) {
+            if (!c->free_events.empty()) { *e = c->free_events.back(); c->free_events.pop_back(); }
+            else { hipError_t r = hipEventCreate(e); if (r != hipSuccess) return r; }
+        }
+        return hipEventRecord(a, s);
+    }
+    hipError_t end()
+    {
+        if (!on) return hipSuccess;
+        hipError_t r = hipEventRecord(b, s);
+        c->pending.push_back({a, b, kernel});
+        return r;
+    }
+};
+
+#define LAUNCH(c, s, kid, kern, grid, block, shmem, ...)                          \
+    do {                                                                          \
+        Bracket br__((c), (s), (kid));                                            \
+        HIPCHK((c), br__.begin());                                                \
+        hipLaunchKernelGGL(kern, grid, block, shmem, (s), __VA_ARGS__);           \
+        HIPCHK((c), hipGetLastError());                                           \
+        HIPCHK((c), br__.end());                                                  \
+    } while (0)
+
+// ---- geometry / grid heuristics -----------------------------------------------------------------
+// Memory-bound kernels: aim for ~8 workgroups per CU in total, never less than 16 KiB per workgroup
+// (a workgroup pays 64 LDS wave-ops to zero and fold its replicated histogram / LUT).
+int blocks_per_frame(const mi_ctx* c, long long bytes_per_frame, int rows, int n_frames, int cap)
+{
+    const long long target = (long long)c->cu_count * 8;
+    long long b = (target + n_frames - 1) / n_frames;
+    const long long by_bytes = std::max<long long>(1, bytes_per_frame / 16384);
+    b = std::min(b, by_bytes);
+    if (rows > 1) b = std::min<long long>(b, rows);
+    b = std::min<long long>(b, cap);
+    return (int)std::max<long long>(1, b);
+}
+
+struct PlaneArgs {
+    const uint8_t* src; size_t src_step, src_frame;
+    uint8_t* dst; size_t dst_step, dst_frame;
+    int width, height, n_frames;
+};
+
+mi_status check_plane(mi_ctx* c, const PlaneArgs& a, bool need_dst)
+{
+    if (!c) return MI_ERR_BAD_ARG;
+    if (a.width < 0 || a.height < 0 || a.n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "negative size");
+    if (a.width == 0 || a.height == 0 || a.n_frames == 0) return MI_OK;
+    if (!a.src || (need_dst && !a.dst)) return fail(c, MI_ERR_BAD_ARG, "null plane pointer");
+    if (a.src_step < (size_t)a.width || (need_dst && a.dst_step < (size_t)a.width)) return fail(c, MI_ERR_BAD_ARG, "step < width");
+    if ((long long)a.width * a.height > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "width*height must be < 2^31 (OpenCV: int total)");
+    if (a.width > (1 << 24) || a.height > (1 << 24)) return fail(c, MI_ERR_UNSUPPORTED, "width/height must be <= 2^24");
+    return MI_OK;
+}
+
+PlaneBatch make_plane(const PlaneArgs& a)
+{
+    PlaneBatch p;
+    p.src = a.src; p.dst = a.dst;
+    p.src_frame = (long long)a.src_frame; p.dst_frame = (long long)a.dst_frame;
+    const bool contiguous = a.src_step == (size_t)a.width && (!a.dst || a.dst_step == (size_t)a.width);
+    if (contiguous || a.height == 1) {
+        p.rows = 1; p.row_bytes = (long long)a.width * a.height;
+        p.src_step = p.row_bytes; p.dst_step = p.row_bytes;
+    } else {
+        p.rows = a.height; p.row_bytes = a.width;
+        p.src_step = (long long)a.src_step; p.dst_step = (long long)a.dst_step;
+    }
+    return p;
+}
+
+constexpr int kMaxGridY = 65535;
+
+// ---- stage launchers (all assume ctx lock held, device set) -------------------------------------
+mi_status launch_hist_partials(mi_ctx* c, hipStream_t s, const PlaneArgs& a, int f0, int nf, int* nparts_out)
+{
+    PlaneArgs b = a;
+    b.src = a.src + (size_t)f0 * a.src_frame; b.dst = nullptr; b.n_frames = nf;
+    PlaneBatch p = make_plane(b);
+    const int B = blocks_per_frame(c, (long long)a.width * a.height, p.rows, nf, 256);
+    mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * B * 256 * sizeof(uint32_t));
+    if (st) return st;
+    LAUNCH(c, s, MI_K_HIST, hist_partial_kernel, dim3(B, nf), dim3(kThreads), 0, p, c->d_partial);
+    *nparts_out = B;
+    return MI_OK;
+}
+
+mi_status launch_apply(mi_ctx* c, hipStream_t s, const PlaneArgs& a, int f0, int nf, const uint8_t* d_luts, const UVJob* uv_all)
+{
+    PlaneArgs b = a;
+    b.src = a.src + (size_t)f0 * a.src_frame; b.dst = a.dst + (size_t)f0 * a.dst_frame; b.n_frames = nf;
+    PlaneBatch p = make_plane(b);
+    UVJob uv{};
+    long long bytes = (long long)a.width * a.height * 2;
+    if (uv_all && uv_all->bytes > 0) {
+        uv = *uv_all;
+        uv.src = uv_all->src ? uv_all->src + (long long)f0 * uv_all->src_frame : nullptr;
+        uv.dst = uv_all->dst + (long long)f0 * uv_all->dst_frame;
+        bytes += uv.bytes * (uv.mode ? 2 : 1);
+    }
+    const int B = blocks_per_frame(c, bytes / 2, p.rows, nf, 2048);
+    LAUNCH(c, s, MI_K_LUT_APPLY, lut_apply_kernel, dim3(B, nf), dim3(kThreads), 0, p, d_luts, uv);
+    return MI_OK;
+}
