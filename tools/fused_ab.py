@@ -1,9 +1,9 @@
-"""A/B of a fused-kernel option in one process (interleaved rounds): python tools/fused_ab.py <option> [uv]"""
+"""A/B of a fused-kernel option in one process (interleaved rounds): python tools/fused_ab.py <option> [modes e.g. 0,1]"""
 import sys, time, torch
 sys.path.insert(0, "opencv-opencl_amd/python"); sys.path.insert(0, ".")
 import mi_lumaeq
 from mi_lumaeq import synth
-opt = sys.argv[1] if len(sys.argv) > 1 else "fused_uv_last"
+opt = sys.argv[1] if len(sys.argv) > 1 else "fused_acquire"
 MODES = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
 a = mi_lumaeq.Context(0)
 for (w, h, B, uv) in ((3840, 2160, 64, 0), (3840, 2160, 64, 1), (3840, 2160, 8, 0), (1920, 1080, 256, 0), (3840, 2160, 1, 0)):
