@@ -151,6 +151,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
     if (!strcmp(name, "fused_fault_inject")) { c->fused_fault_inject = value != 0; return MI_OK; }
     if (!strcmp(name, "fused_timeout_ms")) { c->fused_timeout_ms = std::max(1, value); return MI_OK; }
+    if (!strcmp(name, "bgr_fused")) { c->bgr_fused = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
     return fail(c, MI_ERR_BAD_ARG, "unknown option");
 }

@@ -62,6 +62,25 @@ mi_status bgr_luma_dev(mi_ctx* c, hipStream_t s, const Color3Args& a, int op, do
 {
     if (op != MI_OP_EQUALIZE && op != MI_OP_CLAHE) return fail(c, MI_ERR_BAD_ARG, "op must be MI_OP_EQUALIZE or MI_OP_CLAHE");
     if (op == MI_OP_CLAHE && (tx <= 0 || ty <= 0)) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (op == MI_OP_EQUALIZE && c->bgr_fused) {
+        // two passes over the interleaved image (9 B/px): Y histogram on the fly, then convert + LUT + convert back
+        ColorJob j = color_job(a);
+        for (int f0 = 0; f0 < a.n_frames; f0 += kMaxGridY) {
+            const int nf = std::min(kMaxGridY, a.n_frames - f0);
+            ColorJob q = j;
+            q.src += (long long)f0 * j.src_frame; q.dst += (long long)f0 * j.dst_frame;
+            const int B = blocks_per_frame(c, (long long)a.width * a.height * 3, 1, nf, 256);
+            mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * B * 256 * sizeof(uint32_t));
+            if (st) return st;
+            if ((st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * 256))) return st;
+            LAUNCH(c, s, MI_K_COLOR, bgr_luma_hist_kernel, dim3(B, 1, nf), dim3(kThreads), 0, q, c->d_partial);
+            LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf), dim3(kThreads), 0,
+                   (const uint32_t*)c->d_partial, B, (int)((long long)a.width * a.height), c->d_luts, (int32_t*)nullptr);
+            const int B2 = blocks_per_frame(c, (long long)a.width * a.height * 3, 1, nf, 2048);
+            LAUNCH(c, s, MI_K_COLOR, bgr_luma_apply_kernel, dim3(B2, 1, nf), dim3(kThreads), 0, q, (const uint8_t*)c->d_luts);
+        }
+        return MI_OK;
+    }
     const size_t plane = ((size_t)a.width * a.height + 15) & ~(size_t)15;           // keep every plane 16-B aligned
     const size_t per_frame = plane * 4;                                             // Y, U, V, Y'
     mi_status st = grow_dev(c, &c->d_planes, &c->planes_bytes, per_frame * (size_t)a.n_frames);

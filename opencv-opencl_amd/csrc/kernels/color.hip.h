@@ -125,4 +125,96 @@ __global__ __launch_bounds__(kThreads) void color_kernel(ColorJob j)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused BGR luma equalization (singlecolor.cpp:39-66 in two passes over the interleaved image, 9 B/px instead of the
+// 14 B/px of the planar pipeline): pass 1 converts on the fly and histograms Y; pass 2 converts, maps Y through the
+// frame's LUT and converts back.  Same arithmetic per pixel as cvtColor -> split -> equalizeHist -> merge -> cvtColor
+// (U and V are the saturated 8-bit values the reference would have stored in between).
+// grid = (B, 1, n_frames); every workgroup walks its share of the 16-pixel groups of every row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_bgr16(const uint8_t* p, uint32_t* c0, uint32_t* c1, uint32_t* c2)
+{
+    const u32x4* sp = reinterpret_cast<const u32x4*>(p);
+    const u32x4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+    const uint32_t w[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+    for (int px = 0; px < 16; ++px) {
+        c0[px] = (w[(3 * px) >> 2] >> (8 * ((3 * px) & 3))) & 0xffu;
+        c1[px] = (w[(3 * px + 1) >> 2] >> (8 * ((3 * px + 1) & 3))) & 0xffu;
+        c2[px] = (w[(3 * px + 2) >> 2] >> (8 * ((3 * px + 2) & 3))) & 0xffu;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bgr_luma_hist_kernel(ColorJob j, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[256 * kCopies];
+    lds_hist_zero(h);
+    const int f = blockIdx.z, t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    for (int row = 0; row < j.rows; ++row) {
+        const uint8_t* s3 = j.src + (long long)f * j.src_frame + (long long)row * j.src_step;
+        const long long groups = (((uintptr_t)s3 & 15) == 0) ? (j.row_px >> 4) : 0;
+        for (long long gidx = (long long)blockIdx.x * kThreads + t; gidx < groups; gidx += (long long)gridDim.x * kThreads) {
+            uint32_t c0[16], c1[16], c2[16];
+            load_bgr16(s3 + gidx * 48, c0, c1, c2);
+#pragma unroll
+            for (int px = 0; px < 16; ++px) {
+                uint32_t Y, U, V;
+                px_bgr2yuv(c0[px], c1[px], c2[px], Y, U, V);
+                lds_inc(h, (Y << kCopyShift) + copy);
+            }
+        }
+        for (long long x = (groups << 4) + (long long)blockIdx.x * kThreads + t; x < j.row_px; x += (long long)gridDim.x * kThreads) {
+            uint32_t Y, U, V;
+            px_bgr2yuv(s3[3 * x], s3[3 * x + 1], s3[3 * x + 2], Y, U, V);
+            lds_inc(h, (Y << kCopyShift) + copy);
+        }
+    }
+    __syncthreads();
+    partial[((size_t)f * gridDim.x + blockIdx.x) * 256 + t] = lds_hist_bin(h, t);
+}
+
+__global__ __launch_bounds__(kThreads) void bgr_luma_apply_kernel(ColorJob j, const uint8_t* __restrict__ luts)
+{
+    __shared__ uint32_t lut[256 * kCopies];
+    const int f = blockIdx.z, t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    {
+        const uint32_t v = luts[(size_t)f * 256 + t];
+#pragma unroll
+        for (int k = 0; k < kCopies; ++k) lut[(t << kCopyShift) + ((k + t) & (kCopies - 1))] = v;
+    }
+    __syncthreads();
+    for (int row = 0; row < j.rows; ++row) {
+        const uint8_t* s3 = j.src + (long long)f * j.src_frame + (long long)row * j.src_step;
+        uint8_t* d3 = j.dst + (long long)f * j.dst_frame + (long long)row * j.dst_step;
+        const long long groups = ((((uintptr_t)s3 | (uintptr_t)d3) & 15) == 0) ? (j.row_px >> 4) : 0;
+        for (long long gidx = (long long)blockIdx.x * kThreads + t; gidx < groups; gidx += (long long)gridDim.x * kThreads) {
+            uint32_t c0[16], c1[16], c2[16];
+            load_bgr16(s3 + gidx * 48, c0, c1, c2);
+            uint32_t w[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) w[k] = 0;
+#pragma unroll
+            for (int px = 0; px < 16; ++px) {
+                uint32_t Y, U, V, b, g, r;
+                px_bgr2yuv(c0[px], c1[px], c2[px], Y, U, V);
+                px_yuv2bgr(lut[(Y << kCopyShift) + copy], U, V, b, g, r);
+                w[(3 * px) >> 2] |= b << (8 * ((3 * px) & 3));
+                w[(3 * px + 1) >> 2] |= g << (8 * ((3 * px + 1) & 3));
+                w[(3 * px + 2) >> 2] |= r << (8 * ((3 * px + 2) & 3));
+            }
+            u32x4* dp = reinterpret_cast<u32x4*>(d3 + gidx * 48);
+            const u32x4 r0 = {w[0], w[1], w[2], w[3]}, r1 = {w[4], w[5], w[6], w[7]}, r2 = {w[8], w[9], w[10], w[11]};
+            dp[0] = r0; dp[1] = r1; dp[2] = r2;
+        }
+        for (long long x = (groups << 4) + (long long)blockIdx.x * kThreads + t; x < j.row_px; x += (long long)gridDim.x * kThreads) {
+            uint32_t Y, U, V, b, g, r;
+            px_bgr2yuv(s3[3 * x], s3[3 * x + 1], s3[3 * x + 2], Y, U, V);
+            px_yuv2bgr(lut[(Y << kCopyShift) + copy], U, V, b, g, r);
+            d3[3 * x] = (uint8_t)b; d3[3 * x + 1] = (uint8_t)g; d3[3 * x + 2] = (uint8_t)r;
+        }
+    }
+}
+
 }  // namespace mi

@@ -605,3 +605,20 @@ def test_more_frames_than_grid_limit(ctx):
             assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=2, tiles_y=2)), k
     finally:
         ctx.set_option("fused", 1)
+
+
+def test_bgr_luma_paths_agree(ctx):
+    """The 9 B/px two-pass BGR path and the planar cvtColor+split -> op -> merge+cvtColor path give the oracle's bytes."""
+    try:
+        for fused in (1, 0):
+            ctx.set_option("bgr_fused", fused)
+            for (h, w) in [(1, 1), (5, 3), (47, 63), (360, 640), (1080, 1920)]:
+                a = _bgr(w, h, 31)
+                assert np.array_equal(ctx.bgr_luma_op(a, mi_lumaeq.OP_EQUALIZE), oracle.bgr_luma_op(a, 0)), (fused, h, w)
+            big = _bgr(400, 300, 9)
+            view = big[11:289, 7:391]
+            assert np.array_equal(ctx.bgr_luma_op(view, mi_lumaeq.OP_EQUALIZE), oracle.bgr_luma_op(np.ascontiguousarray(view), 0)), fused
+            flat = np.full((64, 64, 3), (10, 200, 30), np.uint8)                      # constant luma: LUT shortcut
+            assert np.array_equal(ctx.bgr_luma_op(flat, mi_lumaeq.OP_EQUALIZE), oracle.bgr_luma_op(flat, 0)), fused
+    finally:
+        ctx.set_option("bgr_fused", 1)
