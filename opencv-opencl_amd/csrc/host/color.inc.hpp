@@ -23,11 +23,9 @@ mi_status check_color3(mi_ctx* c, const Color3Args& a)
 template <int MODE>
 mi_status launch_color(mi_ctx* c, hipStream_t s, ColorJob j, int n_frames)
 {
-    const long long px = j.row_px * (long long)j.rows;
     const int gy = std::min(j.rows, 65535);
     long long bx = ((long long)c->cu_count * 8 + (long long)gy * n_frames - 1) / ((long long)gy * n_frames);
     bx = std::max<long long>(1, std::min<long long>(bx, (j.row_px / 16 + kThreads - 1) / kThreads + 1));
-    (void)px;
     for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
         const int nf = std::min(kMaxGridY, n_frames - f0);
         ColorJob q = j;
