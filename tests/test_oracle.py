@@ -192,3 +192,25 @@ def test_c_vs_numpy_clahe16(shape, cfg):
         else:
             s = np.full((h, w), 777, np.uint16)
         assert np.array_equal(oracle.clahe16(s, clip, tx, ty), oracle.np_clahe(s, clip, tx, ty)), kind
+
+
+def test_hypothesis_c_vs_numpy():
+    """Property test (hypothesis): the C and numpy restatements agree on arbitrary small images and CLAHE configs."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    img = hnp.arrays(np.uint8, st.tuples(st.integers(1, 40), st.integers(1, 40)), elements=st.integers(0, 255))
+
+    @settings(max_examples=80, deadline=None)
+    @given(img)
+    def eq(a):
+        assert np.array_equal(oracle.equalize_hist(a), oracle.np_equalize_hist(a))
+
+    @settings(max_examples=80, deadline=None)
+    @given(img, st.sampled_from([0.0, 0.3, 1.0, 2.0, 3.0, 40.0]), st.integers(1, 9), st.integers(1, 9))
+    def cl(a, clip, tx, ty):
+        assert np.array_equal(oracle.clahe(a, clip, tx, ty), oracle.np_clahe(a, clip, tx, ty))
+
+    eq()
+    cl()
