@@ -214,3 +214,22 @@ def test_hypothesis_c_vs_numpy():
 
     eq()
     cl()
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """The C restatement built with -fsanitize=address,undefined and run on ragged shapes/strides (CPU build only)."""
+    import shutil
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "oracle_sanitize"
+    cmd = ["gcc", "-O1", "-g", "-std=c11", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           str(root / "tests" / "cxx" / "oracle_sanitize.c"), str(root / "oracle" / "lumaeq_oracle.c"), str(root / "oracle" / "color_oracle.c"),
+           "-o", str(exe), "-lm"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stdout + r.stderr
