@@ -67,3 +67,19 @@ def test_stream_demo_file_io_matches_oracle(tmp_path):
             want = oracle.nv12_frame(frames[k], w, h, uv_mode=1 if uv == "copy" else 0, op=0 if op == "equalize" else 1,
                                      clip_limit=3.0, tiles_x=4, tiles_y=4)
             assert np.array_equal(out[k], want), (op, k)
+
+
+def test_adapter_mat_semantics_cpu(tmp_path):
+    """Mat / ROI / create-no-realloc / split / merge / type errors of the adapter, on the CPU, under ASan + UBSan."""
+    _build()
+    exe = tmp_path / "test_mat_host"
+    lib = ROOT / "opencv-opencl_amd" / "lib"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           str(ROOT / "tests" / "cxx" / "test_mat_host.cpp"), "-o", str(exe), f"-L{lib}", "-lmi_lumaeq",
+           f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert b.returncode == 0, b.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env={"ASAN_OPTIONS": "detect_leaks=0", "PATH": "/usr/bin:/bin"})
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
