@@ -168,7 +168,10 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().mi_ctx_destroy(self._h)
+            try:
+                lib().mi_ctx_destroy(self._h)
+            except Exception:            # interpreter shutdown: the library may already be gone
+                pass
             self._h = None
 
     __del__ = close
