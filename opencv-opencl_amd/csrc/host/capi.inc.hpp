@@ -312,25 +312,26 @@ mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* c, const void* d_src, size_t src_
 static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step,
                          int width, int height, int nv12_mode, bool is_clahe, double clip_limit, int tiles_x, int tiles_y)
 {
+    // Only the Y plane crosses PCIe.  The UV half of a host NV12 frame is not computed on: it is filled with 128 or
+    // copied on the host (exactly the reference's memset/memcpy, OpenCVequalHist.cpp:160-162 / ColoropenCVCwqualHist.cpp:165)
+    // while the GPU works on Y -- a third fewer bytes over the bus than shipping UV both ways.  (The device-resident
+    // forms do the UV fill/copy on the GPU, fused into their launches.)
     const size_t ybytes = (size_t)width * height;
     const size_t uvbytes = nv12_mode >= 0 ? ybytes / 2 : 0;
-    const bool copy_uv_in = nv12_mode == MI_UV_COPY;
-    const size_t in_bytes = ybytes + (copy_uv_in ? uvbytes : 0);
-    const size_t frame_bytes = ybytes + uvbytes;
     mi_status st;
-    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, in_bytes))) return st;
-    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, frame_bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, frame_bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, frame_bytes))) return st;
+    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, ybytes))) return st;
+    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, ybytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, ybytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, ybytes))) return st;
     hipStream_t s = c->stream;
     // Caller-pinned, contiguous buffers (mi_host_register) are DMA'd directly; everything else is staged.
-    const bool in_direct = src_step == (size_t)width && host_range_pinned(src, in_bytes);
-    const bool out_direct = dst_step == (size_t)width && host_range_pinned(dst, frame_bytes);
+    const bool in_direct = src_step == (size_t)width && host_range_pinned(src, ybytes);
+    const bool out_direct = dst_step == (size_t)width && host_range_pinned(dst, ybytes);
     // Chunked staging: the host copy of chunk i+1 into pinned memory overlaps the DMA of chunk i (and the other
     // way round on the way back), so a frame costs ~max(memcpy, PCIe) per direction instead of their sum.
     const int rows_per_chunk = std::max(1, (int)((size_t)(2u << 20) / (size_t)width));
     if (in_direct) {
-        HIPCHK(c, hipMemcpyAsync(c->d_stage_in, src, in_bytes, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_in, src, ybytes, hipMemcpyHostToDevice, s));
     } else {
         for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
             const int nr = std::min(rows_per_chunk, height - y0);
@@ -338,24 +339,23 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
             copy_rows(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
             HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, s));
         }
-        if (copy_uv_in) {                                           // tightly packed NV12 (src_step == width)
-            memcpy(c->h_pin_in + ybytes, src + ybytes, uvbytes);
-            HIPCHK(c, hipMemcpyAsync(c->d_stage_in + ybytes, c->h_pin_in + ybytes, uvbytes, hipMemcpyHostToDevice, s));
-        }
     }
-    PlaneArgs a{c->d_stage_in, (size_t)width, frame_bytes, c->d_stage_out, (size_t)width, frame_bytes, width, height, 1};
-    UVJob uv{};
-    if (nv12_mode >= 0) uv = nv12_uv(c->d_stage_in, c->d_stage_out, width, height, (mi_uv_mode)nv12_mode);
-    st = is_clahe ? clahe_dev(c, s, a, clip_limit, tiles_x, tiles_y, nv12_mode >= 0 ? &uv : nullptr)
-                  : equalize_dev(c, s, a, nv12_mode >= 0 ? &uv : nullptr);
+    PlaneArgs a{c->d_stage_in, (size_t)width, ybytes, c->d_stage_out, (size_t)width, ybytes, width, height, 1};
+    st = is_clahe ? clahe_dev(c, s, a, clip_limit, tiles_x, tiles_y, nullptr) : equalize_dev(c, s, a, nullptr);
     if (st) return st;
     const bool check_status = !is_clahe && c->d_fused;
     if (check_status) {
         if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
         HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
+    auto host_uv = [&]() {                                      // runs while the GPU / DMA engines are busy with Y
+        if (!uvbytes) return;
+        if (nv12_mode == MI_UV_FILL128) memset(dst + ybytes, 128, uvbytes);
+        else if (dst != src) memmove(dst + ybytes, src + ybytes, uvbytes);
+    };
     if (out_direct) {
-        HIPCHK(c, hipMemcpyAsync(dst, c->d_stage_out, frame_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(dst, c->d_stage_out, ybytes, hipMemcpyDeviceToHost, s));
+        host_uv();
         HIPCHK(c, hipStreamSynchronize(s));
         if (check_status && *c->h_status != 0) {
             c->fused_dirty = true;
@@ -370,7 +370,6 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         const int nr = std::min(rows_per_chunk, height - y0);
         chunks.push_back({(size_t)y0 * width, (size_t)nr * width, y0, nr});
     }
-    if (uvbytes) chunks.push_back({ybytes, uvbytes, -1, 0});
     while (c->chunk_events.size() < chunks.size()) {
         hipEvent_t e;
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -380,6 +379,7 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         HIPCHK(c, hipMemcpyAsync(c->h_pin_out + chunks[i].off, c->d_stage_out + chunks[i].off, chunks[i].bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipEventRecord(c->chunk_events[i], s));
     }
+    host_uv();
     for (size_t i = 0; i < chunks.size(); ++i) {
         HIPCHK(c, hipEventSynchronize(c->chunk_events[i]));
         if (i == 0 && check_status && *c->h_status != 0) {
@@ -387,10 +387,7 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
             (void)hipStreamSynchronize(s);
             return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
         }
-        if (chunks[i].y0 >= 0)
-            copy_rows(dst + (size_t)chunks[i].y0 * dst_step, dst_step, c->h_pin_out + chunks[i].off, (size_t)width, width, chunks[i].nr);
-        else
-            memcpy(dst + ybytes, c->h_pin_out + ybytes, uvbytes);
+        copy_rows(dst + (size_t)chunks[i].y0 * dst_step, dst_step, c->h_pin_out + chunks[i].off, (size_t)width, width, chunks[i].nr);
     }
     return MI_OK;
 }

@@ -1,6 +1,9 @@
+import faulthandler
 import os
 import sys
 from pathlib import Path
+
+faulthandler.enable()        # a native crash (HIP runtime, our library) prints the Python stack of every thread
 
 import pytest
 
