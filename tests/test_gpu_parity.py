@@ -499,6 +499,9 @@ def test_hip_graph_capture_and_replay():
         g2.replay()
         torch.cuda.synchronize()
         assert np.array_equal(d_out[1].cpu().numpy(), oracle.nv12_frame(d_in[1].cpu().numpy(), w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
+        # destroy the graphs while the context (whose scratch their kernel nodes point at) is still alive
+        del g, g2
+        torch.cuda.synchronize()
     finally:
         c.close()
 
