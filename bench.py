@@ -133,7 +133,13 @@ def main():
             raise SystemExit("bench.py needs HIP devices (no CPU fallback)")
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except Exception as e:      # the backend only carries the barrier + one scalar max: gloo can stand in
+                print(f"[bench] RCCL init failed ({e!r}); falling back to gloo for the barrier", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group("gloo")
     if args.gpus != world and world > 1:
