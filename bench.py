@@ -367,6 +367,14 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     ms = timeit(lambda: ctx.cvt_color_batch_dev(bgr, bgr_out, w, h, Bc, mi_lumaeq.COLOR_BGR2YUV, stream=stream), 10)
     res["cvtcolor_bgr2yuv_GBs"] = round(2 * 3 * w * h * Bc / (ms * 1e-3) / 1e9, 1)
     del bgr, bgr_out
+    # ... and the NV12 form of the same wording: NV12 -> BGR -> equalizeHist on B, G and R -> NV12 (two passes, 4.5 B/px)
+    Bn = 32
+    nv = synth.nv12_batch_torch(w, h, Bn, args.dist, "cuda", seed=7)
+    nv_out = torch.empty_like(nv)
+    ms = timeit(lambda: ctx.nv12_bgr_equalize_batch_dev(nv, nv_out, w, h, Bn, stream=stream), 10)
+    res["nv12_bgr_channels_equalize_frames_per_s"] = round(Bn / (ms * 1e-3), 1)
+    res["nv12_bgr_channels_equalize_GBs"] = round(4.5 * w * h * Bn / (ms * 1e-3) / 1e9, 1)
+    del nv, nv_out
     # equalizeHist on a strided ROI (generic path: row by row, unaligned starts) and 16-bit CLAHE
     Br = 16
     pitch = w + 64

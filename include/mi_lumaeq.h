@@ -188,6 +188,20 @@ mi_status mi_bgr_luma_op_u8c3_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
                                         int width, int height, int n_frames, int op,
                                         double clip_limit, int tiles_x, int tiles_y, void* stream);
 
+/* ---- BASELINE.json config 5 read literally (second half; parity unpinned) --------------------------
+ * NV12 frame -> BGR -> cv::equalizeHist on each of B, G and R -> NV12.  No file of the reference does this
+ * (ColoropenCVCwqualHist.cpp, which the config names, equalizes Y only and copies UV: :146, :165 -- that behaviour is
+ * mi_equalize_hist_nv12(..., MI_UV_COPY)).  The entry points below stand for the OpenCV 4.4 sequence a maintainer
+ * would write for the config's wording:
+ *     cv::cvtColor(nv12, bgr, cv::COLOR_YUV2BGR_NV12); cv::split; cv::equalizeHist x3; cv::merge;
+ *     cv::cvtColor(bgr, i420, cv::COLOR_BGR2YUV_I420); U and V interleaved back into an NV12 chroma plane
+ * restated in oracle/color_oracle.c (orc_nv12_bgr_equalize).  Tight NV12 frames (W*H luma bytes, then H/2 rows of W
+ * interleaved U,V bytes); width and height must be even (OpenCV asserts the same); in == out allowed. */
+mi_status mi_nv12_bgr_equalize(mi_ctx* ctx, const uint8_t* nv12_in, uint8_t* nv12_out, int width, int height);
+mi_status mi_nv12_bgr_equalize_batch_dev(mi_ctx* ctx, const void* d_in, size_t in_frame_stride,
+                                         void* d_out, size_t out_frame_stride,
+                                         int width, int height, int n_frames, void* stream);
+
 /* ---- stream completion + device-side status -------------------------------------------------------
  * The batched equalizeHist forms normally run as ONE fused launch whose workgroups hand data to each
  * other through bounded waits.  mi_ctx_synchronize() waits for `stream` and returns MI_ERR_HIP if such

@@ -101,6 +101,44 @@ mi_status bgr_luma_dev(mi_ctx* c, hipStream_t s, const Color3Args& a, int op, do
     return launch_color<3>(c, s, k, a.n_frames);
 }
 
+
+// ---- BASELINE.json config 5 read literally: NV12 -> BGR -> equalizeHist on B, G, R -> NV12 (kernels: color.hip.h) ----
+constexpr int kMaxFramesCh = kMaxGridY / 3;        // the LUT kernel runs one workgroup per (frame, channel)
+
+mi_status check_nv12_420(mi_ctx* c, const void* in, const void* out, int width, int height, int n_frames)
+{
+    if (width < 0 || height < 0 || n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "negative size");
+    if ((width & 1) || (height & 1)) return fail(c, MI_ERR_BAD_ARG, "4:2:0 conversion needs even width and height");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    if (!in || !out) return fail(c, MI_ERR_BAD_ARG, "null frame pointer");
+    if ((long long)width * height > 0x7fffffffLL / 3) return fail(c, MI_ERR_UNSUPPORTED, "image too large");
+    return MI_OK;
+}
+
+mi_status nv12_bgr_equalize_dev(mi_ctx* c, hipStream_t s, const uint8_t* in, size_t in_frame, uint8_t* out, size_t out_frame,
+                                int width, int height, int n_frames)
+{
+    const long long ysz = (long long)width * height;
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxFramesCh) {
+        const int nf = std::min(kMaxFramesCh, n_frames - f0);
+        Nv12Job j{};
+        j.in = in + (size_t)f0 * in_frame; j.out = out + (size_t)f0 * out_frame;
+        j.in_frame = (long long)in_frame; j.out_frame = (long long)out_frame;
+        j.width = width; j.height = height;
+        j.vec = (width % 16 == 0) && ((((uintptr_t)j.in | (uintptr_t)j.out | in_frame | out_frame) & 15) == 0);
+        const int B = blocks_per_frame(c, ysz * 3 / 2, 1, nf, 256);
+        mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * 3 * B * 256 * sizeof(uint32_t));
+        if (st) return st;
+        if ((st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * 3 * 256))) return st;
+        LAUNCH(c, s, MI_K_COLOR, nv12_bgr_hist_kernel, dim3(B, nf), dim3(kThreads), 0, j, c->d_partial);
+        LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf * 3), dim3(kThreads), 0,
+               (const uint32_t*)c->d_partial, B, (int)ysz, c->d_luts, (int32_t*)nullptr);
+        const int B2 = blocks_per_frame(c, ysz * 3 / 2, 1, nf, 2048);
+        LAUNCH(c, s, MI_K_COLOR, nv12_bgr_apply_kernel, dim3(B2, nf), dim3(kThreads), 0, j, (const uint8_t*)c->d_luts);
+    }
+    return MI_OK;
+}
+
 // host images staged like host_op(): rows -> pinned -> device (tight) -> op -> pinned -> rows
 mi_status color_host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height,
                         bool luma, int code_or_op, double clip, int tx, int ty)
@@ -176,6 +214,42 @@ mi_status mi_bgr_luma_op_u8c3(mi_ctx* c, const uint8_t* src, size_t src_step, ui
     if (op == MI_OP_CLAHE && (tiles_x <= 0 || tiles_y <= 0)) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
     if (width == 0 || height == 0) return MI_OK;
     return color_host_op(c, src, src_step, dst, dst_step, width, height, true, op, clip_limit, tiles_x, tiles_y);
+}
+
+mi_status mi_nv12_bgr_equalize_batch_dev(mi_ctx* c, const void* d_in, size_t in_frame_stride, void* d_out, size_t out_frame_stride,
+                                         int width, int height, int n_frames, void* stream)
+{
+    ENTER(c);
+    mi_status st = check_nv12_420(c, d_in, d_out, width, height, n_frames);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    const size_t frame = (size_t)width * height * 3 / 2;
+    if (n_frames > 1 && (in_frame_stride < frame || out_frame_stride < frame)) return fail(c, MI_ERR_BAD_ARG, "frame stride < width*height*3/2");
+    return nv12_bgr_equalize_dev(c, pick_stream(c, stream), (const uint8_t*)d_in, in_frame_stride, (uint8_t*)d_out, out_frame_stride,
+                                 width, height, n_frames);
+}
+
+mi_status mi_nv12_bgr_equalize(mi_ctx* c, const uint8_t* nv12_in, uint8_t* nv12_out, int width, int height)
+{
+    ENTER(c);
+    mi_status st = check_nv12_420(c, nv12_in, nv12_out, width, height, 1);
+    if (st || width == 0 || height == 0) return st;
+    const size_t bytes = (size_t)width * height * 3 / 2;
+    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
+    hipStream_t s = c->stream;
+    const bool in_direct = host_range_pinned(nv12_in, bytes), out_direct = host_range_pinned(nv12_out, bytes);
+    if (!in_direct) {
+        if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, bytes))) return st;
+        memcpy(c->h_pin_in, nv12_in, bytes);
+    }
+    if (!out_direct && (st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, bytes))) return st;
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, in_direct ? nv12_in : c->h_pin_in, bytes, hipMemcpyHostToDevice, s));
+    st = nv12_bgr_equalize_dev(c, s, c->d_stage_in, bytes, c->d_stage_out, bytes, width, height, 1);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(out_direct ? nv12_out : c->h_pin_out, c->d_stage_out, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (!out_direct) memcpy(nv12_out, c->h_pin_out, bytes);
+    return MI_OK;
 }
 
 }  // extern "C"

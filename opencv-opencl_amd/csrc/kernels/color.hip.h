@@ -217,4 +217,181 @@ __global__ __launch_bounds__(kThreads) void bgr_luma_apply_kernel(ColorJob j, co
     }
 }
 
+// =============================================================================================
+// BASELINE.json config 5 read literally (second half): NV12 -> BGR -> equalizeHist on B, G and R ->
+// NV12.  No file of the reference does this; the OpenCV 4.4 pipeline it stands for and its 4:2:0 fixed-point
+// arithmetic (ITUR_BT_601_*, shift 20) are restated in oracle/color_oracle.c (orc_nv12_bgr_equalize; parity unpinned).
+// The BGR image is never materialised: pass 1 decodes on the fly and builds the three channel histograms, pass 2
+// decodes again, maps each channel through its LUT and encodes straight back to NV12 -- 4.5 B/px of HBM traffic
+// (1.5 read twice, 1.5 written) instead of the 16.5 B/px of the literal cvtColor/split/merge sequence.
+// A lane owns a 16 x 2 pixel group: two 16-B luma loads + one 16-B chroma load (8 U,V pairs).
+// =============================================================================================
+struct Nv12Job {
+    const uint8_t* in; uint8_t* out;          // tight NV12 frames: W*H luma bytes, then H/2 rows of W interleaved U,V bytes
+    long long in_frame, out_frame;            // bytes between frames
+    int width, height;                        // both even
+    int vec;                                  // 1: W % 16 == 0 and every row start is 16-B aligned -> vector path
+};
+
+constexpr int kChCopies = 16, kChCopyShift = 4;     // 3 channel histograms x 256 bins x 16 copies = 48 KiB of LDS
+
+// (x >> 20) kept opaque for the same reason as yuv_descale(): no v_ashr_pk_u8_i32 pairing.
+__device__ __forceinline__ int bt_shift(int x) { int r = x >> 20; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ void bt601_uv_terms(uint32_t U, uint32_t V, int& ruv, int& guv, int& buv)
+{
+    const int uu = (int)U - 128, vv = (int)V - 128;
+    ruv = (1 << 19) + 1673527 * vv;
+    guv = (1 << 19) - 852492 * vv - 409993 * uu;
+    buv = (1 << 19) + 2116026 * uu;
+}
+__device__ __forceinline__ void bt601_px_bgr(uint32_t Y, int ruv, int guv, int buv, uint32_t& b, uint32_t& g, uint32_t& r)
+{
+    const int yy = max(0, (int)Y - 16) * 1220542;
+    b = sat_u8(bt_shift(yy + buv)); g = sat_u8(bt_shift(yy + guv)); r = sat_u8(bt_shift(yy + ruv));
+}
+__device__ __forceinline__ uint32_t bt601_y(uint32_t b, uint32_t g, uint32_t r)
+{
+    return sat_u8(bt_shift(269484 * (int)r + 528482 * (int)g + 102760 * (int)b + (1 << 19) + (16 << 20)));
+}
+__device__ __forceinline__ void bt601_uv(uint32_t b, uint32_t g, uint32_t r, uint32_t& U, uint32_t& V)
+{
+    U = sat_u8(bt_shift(-155188 * (int)r - 305135 * (int)g + 460324 * (int)b + (1 << 19) + (128 << 20)));
+    V = sat_u8(bt_shift(460324 * (int)r - 385875 * (int)g - 74448 * (int)b + (1 << 19) + (128 << 20)));
+}
+__device__ __forceinline__ uint32_t byte_of(const u32x4& q, int i)       // i is a compile-time constant after unrolling
+{
+    const uint32_t w = i < 4 ? q.x : (i < 8 ? q.y : (i < 12 ? q.z : q.w));
+    return (w >> (8 * (i & 3))) & 0xffu;
+}
+
+// pass 1: partial[((f*3 + ch) * B + part) * 256 + bin], ch = 0 (B), 1 (G), 2 (R).  grid = (B, n_frames)
+__global__ __launch_bounds__(kThreads) void nv12_bgr_hist_kernel(Nv12Job j, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[3 * 256 * kChCopies];
+    const int t = threadIdx.x, f = blockIdx.y;
+    for (int i = t; i < 3 * 256 * kChCopies; i += kThreads) h[i] = 0;
+    __syncthreads();
+    uint32_t* hb = h; uint32_t* hg = h + 256 * kChCopies; uint32_t* hr = h + 2 * 256 * kChCopies;
+    const uint32_t copy = t & (kChCopies - 1);
+    const uint8_t* yp = j.in + (long long)f * j.in_frame;
+    const uint8_t* uvp = yp + (long long)j.width * j.height;
+    auto add = [&](uint32_t Y, int ruv, int guv, int buv) {
+        uint32_t b, g, r;
+        bt601_px_bgr(Y, ruv, guv, buv, b, g, r);
+        lds_inc(hb, (b << kChCopyShift) + copy); lds_inc(hg, (g << kChCopyShift) + copy); lds_inc(hr, (r << kChCopyShift) + copy);
+    };
+    if (j.vec) {
+        const int gx_n = j.width >> 4;
+        const long long groups = (long long)gx_n * (j.height >> 1);
+        for (long long gi = (long long)blockIdx.x * kThreads + t; gi < groups; gi += (long long)gridDim.x * kThreads) {
+            const int by = (int)(gi / gx_n), gx = (int)(gi - (long long)by * gx_n);
+            const u32x4 y0 = *reinterpret_cast<const u32x4*>(yp + (long long)(2 * by) * j.width + (gx << 4));
+            const u32x4 y1 = *reinterpret_cast<const u32x4*>(yp + (long long)(2 * by + 1) * j.width + (gx << 4));
+            const u32x4 uv = *reinterpret_cast<const u32x4*>(uvp + (long long)by * j.width + (gx << 4));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int ruv, guv, buv;
+                bt601_uv_terms(byte_of(uv, 2 * k), byte_of(uv, 2 * k + 1), ruv, guv, buv);
+                add(byte_of(y0, 2 * k), ruv, guv, buv); add(byte_of(y0, 2 * k + 1), ruv, guv, buv);
+                add(byte_of(y1, 2 * k), ruv, guv, buv); add(byte_of(y1, 2 * k + 1), ruv, guv, buv);
+            }
+        }
+    } else {                                            // one 2x2 block per lane
+        const int bx_n = j.width >> 1;
+        const long long blocks = (long long)bx_n * (j.height >> 1);
+        for (long long bi = (long long)blockIdx.x * kThreads + t; bi < blocks; bi += (long long)gridDim.x * kThreads) {
+            const int by = (int)(bi / bx_n), bx = (int)(bi - (long long)by * bx_n);
+            const uint8_t* r0 = yp + (long long)(2 * by) * j.width + 2 * bx;
+            const uint8_t* uv = uvp + (long long)by * j.width + 2 * bx;
+            int ruv, guv, buv;
+            bt601_uv_terms(uv[0], uv[1], ruv, guv, buv);
+            add(r0[0], ruv, guv, buv); add(r0[1], ruv, guv, buv);
+            add(r0[j.width], ruv, guv, buv); add(r0[j.width + 1], ruv, guv, buv);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < kChCopies; ++k) s += h[ch * 256 * kChCopies + (t << kChCopyShift) + ((k + t) & (kChCopies - 1))];
+        partial[(((size_t)f * 3 + ch) * gridDim.x + blockIdx.x) * 256 + t] = s;
+    }
+}
+
+// pass 2: luts[(f*3 + ch) * 256 + v].  grid = (B, n_frames).  in == out allowed (a lane reads its group before writing it).
+__global__ __launch_bounds__(kThreads) void nv12_bgr_apply_kernel(Nv12Job j, const uint8_t* __restrict__ luts)
+{
+    __shared__ uint32_t lut3[256 * kCopies];            // entry v: lutB[v] | lutG[v] << 8 | lutR[v] << 16, 32 copies
+    const int t = threadIdx.x, f = blockIdx.y;
+    const uint32_t copy = t & (kCopies - 1);
+    {
+        const uint8_t* lf = luts + (size_t)f * 3 * 256;
+        const uint32_t v = (uint32_t)lf[t] | ((uint32_t)lf[256 + t] << 8) | ((uint32_t)lf[512 + t] << 16);
+#pragma unroll
+        for (int k = 0; k < kCopies; ++k) lut3[(t << kCopyShift) + ((k + t) & (kCopies - 1))] = v;
+    }
+    __syncthreads();
+    const uint8_t* yp = j.in + (long long)f * j.in_frame;
+    const uint8_t* uvp = yp + (long long)j.width * j.height;
+    uint8_t* yo = j.out + (long long)f * j.out_frame;
+    uint8_t* uvo = yo + (long long)j.width * j.height;
+    // decode -> per-channel LUT -> luma of the equalized pixel; (b, g, r) returned for the chroma of a block's first pixel
+    auto px = [&](uint32_t Y, int ruv, int guv, int buv, uint32_t& b, uint32_t& g, uint32_t& r) -> uint32_t {
+        bt601_px_bgr(Y, ruv, guv, buv, b, g, r);
+        b = lut3[(b << kCopyShift) + copy] & 0xffu;
+        g = (lut3[(g << kCopyShift) + copy] >> 8) & 0xffu;
+        r = (lut3[(r << kCopyShift) + copy] >> 16) & 0xffu;
+        return bt601_y(b, g, r);
+    };
+    if (j.vec) {
+        const int gx_n = j.width >> 4;
+        const long long groups = (long long)gx_n * (j.height >> 1);
+        for (long long gi = (long long)blockIdx.x * kThreads + t; gi < groups; gi += (long long)gridDim.x * kThreads) {
+            const int by = (int)(gi / gx_n), gx = (int)(gi - (long long)by * gx_n);
+            const long long o0 = (long long)(2 * by) * j.width + (gx << 4), o1 = o0 + j.width, ouv = (long long)by * j.width + (gx << 4);
+            const u32x4 y0 = *reinterpret_cast<const u32x4*>(yp + o0);
+            const u32x4 y1 = *reinterpret_cast<const u32x4*>(yp + o1);
+            const u32x4 uv = *reinterpret_cast<const u32x4*>(uvp + ouv);
+            uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, wuv[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int ruv, guv, buv;
+                bt601_uv_terms(byte_of(uv, 2 * k), byte_of(uv, 2 * k + 1), ruv, guv, buv);
+                uint32_t b0, g0, r0, b, g, r, U, V;
+                const uint32_t a00 = px(byte_of(y0, 2 * k), ruv, guv, buv, b0, g0, r0);
+                const uint32_t a01 = px(byte_of(y0, 2 * k + 1), ruv, guv, buv, b, g, r);
+                const uint32_t a10 = px(byte_of(y1, 2 * k), ruv, guv, buv, b, g, r);
+                const uint32_t a11 = px(byte_of(y1, 2 * k + 1), ruv, guv, buv, b, g, r);
+                bt601_uv(b0, g0, r0, U, V);
+                w0[k >> 1] |= (a00 | (a01 << 8)) << (16 * (k & 1));
+                w1[k >> 1] |= (a10 | (a11 << 8)) << (16 * (k & 1));
+                wuv[k >> 1] |= (U | (V << 8)) << (16 * (k & 1));
+            }
+            const u32x4 q0 = {w0[0], w0[1], w0[2], w0[3]}, q1 = {w1[0], w1[1], w1[2], w1[3]}, q2 = {wuv[0], wuv[1], wuv[2], wuv[3]};
+            *reinterpret_cast<u32x4*>(yo + o0) = q0;
+            *reinterpret_cast<u32x4*>(yo + o1) = q1;
+            *reinterpret_cast<u32x4*>(uvo + ouv) = q2;
+        }
+    } else {
+        const int bx_n = j.width >> 1;
+        const long long blocks = (long long)bx_n * (j.height >> 1);
+        for (long long bi = (long long)blockIdx.x * kThreads + t; bi < blocks; bi += (long long)gridDim.x * kThreads) {
+            const int by = (int)(bi / bx_n), bx = (int)(bi - (long long)by * bx_n);
+            const long long o0 = (long long)(2 * by) * j.width + 2 * bx, ouv = (long long)by * j.width + 2 * bx;
+            const uint32_t Y00 = yp[o0], Y01 = yp[o0 + 1], Y10 = yp[o0 + j.width], Y11 = yp[o0 + j.width + 1];
+            int ruv, guv, buv;
+            bt601_uv_terms(uvp[ouv], uvp[ouv + 1], ruv, guv, buv);
+            uint32_t b0, g0, r0, b, g, r, U, V;
+            const uint32_t a00 = px(Y00, ruv, guv, buv, b0, g0, r0);
+            const uint32_t a01 = px(Y01, ruv, guv, buv, b, g, r);
+            const uint32_t a10 = px(Y10, ruv, guv, buv, b, g, r);
+            const uint32_t a11 = px(Y11, ruv, guv, buv, b, g, r);
+            bt601_uv(b0, g0, r0, U, V);
+            yo[o0] = (uint8_t)a00; yo[o0 + 1] = (uint8_t)a01; yo[o0 + j.width] = (uint8_t)a10; yo[o0 + j.width + 1] = (uint8_t)a11;
+            uvo[ouv] = (uint8_t)U; uvo[ouv + 1] = (uint8_t)V;
+        }
+    }
+}
+
 }  // namespace mi

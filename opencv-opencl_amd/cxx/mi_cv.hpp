@@ -359,6 +359,15 @@ inline void claheNV12(const unsigned char* in, unsigned char* out, int width, in
     detail::check(c, mi_clahe_nv12(c, in, out, width, height, (mi_uv_mode)uv, clipLimit, tiles.width, tiles.height), "mi_clahe_nv12");
 }
 
+// BASELINE.json config 5 read literally: cvtColor(COLOR_YUV2BGR_NV12) -> split -> equalizeHist on B, G and R -> merge ->
+// cvtColor(COLOR_BGR2YUV_I420) + U/V interleave, NV12 in -> NV12 out in one call (no file of the reference does this;
+// ColoropenCVCwqualHist.cpp itself is equalizeHistNV12(..., UV_COPY)).  Width and height must be even.
+inline void equalizeHistChannelsNV12(const unsigned char* in, unsigned char* out, int width, int height)
+{
+    mi_ctx* c = detail::thread_ctx();
+    detail::check(c, mi_nv12_bgr_equalize(c, in, out, width, height), "mi_nv12_bgr_equalize");
+}
+
 }  // namespace micv
 
 // ---- real OpenCV front end (only when the including program already uses OpenCV) ----

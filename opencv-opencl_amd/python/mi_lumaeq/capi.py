@@ -1,8 +1,11 @@
 """ctypes binding of include/mi_lumaeq.h.  Fails loudly when the HIP library is missing."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -30,6 +33,7 @@ DECLARED_SYMBOLS = [
     "mi_ctx_synchronize", "mi_ctx_set_option",
     "mi_host_register", "mi_host_unregister", "mi_clahe_u16", "mi_clahe_u16_batch_dev",
     "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
+    "mi_nv12_bgr_equalize", "mi_nv12_bgr_equalize_batch_dev",
 ]
 
 _K = len(KERNEL_NAMES)
@@ -96,6 +100,8 @@ def lib() -> C.CDLL:
     L.mi_cvt_color_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, vp]
     L.mi_bgr_luma_op_u8c3.argtypes = [vp, vp, sz, vp, sz, i, i, i, d, i, i]
     L.mi_bgr_luma_op_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, d, i, i, vp]
+    L.mi_nv12_bgr_equalize.argtypes = [vp, vp, vp, i, i]
+    L.mi_nv12_bgr_equalize_batch_dev.argtypes = [vp, vp, sz, vp, sz, i, i, i, vp]
     L.mi_clahe_u16.argtypes = [vp, vp, sz, vp, sz, i, i, d, i, i]
     L.mi_clahe_u16_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, d, i, i, vp]
     L.mi_host_register.argtypes = [vp, sz]
@@ -157,6 +163,19 @@ def _dptr(t) -> int:
     return int(t.data_ptr())
 
 
+_live_contexts: "weakref.WeakSet[Context]" = weakref.WeakSet()
+
+
+def _close_live_contexts() -> None:
+    """atexit: destroy every context while the HIP runtime is still up.  Destroying one from ``__del__`` during
+    interpreter finalisation can run after the runtime's own teardown (hipFree on a dead runtime)."""
+    for c in list(_live_contexts):
+        c.close()
+
+
+atexit.register(_close_live_contexts)
+
+
 class Context:
     """mi_ctx wrapper.  One per (thread x device), like the reference's per-worker OpenCL objects."""
 
@@ -165,16 +184,22 @@ class Context:
         rc = lib().mi_ctx_create(int(device), C.byref(self._h))
         if rc != 0:
             raise MiError(rc, f"mi_ctx_create(device={device})")
+        _live_contexts.add(self)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            try:
-                lib().mi_ctx_destroy(self._h)
-            except Exception:            # interpreter shutdown: the library may already be gone
-                pass
-            self._h = None
+            h, self._h = self._h, None
+            lib().mi_ctx_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        # Never call into the library while the interpreter is finalising: the atexit hook has already closed
+        # every live context, and anything that slipped past it is leaked rather than freed on a dead runtime.
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self
@@ -346,6 +371,22 @@ class Context:
         self._chk(lib().mi_bgr_luma_op_u8c3_batch_dev(self._h, _dptr(src), width * 3, width * 3 * height, _dptr(dst), width * 3,
                                                       width * 3 * height, width, height, n_frames, int(op), float(clip_limit),
                                                       int(tiles_x), int(tiles_y), stream), "mi_bgr_luma_op_u8c3_batch_dev")
+
+    def nv12_bgr_equalize(self, nv12: np.ndarray, width: int, height: int, out: np.ndarray | None = None) -> np.ndarray:
+        """NV12 -> BGR -> equalizeHist on B, G, R -> NV12 (BASELINE.json config 5 read literally)."""
+        if not isinstance(nv12, np.ndarray) or nv12.dtype != np.uint8 or not nv12.flags.c_contiguous:
+            raise MiError(2, "nv12_bgr_equalize", "expected a contiguous uint8 ndarray")
+        if width >= 0 and height >= 0 and nv12.size != width * height * 3 // 2:
+            raise MiError(1, "nv12_bgr_equalize", "NV12 frame must hold width*height*3/2 bytes")
+        if out is None:
+            out = np.empty_like(nv12)
+        self._chk(lib().mi_nv12_bgr_equalize(self._h, nv12.ctypes.data, out.ctypes.data, int(width), int(height)), "mi_nv12_bgr_equalize")
+        return out
+
+    def nv12_bgr_equalize_batch_dev(self, src, dst, width, height, n_frames, stream=0, frame_stride=None):
+        fs = width * height * 3 // 2 if frame_stride is None else int(frame_stride)
+        self._chk(lib().mi_nv12_bgr_equalize_batch_dev(self._h, _dptr(src), fs, _dptr(dst), fs, width, height, n_frames, stream),
+                  "mi_nv12_bgr_equalize_batch_dev")
 
     def synchronize(self, stream=0):
         """Wait for `stream`; raises if the fused kernel reported an expired inter-workgroup wait."""

@@ -60,7 +60,10 @@ def lib() -> ctypes.CDLL:
         L.orc_clahe_u16.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_double, ctypes.c_int, ctypes.c_int]
         L.orc_clahe_u16.restype = ctypes.c_int
-        for f in (L.orc_bgr2yuv_u8, L.orc_yuv2bgr_u8, L.orc_bgr_luma_op):
+        L.orc_nv12_to_bgr.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
+        L.orc_bgr_to_nv12.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
+        L.orc_nv12_bgr_equalize.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
+        for f in (L.orc_bgr2yuv_u8, L.orc_yuv2bgr_u8, L.orc_bgr_luma_op, L.orc_nv12_to_bgr, L.orc_bgr_to_nv12, L.orc_nv12_bgr_equalize):
             f.restype = ctypes.c_int
         for f in (L.orc_hist_u8, L.orc_equalize_lut, L.orc_lut_apply_u8, L.orc_equalize_hist_u8,
                   L.orc_clahe_tile_luts, L.orc_clahe_u8, L.orc_nv12_frame):
@@ -214,4 +217,41 @@ def bgr_luma_op(src: np.ndarray, op: int = 0, clip_limit: float = 3.0, tiles_x: 
     return dst
 
 
-from .np_oracle import np_equalize_hist, np_clahe, np_clahe_geometry  # noqa: E402,F401
+def _nv12(a: np.ndarray, width: int, height: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, np.uint8).reshape(-1)
+    if width < 0 or height < 0 or width % 2 or height % 2:
+        raise ValueError("oracle: NV12 4:2:0 needs even width and height")
+    if a.size != width * height * 3 // 2:
+        raise ValueError("oracle: NV12 frame must hold width*height*3/2 bytes")
+    return a
+
+
+def nv12_to_bgr(nv12: np.ndarray, width: int, height: int) -> np.ndarray:
+    """cv::cvtColor(nv12, COLOR_YUV2BGR_NV12) (BASELINE config 5 read literally; parity unpinned)."""
+    a = _nv12(nv12, width, height)
+    dst = np.empty((height, width, 3), np.uint8)
+    if dst.size:
+        _check(lib().orc_nv12_to_bgr(_ptr(a), _ptr(dst), width, height), "nv12_to_bgr")
+    return dst
+
+
+def bgr_to_nv12(bgr: np.ndarray) -> np.ndarray:
+    """cv::cvtColor(bgr, COLOR_BGR2YUV_I420) with U and V interleaved into an NV12 chroma plane."""
+    bgr = np.ascontiguousarray(_as3(bgr))
+    h, w = bgr.shape[:2]
+    dst = np.empty(w * h * 3 // 2, np.uint8)
+    if dst.size:
+        _check(lib().orc_bgr_to_nv12(_ptr(bgr), _ptr(dst), w, h), "bgr_to_nv12")
+    return dst
+
+
+def nv12_bgr_equalize(nv12: np.ndarray, width: int, height: int) -> np.ndarray:
+    """NV12 -> BGR -> equalizeHist on B, G and R -> NV12 (BASELINE.json config 5 read literally)."""
+    a = _nv12(nv12, width, height)
+    dst = np.empty_like(a)
+    if dst.size:
+        _check(lib().orc_nv12_bgr_equalize(_ptr(a), _ptr(dst), width, height), "nv12_bgr_equalize")
+    return dst
+
+
+from .np_oracle import np_equalize_hist, np_clahe, np_clahe_geometry, np_nv12_bgr_equalize  # noqa: E402,F401

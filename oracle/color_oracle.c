@@ -99,3 +99,97 @@ int orc_bgr_luma_op(const uint8_t* bgr_in, uint8_t* bgr_out, int width, int heig
     free(yuv); free(y); free(y2);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * BASELINE.json config 5 read literally (second half): an NV12 frame taken to BGR, every colour
+ * channel equalized, and the result taken back to NV12.  NO file of the reference does this (ColoropenCVCwqualHist.cpp
+ * equalizes Y only, :146/:165); the pipeline restated here is what a maintainer would write with OpenCV 4.4:
+ *     cvtColor(nv12, bgr, COLOR_YUV2BGR_NV12); split; equalizeHist(B), (G), (R); merge;
+ *     cvtColor(bgr, i420, COLOR_BGR2YUV_I420); interleave U and V into the NV12 chroma plane.
+ * PARITY UNPINNED (twice over: no reference implementation and no OpenCV here).  4:2:0 arithmetic restated from OpenCV
+ * 4.4 modules/imgproc/src/color_yuv.simd.hpp (YUV420sp2RGB8Invoker / RGB8toYUV420pInvoker), ITUR_BT_601_SHIFT = 20:
+ *     decode: CY 1220542, CUB 2116026, CUG -409993, CVG -852492, CVR 1673527
+ *        y = max(0, Y-16)*CY;  ruv = 2^19 + CVR*(V-128);  guv = 2^19 + CVG*(V-128) + CUG*(U-128);  buv = 2^19 + CUB*(U-128)
+ *        R,G,B = saturate_cast<uchar>((y + {r,g,b}uv) >> 20); the four pixels of a 2x2 block share one (U,V)
+ *     encode: CRY 269484, CGY 528482, CBY 102760, CRU -155188, CGU -305135, CBU 460324, CGV -385875, CBV -74448
+ *        Y = sat((CRY*R + CGY*G + CBY*B + 2^19 + (16 << 20)) >> 20) for every pixel
+ *        U = sat((CRU*R + CGU*G + CBU*B + 2^19 + (128 << 20)) >> 20), V = sat((CBU*R + CGV*G + CBV*B + 2^19 + (128 << 20)) >> 20)
+ *        taken from the TOP-LEFT pixel of each 2x2 block (no averaging)
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { BT_SHIFT = 20, BT_CY = 1220542, BT_CUB = 2116026, BT_CUG = -409993, BT_CVG = -852492, BT_CVR = 1673527,
+       BT_CRY = 269484, BT_CGY = 528482, BT_CBY = 102760, BT_CRU = -155188, BT_CGU = -305135, BT_CBU = 460324,
+       BT_CGV = -385875, BT_CBV = -74448 };
+
+/* NV12 (tight: Y rows of `width` bytes, then height/2 rows of interleaved U,V) -> CV_8UC3 BGR (tight). width, height even. */
+int orc_nv12_to_bgr(const uint8_t* nv12, uint8_t* bgr, int width, int height)
+{
+    if (width < 0 || height < 0 || (width & 1) || (height & 1)) return 1;
+    if (width == 0 || height == 0) return 0;
+    if (!nv12 || !bgr) return 1;
+    const uint8_t* uvp = nv12 + (size_t)width * height;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int y = 0; y < height; ++y) {
+        const uint8_t* yr = nv12 + (size_t)y * width;
+        const uint8_t* uvr = uvp + (size_t)(y / 2) * width;
+        uint8_t* d = bgr + (size_t)y * width * 3;
+        for (int x = 0; x < width; ++x) {
+            const int uu = (int)uvr[x & ~1] - 128, vv = (int)uvr[(x & ~1) + 1] - 128;
+            const int ruv = (1 << (BT_SHIFT - 1)) + BT_CVR * vv;
+            const int guv = (1 << (BT_SHIFT - 1)) + BT_CVG * vv + BT_CUG * uu;
+            const int buv = (1 << (BT_SHIFT - 1)) + BT_CUB * uu;
+            const int yy = (yr[x] > 16 ? (int)yr[x] - 16 : 0) * BT_CY;
+            d[3 * x] = sat((yy + buv) >> BT_SHIFT); d[3 * x + 1] = sat((yy + guv) >> BT_SHIFT); d[3 * x + 2] = sat((yy + ruv) >> BT_SHIFT);
+        }
+    }
+    return 0;
+}
+
+/* CV_8UC3 BGR (tight) -> NV12 (tight): COLOR_BGR2YUV_I420 arithmetic, U and V interleaved. */
+int orc_bgr_to_nv12(const uint8_t* bgr, uint8_t* nv12, int width, int height)
+{
+    if (width < 0 || height < 0 || (width & 1) || (height & 1)) return 1;
+    if (width == 0 || height == 0) return 0;
+    if (!nv12 || !bgr) return 1;
+    uint8_t* uvp = nv12 + (size_t)width * height;
+    const int half = 1 << (BT_SHIFT - 1);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int y = 0; y < height; ++y) {
+        const uint8_t* s = bgr + (size_t)y * width * 3;
+        uint8_t* yr = nv12 + (size_t)y * width;
+        for (int x = 0; x < width; ++x) {
+            const int b = s[3 * x], g = s[3 * x + 1], r = s[3 * x + 2];
+            yr[x] = sat((BT_CRY * r + BT_CGY * g + BT_CBY * b + half + (16 << BT_SHIFT)) >> BT_SHIFT);
+            if (!(y & 1) && !(x & 1)) {
+                uint8_t* uv = uvp + (size_t)(y / 2) * width + x;
+                uv[0] = sat((BT_CRU * r + BT_CGU * g + BT_CBU * b + half + (128 << BT_SHIFT)) >> BT_SHIFT);
+                uv[1] = sat((BT_CBU * r + BT_CGV * g + BT_CBV * b + half + (128 << BT_SHIFT)) >> BT_SHIFT);
+            }
+        }
+    }
+    return 0;
+}
+
+/* The whole literal config-5 frame op: NV12 in -> NV12 out (in place allowed). */
+int orc_nv12_bgr_equalize(const uint8_t* nv12_in, uint8_t* nv12_out, int width, int height)
+{
+    if (width < 0 || height < 0 || (width & 1) || (height & 1)) return 1;
+    if (width == 0 || height == 0) return 0;
+    const size_t n = (size_t)width * height;
+    uint8_t* bgr = (uint8_t*)malloc(n * 3);
+    uint8_t* p = (uint8_t*)malloc(n);
+    uint8_t* q = (uint8_t*)malloc(n);
+    if (!bgr || !p || !q) { free(bgr); free(p); free(q); return 4; }
+    int rc = orc_nv12_to_bgr(nv12_in, bgr, width, height);
+    for (int c = 0; c < 3 && !rc; ++c) {
+        for (size_t i = 0; i < n; ++i) p[i] = bgr[3 * i + c];                        /* split */
+        rc = orc_equalize_hist_u8(p, (size_t)width, q, (size_t)width, width, height);
+        for (size_t i = 0; i < n; ++i) bgr[3 * i + c] = q[i];                        /* merge */
+    }
+    if (!rc) rc = orc_bgr_to_nv12(bgr, nv12_out, width, height);
+    free(bgr); free(p); free(q);
+    return rc;
+}

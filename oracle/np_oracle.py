@@ -110,3 +110,28 @@ def np_clahe(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_
     res = top + bot
     assert res.dtype == np.float32
     return np.clip(np.rint(res), 0, HS - 1).astype(src.dtype)
+
+
+def np_nv12_bgr_equalize(nv12: np.ndarray, width: int, height: int) -> np.ndarray:
+    """Second restatement of the literal BASELINE config-5 pipeline (see color_oracle.c): COLOR_YUV2BGR_NV12 ->
+    equalizeHist on B, G, R -> COLOR_BGR2YUV_I420 with U,V interleaved.  Vectorised, int64 arithmetic."""
+    a = np.asarray(nv12, np.uint8).reshape(-1)
+    assert width % 2 == 0 and height % 2 == 0 and a.size == width * height * 3 // 2
+    if a.size == 0:
+        return a.copy()
+    Y = a[:width * height].reshape(height, width).astype(np.int64)
+    uv = a[width * height:].reshape(height // 2, width // 2, 2).astype(np.int64) - 128
+    U = np.repeat(np.repeat(uv[..., 0], 2, axis=0), 2, axis=1)
+    V = np.repeat(np.repeat(uv[..., 1], 2, axis=0), 2, axis=1)
+    half = 1 << 19
+    yy = np.maximum(Y - 16, 0) * 1220542
+    sat = lambda x: np.clip(x, 0, 255).astype(np.uint8)
+    R = sat((yy + half + 1673527 * V) >> 20)
+    G = sat((yy + half - 852492 * V - 409993 * U) >> 20)
+    B = sat((yy + half + 2116026 * U) >> 20)
+    B, G, R = (np_equalize_hist(c).astype(np.int64) for c in (B, G, R))
+    Yo = sat((269484 * R + 528482 * G + 102760 * B + half + (16 << 20)) >> 20)
+    r0, g0, b0 = R[::2, ::2], G[::2, ::2], B[::2, ::2]
+    Uo = sat((-155188 * r0 - 305135 * g0 + 460324 * b0 + half + (128 << 20)) >> 20)
+    Vo = sat((460324 * r0 - 385875 * g0 - 74448 * b0 + half + (128 << 20)) >> 20)
+    return np.concatenate([Yo.reshape(-1), np.stack([Uo, Vo], axis=-1).reshape(-1)])

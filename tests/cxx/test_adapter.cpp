@@ -16,6 +16,7 @@ int orc_clahe_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int, double, int
 int orc_nv12_frame(const uint8_t*, uint8_t*, int, int, int, int, double, int, int);
 int orc_bgr_luma_op(const uint8_t*, uint8_t*, int, int, int, double, int, int);
 int orc_bgr2yuv_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int);
+int orc_nv12_bgr_equalize(const uint8_t*, uint8_t*, int, int);
 int orc_clahe_u16(const uint16_t*, size_t, uint16_t*, size_t, int, int, double, int, int);
 }
 
@@ -139,6 +140,19 @@ int main()
         EXPECT(memcmp(fused_clahe.data, want.data(), want.size()) == 0);
         bool threw = false;
         try { Mat g(4, 4, CV_8UC1), o; cvtColor(g, o, COLOR_BGR2YUV); } catch (const std::exception&) { threw = true; }
+        EXPECT(threw);
+    }
+    // --- BASELINE config 5 read literally: NV12 -> BGR -> equalizeHist on B, G, R -> NV12 in one call
+    {
+        const int CW = 322, CH = 178;                                    // W % 16 != 0: block-per-lane path
+        std::vector<uint8_t> f((size_t)CW * CH * 3 / 2), got(f.size()), want(f.size());
+        uint64_t s = 1234;
+        for (auto& v : f) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (uint8_t)(60 + (s >> 40) % 120); }
+        equalizeHistChannelsNV12(f.data(), got.data(), CW, CH);
+        orc_nv12_bgr_equalize(f.data(), want.data(), CW, CH);
+        EXPECT(memcmp(got.data(), want.data(), want.size()) == 0);
+        bool threw = false;
+        try { equalizeHistChannelsNV12(f.data(), got.data(), 321, CH); } catch (const std::exception&) { threw = true; }
         EXPECT(threw);
     }
     // --- 16-bit CLAHE through the same cv::CLAHE-shaped object

@@ -177,6 +177,48 @@ def test_color_conversion_kats():
     assert np.array_equal(oracle.bgr_luma_op(a, 0), oracle.yuv2bgr(yuv_img2))
 
 
+def test_nv12_bgr_channel_equalize_oracle():
+    """BASELINE config 5 read literally (parity unpinned): 4:2:0 BT.601 KATs, C vs numpy, composite = pieces."""
+    # decode KATs (hand-computed, shift 20): a grey 2x2 block (U=V=128) and a block carrying the chroma of pure red (U=90, V=240)
+    nv = np.array([16, 235, 81, 0,
+                   126, 81, 255, 16,
+                   128, 128, 90, 240], np.uint8)
+    bgr = oracle.nv12_to_bgr(nv, 4, 2)
+    assert bgr[0, 0].tolist() == [0, 0, 0] and bgr[0, 1].tolist() == [255, 255, 255]       # video black / white
+    assert bgr[1, 0].tolist() == [128, 128, 128]        # (110*1220542 + 2^19) >> 20
+    assert bgr[1, 1].tolist() == [76, 76, 76]           # ( 65*1220542 + 2^19) >> 20
+    assert bgr[0, 2].tolist() == [0, 0, 254]            # R = (65*1220542 + 2^19 + 1673527*112) >> 20; G, B go negative -> 0
+    assert bgr[0, 3].tolist() == [0, 0, 179]            # Y < 16 clamps to 0: R = (2^19 + 1673527*112) >> 20
+    assert bgr[1, 2].tolist() == [202, 202, 255]        # Y=255: B = (239*1220542 + 2^19 - 2116026*38) >> 20
+    # encode KATs: luma of every pixel, chroma from the top-left pixel of the block only
+    px = np.array([[[0, 0, 255], [255, 255, 255]], [[0, 0, 0], [128, 128, 128]]], np.uint8)  # B,G,R
+    out = oracle.bgr_to_nv12(px)
+    assert out.tolist() == [82, 235, 16, 126, 90, 240]
+    assert (269484 * 255 + (1 << 19) + (16 << 20)) >> 20 == 82 and (460324 * 255 + (1 << 19) + (128 << 20)) >> 20 == 240
+    # a grey frame on the video range survives decode + encode unchanged
+    ramp = np.arange(16, 236, dtype=np.uint8)
+    grey = np.concatenate([ramp, ramp[::-1], np.full(220, 128, np.uint8)])
+    assert np.array_equal(oracle.bgr_to_nv12(oracle.nv12_to_bgr(grey, 220, 2)), grey)
+    # C vs numpy on random and structured frames
+    rng = np.random.default_rng(12)
+    for (w, h) in [(2, 2), (16, 2), (18, 6), (64, 48), (322, 178)]:
+        a = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+        assert np.array_equal(oracle.nv12_bgr_equalize(a, w, h), oracle.np_nv12_bgr_equalize(a, w, h)), (w, h)
+        lo = (a // 4 + 90).astype(np.uint8)                        # low-contrast frame
+        assert np.array_equal(oracle.nv12_bgr_equalize(lo, w, h), oracle.np_nv12_bgr_equalize(lo, w, h)), (w, h)
+    # composite = pieces
+    w, h = 64, 48
+    a = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+    bgr = oracle.nv12_to_bgr(a, w, h)
+    for c in range(3):
+        bgr[..., c] = oracle.equalize_hist(np.ascontiguousarray(bgr[..., c]))
+    assert np.array_equal(oracle.nv12_bgr_equalize(a, w, h), oracle.bgr_to_nv12(bgr))
+    # odd sizes are rejected (OpenCV asserts even dimensions for 4:2:0)
+    with pytest.raises(ValueError):
+        oracle.nv12_bgr_equalize(np.zeros(3 * 2 * 3 // 2, np.uint8), 3, 2)
+    assert oracle.nv12_bgr_equalize(np.zeros(0, np.uint8), 0, 0).size == 0
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (15, 16), (47, 63), (64, 48)], ids=str)
 @pytest.mark.parametrize("cfg", [(2.0, 8, 8), (3.0, 4, 4), (0.0, 3, 5), (40.0, 1, 1)], ids=str)
 def test_c_vs_numpy_clahe16(shape, cfg):
