@@ -202,6 +202,19 @@ mi_status mi_nv12_bgr_equalize_batch_dev(mi_ctx* ctx, const void* d_in, size_t i
                                          void* d_out, size_t out_frame_stride,
                                          int width, int height, int n_frames, void* stream);
 
+/* cv::cvtColor's 4:2:0 codes on their own (same arithmetic as the pipeline above; parity unpinned):
+ *   MI_COLOR_BGR2YUV_I420 (cv::COLOR_BGR2YUV_I420 = 128; 1frameMeasure.cpp:32 prepares its bench input with it):
+ *     src CV_8UC3 W x H (pitch >= 3W) -> dst CV_8UC1 W x H*3/2 (pitch >= W): Y rows, then the U and the V plane packed
+ *     the way OpenCV packs them (as if the W x H*3/2 matrix were tight, then laid out with dst_step);
+ *   MI_COLOR_YUV2BGR_NV12 (cv::COLOR_YUV2BGR_NV12 = 93): src CV_8UC1 W x H*3/2 NV12 -> dst CV_8UC3 W x H.
+ * width/height are the picture's (even).  The device form wants the planar side tight (step == width). */
+enum { MI_COLOR_YUV2BGR_NV12 = 93, MI_COLOR_BGR2YUV_I420 = 128 };
+mi_status mi_cvt_color_420_u8(mi_ctx* ctx, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step,
+                              int width, int height, int code);
+mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                        void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                        int width, int height, int n_frames, int code, void* stream);
+
 /* ---- stream completion + device-side status -------------------------------------------------------
  * The batched equalizeHist forms normally run as ONE fused launch whose workgroups hand data to each
  * other through bounded waits.  mi_ctx_synchronize() waits for `stream` and returns MI_ERR_HIP if such

@@ -139,6 +139,43 @@ mi_status nv12_bgr_equalize_dev(mi_ctx* c, hipStream_t s, const uint8_t* in, siz
     return MI_OK;
 }
 
+
+// cv::cvtColor 4:2:0 codes as stand-alone conversions.  `c3_*` describe the CV_8UC3 side, the planar side is tight.
+mi_status cvt420_dev(mi_ctx* c, hipStream_t s, int code, const uint8_t* src, uint8_t* dst, size_t c3_step, size_t c3_frame,
+                     size_t planar_frame, int width, int height, int n_frames)
+{
+    const long long blocks = (long long)(width / 2) * (height / 2);
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxGridY) {
+        const int nf = std::min(kMaxGridY, n_frames - f0);
+        Cvt420Job j{};
+        const bool enc = code == MI_COLOR_BGR2YUV_I420;
+        j.src = src + (size_t)f0 * (enc ? c3_frame : planar_frame);
+        j.dst = dst + (size_t)f0 * (enc ? planar_frame : c3_frame);
+        j.c3_step = (long long)c3_step; j.c3_frame = (long long)c3_frame; j.planar_frame = (long long)planar_frame;
+        j.width = width; j.height = height;
+        long long bx = ((long long)c->cu_count * 8 + nf - 1) / nf;
+        bx = std::max<long long>(1, std::min<long long>(bx, (blocks + kThreads - 1) / kThreads));
+        if (enc) LAUNCH(c, s, MI_K_COLOR, cvt420_kernel<0>, dim3((unsigned)bx, nf), dim3(kThreads), 0, j);
+        else     LAUNCH(c, s, MI_K_COLOR, cvt420_kernel<1>, dim3((unsigned)bx, nf), dim3(kThreads), 0, j);
+    }
+    return MI_OK;
+}
+
+mi_status check_cvt420(mi_ctx* c, const void* src, size_t src_step, const void* dst, size_t dst_step, int width, int height, int n_frames, int code)
+{
+    if (code != MI_COLOR_BGR2YUV_I420 && code != MI_COLOR_YUV2BGR_NV12)
+        return fail(c, MI_ERR_UNSUPPORTED, "4:2:0 colour code must be 128 (BGR2YUV_I420) or 93 (YUV2BGR_NV12)");
+    if (width < 0 || height < 0 || n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "negative size");
+    if ((width & 1) || (height & 1)) return fail(c, MI_ERR_BAD_ARG, "4:2:0 conversion needs even width and height");
+    if (width == 0 || height == 0 || n_frames == 0) return MI_OK;
+    if (!src || !dst) return fail(c, MI_ERR_BAD_ARG, "null image pointer");
+    const size_t need_src = code == MI_COLOR_BGR2YUV_I420 ? (size_t)width * 3 : (size_t)width;
+    const size_t need_dst = code == MI_COLOR_BGR2YUV_I420 ? (size_t)width : (size_t)width * 3;
+    if (src_step < need_src || dst_step < need_dst) return fail(c, MI_ERR_BAD_ARG, "step too small for the image width");
+    if ((long long)width * height > 0x7fffffffLL / 3) return fail(c, MI_ERR_UNSUPPORTED, "image too large");
+    return MI_OK;
+}
+
 // host images staged like host_op(): rows -> pinned -> device (tight) -> op -> pinned -> rows
 mi_status color_host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height,
                         bool luma, int code_or_op, double clip, int tx, int ty)
@@ -249,6 +286,43 @@ mi_status mi_nv12_bgr_equalize(mi_ctx* c, const uint8_t* nv12_in, uint8_t* nv12_
     HIPCHK(c, hipMemcpyAsync(out_direct ? nv12_out : c->h_pin_out, c->d_stage_out, bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (!out_direct) memcpy(nv12_out, c->h_pin_out, bytes);
+    return MI_OK;
+}
+
+mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
+                                        void* d_dst, size_t dst_step, size_t dst_frame_stride,
+                                        int width, int height, int n_frames, int code, void* stream)
+{
+    ENTER(c);
+    mi_status st = check_cvt420(c, d_src, src_step, d_dst, dst_step, width, height, n_frames, code);
+    if (st || width == 0 || height == 0 || n_frames == 0) return st;
+    const bool enc = code == MI_COLOR_BGR2YUV_I420;
+    if ((enc ? dst_step : src_step) != (size_t)width) return fail(c, MI_ERR_UNSUPPORTED, "device form: the planar image must be tightly packed (step == width)");
+    return cvt420_dev(c, pick_stream(c, stream), code, (const uint8_t*)d_src, (uint8_t*)d_dst, enc ? src_step : dst_step,
+                      enc ? src_frame_stride : dst_frame_stride, enc ? dst_frame_stride : src_frame_stride, width, height, n_frames);
+}
+
+mi_status mi_cvt_color_420_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height, int code)
+{
+    ENTER(c);
+    mi_status st = check_cvt420(c, src, src_step, dst, dst_step, width, height, 1, code);
+    if (st || width == 0 || height == 0) return st;
+    const bool enc = code == MI_COLOR_BGR2YUV_I420;
+    const size_t c3_row = (size_t)width * 3, c3_bytes = c3_row * height, pl_bytes = (size_t)width * height * 3 / 2;
+    const size_t in_row = enc ? c3_row : (size_t)width, in_rows = enc ? (size_t)height : (size_t)height * 3 / 2, in_bytes = enc ? c3_bytes : pl_bytes;
+    const size_t out_row = enc ? (size_t)width : c3_row, out_rows = enc ? (size_t)height * 3 / 2 : (size_t)height, out_bytes = enc ? pl_bytes : c3_bytes;
+    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, in_bytes))) return st;
+    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, out_bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, in_bytes))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, out_bytes))) return st;
+    hipStream_t s = c->stream;
+    for (size_t y = 0; y < in_rows; ++y) memcpy(c->h_pin_in + y * in_row, src + y * src_step, in_row);
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, c->h_pin_in, in_bytes, hipMemcpyHostToDevice, s));
+    st = cvt420_dev(c, s, code, c->d_stage_in, c->d_stage_out, c3_row, c3_bytes, pl_bytes, width, height, 1);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (size_t y = 0; y < out_rows; ++y) memcpy(dst + y * dst_step, c->h_pin_out + y * out_row, out_row);
     return MI_OK;
 }
 

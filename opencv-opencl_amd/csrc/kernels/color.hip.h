@@ -394,4 +394,47 @@ __global__ __launch_bounds__(kThreads) void nv12_bgr_apply_kernel(Nv12Job j, con
     }
 }
 
+// cv::cvtColor 4:2:0 codes as stand-alone conversions (same arithmetic as above, one 2x2 block per lane):
+// MODE 0: COLOR_BGR2YUV_I420 (1frameMeasure.cpp:32 prepares its input with it): CV_8UC3 -> Y plane, U plane, V plane (tight)
+// MODE 1: COLOR_YUV2BGR_NV12: tight NV12 -> CV_8UC3.        grid = (blocks, n_frames)
+struct Cvt420Job {
+    const uint8_t* src; uint8_t* dst;
+    long long c3_step, c3_frame;               // the interleaved CV_8UC3 side (src for MODE 0, dst for MODE 1)
+    long long planar_frame;                    // bytes between frames of the tight planar side
+    int width, height;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void cvt420_kernel(Cvt420Job j)
+{
+    const int f = blockIdx.y, bx_n = j.width >> 1;
+    const long long blocks = (long long)bx_n * (j.height >> 1), ysz = (long long)j.width * j.height;
+    for (long long bi = (long long)blockIdx.x * kThreads + threadIdx.x; bi < blocks; bi += (long long)gridDim.x * kThreads) {
+        const int by = (int)(bi / bx_n), bx = (int)(bi - (long long)by * bx_n);
+        if (MODE == 0) {
+            const uint8_t* r0 = j.src + (long long)f * j.c3_frame + (long long)(2 * by) * j.c3_step + 6 * bx;
+            const uint8_t* r1 = r0 + j.c3_step;
+            uint8_t* yo = j.dst + (long long)f * j.planar_frame + (long long)(2 * by) * j.width + 2 * bx;
+            uint8_t* uo = j.dst + (long long)f * j.planar_frame + ysz + (long long)by * bx_n + bx;
+            uint32_t U, V;
+            bt601_uv(r0[0], r0[1], r0[2], U, V);
+            yo[0] = (uint8_t)bt601_y(r0[0], r0[1], r0[2]); yo[1] = (uint8_t)bt601_y(r0[3], r0[4], r0[5]);
+            yo[j.width] = (uint8_t)bt601_y(r1[0], r1[1], r1[2]); yo[j.width + 1] = (uint8_t)bt601_y(r1[3], r1[4], r1[5]);
+            uo[0] = (uint8_t)U; uo[ysz >> 2] = (uint8_t)V;
+        } else {
+            const uint8_t* yp = j.src + (long long)f * j.planar_frame + (long long)(2 * by) * j.width + 2 * bx;
+            const uint8_t* uv = j.src + (long long)f * j.planar_frame + ysz + (long long)by * j.width + 2 * bx;
+            uint8_t* d0 = j.dst + (long long)f * j.c3_frame + (long long)(2 * by) * j.c3_step + 6 * bx;
+            uint8_t* d1 = d0 + j.c3_step;
+            int ruv, guv, buv;
+            bt601_uv_terms(uv[0], uv[1], ruv, guv, buv);
+            uint32_t b, g, r;
+            bt601_px_bgr(yp[0], ruv, guv, buv, b, g, r); d0[0] = (uint8_t)b; d0[1] = (uint8_t)g; d0[2] = (uint8_t)r;
+            bt601_px_bgr(yp[1], ruv, guv, buv, b, g, r); d0[3] = (uint8_t)b; d0[4] = (uint8_t)g; d0[5] = (uint8_t)r;
+            bt601_px_bgr(yp[j.width], ruv, guv, buv, b, g, r); d1[0] = (uint8_t)b; d1[1] = (uint8_t)g; d1[2] = (uint8_t)r;
+            bt601_px_bgr(yp[j.width + 1], ruv, guv, buv, b, g, r); d1[3] = (uint8_t)b; d1[4] = (uint8_t)g; d1[5] = (uint8_t)r;
+        }
+    }
+}
+
 }  // namespace mi

@@ -269,10 +269,25 @@ inline Ptr<CLAHE> createCLAHE(double clipLimit = 40.0, Size tileGridSize = Size(
 // cv::cvtColor(bgr, yuv, cv::COLOR_BGR2YUV) ... cv::cvtColor(yuv, bgr, cv::COLOR_YUV2BGR)   singlecolor.cpp:39/:66,
 //                                                                                           clahe1frame.cpp:83/:102
 constexpr int COLOR_BGR2YUV = MI_COLOR_BGR2YUV, COLOR_YUV2BGR = MI_COLOR_YUV2BGR;     // OpenCV's numeric values (82, 84)
+// 4:2:0 codes: cv::cvtColor(bgr, yuv, cv::COLOR_BGR2YUV_I420) prepares the bench input at 1frameMeasure.cpp:32;
+// COLOR_YUV2BGR_NV12 is its NV12 inverse (BASELINE config 5 read literally).  OpenCV's numeric values (128, 93).
+constexpr int COLOR_BGR2YUV_I420 = MI_COLOR_BGR2YUV_I420, COLOR_YUV2BGR_NV12 = MI_COLOR_YUV2BGR_NV12;
 
 inline void cvtColor(const Mat& src, Mat& dst, int code)
 {
-    MI_CV_ASSERT(code == COLOR_BGR2YUV || code == COLOR_YUV2BGR);
+    MI_CV_ASSERT(code == COLOR_BGR2YUV || code == COLOR_YUV2BGR || code == COLOR_BGR2YUV_I420 || code == COLOR_YUV2BGR_NV12);
+    if (code == COLOR_BGR2YUV_I420 || code == COLOR_YUV2BGR_NV12) {
+        const bool enc = code == COLOR_BGR2YUV_I420;
+        MI_CV_ASSERT(src.type() == (enc ? CV_8UC3 : CV_8UC1));
+        if (src.empty()) return;
+        const Mat s = src;                                               // keeps the data alive if dst aliases src
+        const int w = s.cols, h = enc ? s.rows : s.rows * 2 / 3;
+        MI_CV_ASSERT(w % 2 == 0 && (enc ? s.rows % 2 == 0 : s.rows % 3 == 0));   // OpenCV's own size checks
+        dst.create(enc ? h * 3 / 2 : h, w, enc ? CV_8UC1 : CV_8UC3);
+        mi_ctx* c = detail::thread_ctx();
+        detail::check(c, mi_cvt_color_420_u8(c, s.data, s.step, dst.data, dst.step, w, h, code), "mi_cvt_color_420_u8");
+        return;
+    }
     MI_CV_ASSERT(src.type() == CV_8UC3);
     if (src.empty()) return;
     const Mat s = src;

@@ -18,6 +18,7 @@ STREAM_CTX = C.c_void_p(-1).value      # MI_STREAM_CTX: the context's private st
 KERNEL_NAMES = ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
                 "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel"]
 COLOR_BGR2YUV, COLOR_YUV2BGR = 82, 84
+COLOR_YUV2BGR_NV12, COLOR_BGR2YUV_I420 = 93, 128
 OP_EQUALIZE, OP_CLAHE = 0, 1
 
 # every extern "C" symbol include/mi_lumaeq.h declares (tests check the .so exports them all)
@@ -33,7 +34,7 @@ DECLARED_SYMBOLS = [
     "mi_ctx_synchronize", "mi_ctx_set_option",
     "mi_host_register", "mi_host_unregister", "mi_clahe_u16", "mi_clahe_u16_batch_dev",
     "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
-    "mi_nv12_bgr_equalize", "mi_nv12_bgr_equalize_batch_dev",
+    "mi_nv12_bgr_equalize", "mi_nv12_bgr_equalize_batch_dev", "mi_cvt_color_420_u8", "mi_cvt_color_420_u8_batch_dev",
 ]
 
 _K = len(KERNEL_NAMES)
@@ -101,6 +102,8 @@ def lib() -> C.CDLL:
     L.mi_bgr_luma_op_u8c3.argtypes = [vp, vp, sz, vp, sz, i, i, i, d, i, i]
     L.mi_bgr_luma_op_u8c3_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, d, i, i, vp]
     L.mi_nv12_bgr_equalize.argtypes = [vp, vp, vp, i, i]
+    L.mi_cvt_color_420_u8.argtypes = [vp, vp, sz, vp, sz, i, i, i]
+    L.mi_cvt_color_420_u8_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, i, vp]
     L.mi_nv12_bgr_equalize_batch_dev.argtypes = [vp, vp, sz, vp, sz, i, i, i, vp]
     L.mi_clahe_u16.argtypes = [vp, vp, sz, vp, sz, i, i, d, i, i]
     L.mi_clahe_u16_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, d, i, i, vp]
@@ -371,6 +374,34 @@ class Context:
         self._chk(lib().mi_bgr_luma_op_u8c3_batch_dev(self._h, _dptr(src), width * 3, width * 3 * height, _dptr(dst), width * 3,
                                                       width * 3 * height, width, height, n_frames, int(op), float(clip_limit),
                                                       int(tiles_x), int(tiles_y), stream), "mi_bgr_luma_op_u8c3_batch_dev")
+
+    def cvt_color_420(self, src: np.ndarray, code: int, dst: np.ndarray | None = None) -> np.ndarray:
+        """cv::cvtColor with COLOR_BGR2YUV_I420 (HxWx3 -> (H*3/2)xW) or COLOR_YUV2BGR_NV12 ((H*3/2)xW -> HxWx3)."""
+        if not isinstance(src, np.ndarray) or src.dtype != np.uint8:
+            raise MiError(2, "cvt_color_420", "expected a uint8 ndarray")
+        if code == COLOR_BGR2YUV_I420:
+            src = self._host3(src, "cvt_color_420")
+            h, w = src.shape[:2]
+            shape = (h * 3 // 2, w)
+        else:
+            src = _host2d(src, "cvt_color_420")
+            if src.shape[0] % 3:
+                raise MiError(1, "cvt_color_420", "NV12 matrix must have H*3/2 rows")
+            h, w = src.shape[0] * 2 // 3, src.shape[1]
+            shape = (h, w, 3)
+        if dst is None or dst.shape != shape:
+            dst = np.empty(shape, np.uint8)
+        sstep = int(src.strides[0]) if src.shape[0] > 1 else max(int(src.strides[0]), 1)
+        dstep = int(dst.strides[0]) if dst.shape[0] > 1 else max(int(dst.strides[0]), 1)
+        self._chk(lib().mi_cvt_color_420_u8(self._h, src.ctypes.data, sstep, dst.ctypes.data, dstep, w, h, int(code)), "mi_cvt_color_420_u8")
+        return dst
+
+    def cvt_color_420_batch_dev(self, src, dst, width, height, n_frames, code, stream=0):
+        c3, pl = width * 3, width
+        enc = code == COLOR_BGR2YUV_I420
+        self._chk(lib().mi_cvt_color_420_u8_batch_dev(self._h, _dptr(src), c3 if enc else pl, (c3 * height) if enc else pl * height * 3 // 2,
+                                                      _dptr(dst), pl if enc else c3, (pl * height * 3 // 2) if enc else c3 * height,
+                                                      width, height, n_frames, int(code), stream), "mi_cvt_color_420_u8_batch_dev")
 
     def nv12_bgr_equalize(self, nv12: np.ndarray, width: int, height: int, out: np.ndarray | None = None) -> np.ndarray:
         """NV12 -> BGR -> equalizeHist on B, G, R -> NV12 (BASELINE.json config 5 read literally)."""

@@ -63,6 +63,8 @@ def lib() -> ctypes.CDLL:
         L.orc_nv12_to_bgr.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
         L.orc_bgr_to_nv12.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
         L.orc_nv12_bgr_equalize.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
+        L.orc_bgr_to_i420.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
+        L.orc_bgr_to_i420.restype = ctypes.c_int
         for f in (L.orc_bgr2yuv_u8, L.orc_yuv2bgr_u8, L.orc_bgr_luma_op, L.orc_nv12_to_bgr, L.orc_bgr_to_nv12, L.orc_nv12_bgr_equalize):
             f.restype = ctypes.c_int
         for f in (L.orc_hist_u8, L.orc_equalize_lut, L.orc_lut_apply_u8, L.orc_equalize_hist_u8,
@@ -242,6 +244,16 @@ def bgr_to_nv12(bgr: np.ndarray) -> np.ndarray:
     dst = np.empty(w * h * 3 // 2, np.uint8)
     if dst.size:
         _check(lib().orc_bgr_to_nv12(_ptr(bgr), _ptr(dst), w, h), "bgr_to_nv12")
+    return dst
+
+
+def bgr_to_i420(bgr: np.ndarray) -> np.ndarray:
+    """cv::cvtColor(bgr, COLOR_BGR2YUV_I420) (1frameMeasure.cpp:32): returns the (H*3/2, W) CV_8UC1 matrix."""
+    bgr = np.ascontiguousarray(_as3(bgr))
+    h, w = bgr.shape[:2]
+    dst = np.empty((h * 3 // 2, w), np.uint8)
+    if dst.size:
+        _check(lib().orc_bgr_to_i420(_ptr(bgr), _ptr(dst), w, h), "bgr_to_i420")
     return dst
 
 

@@ -193,3 +193,20 @@ int orc_nv12_bgr_equalize(const uint8_t* nv12_in, uint8_t* nv12_out, int width, 
     free(bgr); free(p); free(q);
     return rc;
 }
+
+/* cv::cvtColor(bgr, yuv, COLOR_BGR2YUV_I420) as the reference calls it (1frameMeasure.cpp:32): tight CV_8UC3 in, tight
+ * W x H*3/2 CV_8UC1 out = Y plane, U plane (W/2 x H/2), V plane.  Same arithmetic as orc_bgr_to_nv12, planar chroma. */
+int orc_bgr_to_i420(const uint8_t* bgr, uint8_t* i420, int width, int height)
+{
+    if (width < 0 || height < 0 || (width & 1) || (height & 1)) return 1;
+    if (width == 0 || height == 0) return 0;
+    if (!bgr || !i420) return 1;
+    const size_t n = (size_t)width * height;
+    uint8_t* nv = (uint8_t*)malloc(n * 3 / 2);
+    if (!nv) return 4;
+    const int rc = orc_bgr_to_nv12(bgr, nv, width, height);
+    memcpy(i420, nv, n);
+    for (size_t i = 0; i < n / 4; ++i) { i420[n + i] = nv[n + 2 * i]; i420[n + n / 4 + i] = nv[n + 2 * i + 1]; }
+    free(nv);
+    return rc;
+}

@@ -17,6 +17,8 @@ int orc_nv12_frame(const uint8_t*, uint8_t*, int, int, int, int, double, int, in
 int orc_bgr_luma_op(const uint8_t*, uint8_t*, int, int, int, double, int, int);
 int orc_bgr2yuv_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int);
 int orc_nv12_bgr_equalize(const uint8_t*, uint8_t*, int, int);
+int orc_bgr_to_i420(const uint8_t*, uint8_t*, int, int);
+int orc_nv12_to_bgr(const uint8_t*, uint8_t*, int, int);
 int orc_clahe_u16(const uint16_t*, size_t, uint16_t*, size_t, int, int, double, int, int);
 }
 
@@ -154,6 +156,20 @@ int main()
         bool threw = false;
         try { equalizeHistChannelsNV12(f.data(), got.data(), 321, CH); } catch (const std::exception&) { threw = true; }
         EXPECT(threw);
+        // 1frameMeasure.cpp:30-36: cvtColor(bgr, yuv, COLOR_BGR2YUV_I420), then a Y-plane view over yuv.data
+        std::vector<uint8_t> bgrv((size_t)CW * CH * 3), i420((size_t)CW * CH * 3 / 2), back((size_t)CW * CH * 3);
+        for (auto& v : bgrv) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (uint8_t)(s >> 40); }
+        Mat bgr(CH, CW, CV_8UC3, bgrv.data());
+        Mat yuv;
+        cvtColor(bgr, yuv, COLOR_BGR2YUV_I420);
+        orc_bgr_to_i420(bgrv.data(), i420.data(), CW, CH);
+        EXPECT(yuv.rows == CH * 3 / 2 && yuv.cols == CW && yuv.type() == CV_8UC1 && memcmp(yuv.data, i420.data(), i420.size()) == 0);
+        Mat y_plane(CH, CW, CV_8UC1, yuv.data);
+        EXPECT(memcmp(y_plane.data, i420.data(), (size_t)CW * CH) == 0);
+        Mat nv(CH * 3 / 2, CW, CV_8UC1, f.data()), bgr2;
+        cvtColor(nv, bgr2, COLOR_YUV2BGR_NV12);
+        orc_nv12_to_bgr(f.data(), back.data(), CW, CH);
+        EXPECT(bgr2.rows == CH && bgr2.type() == CV_8UC3 && memcmp(bgr2.data, back.data(), back.size()) == 0);
     }
     // --- 16-bit CLAHE through the same cv::CLAHE-shaped object
     {

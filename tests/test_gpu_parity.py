@@ -689,3 +689,43 @@ def test_nv12_bgr_channel_equalize_batch_and_errors(ctx):
         ctx.nv12_bgr_equalize_batch_dev(0, 0, 16, 16, 1)
     ctx.nv12_bgr_equalize_batch_dev(0, 0, 0, 0, 0)
     assert ctx.nv12_bgr_equalize(np.zeros(0, np.uint8), 0, 0).size == 0
+
+
+@pytest.mark.parametrize("size", [(2, 2), (6, 4), (62, 34), (640, 360), (1920, 1080)], ids=str)
+def test_cvt_color_420_codes(ctx, size):
+    """cv::cvtColor COLOR_BGR2YUV_I420 (1frameMeasure.cpp:32) and COLOR_YUV2BGR_NV12 vs the oracle, host and device forms."""
+    import torch
+    w, h = size
+    bgr = _bgr(w, h, 77)
+    want_i420 = oracle.bgr_to_i420(bgr)
+    assert np.array_equal(ctx.cvt_color_420(bgr, mi_lumaeq.COLOR_BGR2YUV_I420), want_i420)
+    nv = _nv12_frames(w, h, 1, 78)[0].reshape(h * 3 // 2, w)
+    want_bgr = oracle.nv12_to_bgr(nv, w, h)
+    assert np.array_equal(ctx.cvt_color_420(nv, mi_lumaeq.COLOR_YUV2BGR_NV12), want_bgr)
+    # strided host views on both sides
+    big = np.zeros((h + 3, w + 5, 3), np.uint8); big[1:h + 1, 2:w + 2] = bgr
+    outbig = np.zeros((h * 3 // 2 + 2, w + 7), np.uint8)
+    ctx.cvt_color_420(big[1:h + 1, 2:w + 2], mi_lumaeq.COLOR_BGR2YUV_I420, dst=outbig[1:h * 3 // 2 + 1, 3:w + 3])
+    assert np.array_equal(outbig[1:h * 3 // 2 + 1, 3:w + 3], want_i420) and outbig[0].sum() == 0 and outbig[:, :3].sum() == 0
+    # device batch
+    n = 3
+    d_bgr = torch.from_numpy(np.stack([_bgr(w, h, 80 + k) for k in range(n)])).cuda()
+    d_pl = torch.empty((n, h * 3 // 2, w), dtype=torch.uint8, device="cuda")
+    ctx.cvt_color_420_batch_dev(d_bgr, d_pl, w, h, n, mi_lumaeq.COLOR_BGR2YUV_I420)
+    d_nv = torch.from_numpy(_nv12_frames(w, h, n, 90)).cuda()
+    d_out = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    ctx.cvt_color_420_batch_dev(d_nv, d_out, w, h, n, mi_lumaeq.COLOR_YUV2BGR_NV12)
+    torch.cuda.synchronize()
+    for k in range(n):
+        assert np.array_equal(d_pl[k].cpu().numpy(), oracle.bgr_to_i420(d_bgr[k].cpu().numpy())), k
+        assert np.array_equal(d_out[k].cpu().numpy(), oracle.nv12_to_bgr(d_nv[k].cpu().numpy(), w, h)), k
+
+
+def test_cvt_color_420_errors(ctx):
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.cvt_color_420(np.zeros((3, 4, 3), np.uint8), mi_lumaeq.COLOR_BGR2YUV_I420)          # odd height
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.cvt_color_420_batch_dev(0, 0, 16, 16, 1, mi_lumaeq.COLOR_BGR2YUV_I420)               # null pointers
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.cvt_color_420_batch_dev(1, 1, 16, 16, 1, 82)                                          # not a 4:2:0 code
+    ctx.cvt_color_420_batch_dev(0, 0, 0, 0, 0, mi_lumaeq.COLOR_BGR2YUV_I420)

@@ -213,6 +213,12 @@ def test_nv12_bgr_channel_equalize_oracle():
     for c in range(3):
         bgr[..., c] = oracle.equalize_hist(np.ascontiguousarray(bgr[..., c]))
     assert np.array_equal(oracle.nv12_bgr_equalize(a, w, h), oracle.bgr_to_nv12(bgr))
+    # COLOR_BGR2YUV_I420 (1frameMeasure.cpp:32): same values as the NV12 encode, planar chroma, (H*3/2, W) matrix
+    i420 = oracle.bgr_to_i420(bgr)
+    nvv = oracle.bgr_to_nv12(bgr)
+    assert i420.shape == (h * 3 // 2, w)
+    assert np.array_equal(i420.reshape(-1)[:w * h], nvv[:w * h])
+    assert np.array_equal(i420.reshape(-1)[w * h:w * h * 5 // 4], nvv[w * h::2]) and np.array_equal(i420.reshape(-1)[w * h * 5 // 4:], nvv[w * h + 1::2])
     # odd sizes are rejected (OpenCV asserts even dimensions for 4:2:0)
     with pytest.raises(ValueError):
         oracle.nv12_bgr_equalize(np.zeros(3 * 2 * 3 // 2, np.uint8), 3, 2)
