@@ -182,7 +182,21 @@ __device__ __forceinline__ u32x4 clahe_vec16(const uint32_t* quad, u32x4 q, cons
 // Float-table variant of the 16-pixel body: the LDS entry is {a, c, b, d} as f32, so one ds_read_b128 delivers
 // two register pairs that feed v_pk_mul_f32 / v_pk_add_f32 directly (each lane of a packed op is an ordinary
 // individually rounded f32 op): 4 packed ops + 1 add per pixel, no byte->float converts.
-__device__ __forceinline__ u32x4 clahe_vec16_f32(const f32x4* quadf, u32x4 q, const int* poff, const float* xa, const float* xa1, float ya, float ya1)
+// The column weights live as ONE register pair {xa1, xa} per pixel; op_sel broadcasts one half of it to both lanes of
+// the packed multiply (the compiler would otherwise keep {xa1, xa1} and {xa, xa}: 32 more VGPRs per lane).
+__device__ __forceinline__ f32x2 pk_mul_bcast_lo(f32x2 a, f32x2 x)      // {a.x * x.x, a.y * x.x}
+{
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(x));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_mul_bcast_hi(f32x2 a, f32x2 x)      // {a.x * x.y, a.y * x.y}
+{
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(x));
+    return d;
+}
+__device__ __forceinline__ u32x4 clahe_vec16_f32(const f32x4* quadf, u32x4 q, const int* poff, const f32x2* xw, float ya, float ya1)
 {
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
     const f32x2 yv = {ya1, ya};
@@ -199,8 +213,7 @@ __device__ __forceinline__ u32x4 clahe_vec16_f32(const f32x4* quadf, u32x4 q, co
         for (int b = 0; b < 4; ++b) {
             const int j = k * 4 + b;
             const f32x2 ac = {e[b].x, e[b].y}, bd = {e[b].z, e[b].w};
-            const f32x2 x1 = {xa1[j], xa1[j]}, x0v = {xa[j], xa[j]};
-            tb[b] = (ac * x1 + bd * x0v) * yv;                   // -ffp-contract=off: pk_mul, pk_mul, pk_add, pk_mul
+            tb[b] = (pk_mul_bcast_lo(ac, xw[j]) + pk_mul_bcast_hi(bd, xw[j])) * yv;      // pk_mul, pk_mul, pk_add, pk_mul
         }
         uint32_t acc = 0;
 #pragma unroll
@@ -251,6 +264,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
     const int x0 = (blockIdx.z * groups + grp) * kInterpPx;
     if (phase < phases && x0 < g.width) {
         float xa[kInterpPx], xa1[kInterpPx];
+        f32x2 xw[kInterpPx];                                   // {xa1, xa} pairs for the packed float-table body
         int poff[kInterpPx];
 #pragma unroll
         for (int j = 0; j < kInterpPx; ++j) {
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
             const int tx1 = floor_f32_to_int(txf);
             xa[j] = __fsub_rn(txf, (float)tx1);
             xa1[j] = __fsub_rn(1.0f, xa[j]);
+            xw[j].x = xa1[j]; xw[j].y = xa[j];
             int pr = tx1 + 1;                                  // pair index; columns beyond the frame are never used
             pr = pr < 0 ? 0 : (pr > g.tiles_x ? g.tiles_x : pr);
             poff[j] = pr << 8;
@@ -277,13 +292,23 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
             // The loop is VALU-issue bound (~290 instructions per 16 pixels: 64 byte->float converts, 144 blend
             // flops, 16 LDS reads); an explicit 2-row software pipeline measured 11 % SLOWER than letting the
             // other resident waves cover the load latency, so the row loop stays simple.
-            for (; y < ya_hi; y += phases) {
-                const u32x4 q = *reinterpret_cast<const u32x4_u*>(src + (long long)y * p.src_step + x0);
-                const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+            auto do_row = [&](int yy, const u32x4& q) {
+                const float tyf = __fsub_rn(__fmul_rn((float)yy, g.inv_th), 0.5f);
                 const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
-                *reinterpret_cast<u32x4_u*>(dst + (long long)y * p.dst_step + x0) =
-                    FT ? clahe_vec16_f32(quadf, q, poff, xa, xa1, ya, ya1) : clahe_vec16(quad, q, poff, xa, xa1, ya, ya1);
+                *reinterpret_cast<u32x4_u*>(dst + (long long)yy * p.dst_step + x0) =
+                    FT ? clahe_vec16_f32(quadf, q, poff, xw, ya, ya1) : clahe_vec16(quad, q, poff, xa, xa1, ya, ya1);
+            };
+            constexpr int kRowsInFlight = FT ? 4 : 2;         // register budget: stay at 4 waves/SIMD (<= 128 VGPRs)
+            // kRowsInFlight rows are loaded before the first is blended: a lane then has 64 B in flight instead of 16, and a
+            // wave pays the HBM latency once per four rows (the kernel sits at 4 waves/SIMD, too few to hide it otherwise)
+            for (; y + (kRowsInFlight - 1) * phases < ya_hi; y += kRowsInFlight * phases) {
+                u32x4 q[kRowsInFlight];
+#pragma unroll
+                for (int k = 0; k < kRowsInFlight; ++k) q[k] = *reinterpret_cast<const u32x4_u*>(src + (long long)(y + k * phases) * p.src_step + x0);
+#pragma unroll
+                for (int k = 0; k < kRowsInFlight; ++k) { do_row(y + k * phases, q[k]); __builtin_amdgcn_sched_barrier(0); }
             }
+            for (; y < ya_hi; y += phases) do_row(y, *reinterpret_cast<const u32x4_u*>(src + (long long)y * p.src_step + x0));
         } else {
             for (; y < ya_hi; y += phases) {
                 const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);

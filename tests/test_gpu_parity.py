@@ -729,3 +729,43 @@ def test_cvt_color_420_errors(ctx):
     with pytest.raises(mi_lumaeq.MiError):
         ctx.cvt_color_420_batch_dev(1, 1, 16, 16, 1, 82)                                          # not a 4:2:0 code
     ctx.cvt_color_420_batch_dev(0, 0, 0, 0, 0, mi_lumaeq.COLOR_BGR2YUV_I420)
+
+
+def test_real_photograph(ctx):
+    """The reference's own bench image (luma plane, 1919 x 1079; tests/golden/make_photo_fixture.py): smooth gradients and
+    large flat areas -- hot histogram bins and LDS broadcasts that the synthetic distributions do not produce."""
+    import torch
+    from pathlib import Path
+    z = np.load(Path(__file__).parent / "golden" / "photo_luma_1919x1079.npz")
+    y, crop = z["y"], z["bgr_crop"]
+    assert np.array_equal(ctx.equalize_hist(y), oracle.equalize_hist(y))
+    for cfg in [(2.0, 8, 8), (3.0, 4, 4), (40.0, 16, 2)]:
+        assert np.array_equal(ctx.clahe(y, *cfg), oracle.clahe(y, *cfg)), cfg
+    assert np.array_equal(ctx.bgr_luma_op(crop, mi_lumaeq.OP_EQUALIZE), oracle.bgr_luma_op(crop, 0))
+    assert np.array_equal(ctx.bgr_luma_op(crop, mi_lumaeq.OP_CLAHE, 3.0, 4, 4), oracle.bgr_luma_op(crop, 1, 3.0, 4, 4))
+    # 4K NV12 frames built from the photo (tiled and shifted), through the fused batch path and CLAHE
+    w, h, n = 3840, 2160, 3
+    big = np.tile(y, (3, 3))
+    frames = np.empty((n, w * h * 3 // 2), np.uint8)
+    for k in range(n):
+        frames[k, : w * h] = big[37 * k: 37 * k + h, 91 * k: 91 * k + w].reshape(-1)
+        frames[k, w * h:] = np.random.default_rng(k).integers(0, 256, w * h // 2, dtype=np.uint8)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.empty_like(d_in)
+    ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.UV_COPY)
+    ctx.synchronize()
+    got = d_out.cpu().numpy()
+    for k in range(n):
+        yk = frames[k, : w * h].reshape(h, w)
+        assert np.array_equal(got[k, : w * h].reshape(h, w), oracle.equalize_hist(yk)), k
+        assert np.array_equal(got[k, w * h:], frames[k, w * h:]), k
+    ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.UV_FILL128, 2.0, 8, 8)
+    ctx.synchronize()
+    got = d_out.cpu().numpy()
+    for k in range(n):
+        yk = frames[k, : w * h].reshape(h, w)
+        assert np.array_equal(got[k, : w * h].reshape(h, w), oracle.clahe(yk, 2.0, 8, 8)), k
+        assert (got[k, w * h:] == 128).all()
+    ctx.nv12_bgr_equalize_batch_dev(d_in, d_out, w, h, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out[0].cpu().numpy(), oracle.nv12_bgr_equalize(frames[0], w, h))

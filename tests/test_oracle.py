@@ -281,3 +281,21 @@ def test_oracle_under_sanitizers(tmp_path):
     assert b.returncode == 0, b.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "clean" in r.stdout, r.stdout + r.stderr
+
+
+def test_photo_fixture():
+    """Real-photograph input vector (tests/golden/make_photo_fixture.py; odd-sized, so CLAHE pads): the C oracle still
+    produces the recorded bytes, and the independent numpy restatement agrees on it."""
+    import zlib
+    z = np.load(Path(__file__).parent / "golden" / "photo_luma_1919x1079.npz")
+    y, crop = z["y"], z["bgr_crop"]
+    assert y.shape == (1079, 1919) and crop.shape == (256, 384, 3)
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes())
+    eq = oracle.equalize_hist(y)
+    assert crc(eq) == int(z["crc_equalize"])
+    assert np.array_equal(eq, oracle.np_equalize_hist(y))
+    c8 = oracle.clahe(y, 2.0, 8, 8)
+    assert crc(c8) == int(z["crc_clahe_2_8x8"]) and crc(oracle.clahe(y, 3.0, 4, 4)) == int(z["crc_clahe_3_4x4"])
+    assert np.array_equal(c8, oracle.np_clahe(y, 2.0, 8, 8))
+    assert crc(oracle.bgr_luma_op(crop, 0)) == int(z["crc_bgr_luma_equalize_crop"])
+    assert crc(oracle.bgr_luma_op(crop, 1, 3.0, 4, 4)) == int(z["crc_bgr_luma_clahe_crop"])
