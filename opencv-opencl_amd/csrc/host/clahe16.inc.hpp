@@ -71,19 +71,12 @@ mi_status mi_clahe_u16(mi_ctx* c, const uint16_t* src, size_t src_step, uint16_t
     mi_status st = check_u16(c, src, src_step, dst, dst_step, width, height, 1, tiles_x, tiles_y);
     if (st || width == 0 || height == 0) return st;
     const size_t row = (size_t)width * 2, bytes = row * height;
-    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, bytes))) return st;
-    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     hipStream_t s = c->stream;
-    for (int y = 0; y < height; ++y) memcpy(c->h_pin_in + (size_t)y * row, (const uint8_t*)src + (size_t)y * src_step, row);
-    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, c->h_pin_in, bytes, hipMemcpyHostToDevice, s));
+    if ((st = stage_in(c, s, (const uint8_t*)src, src_step, row, (size_t)height))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     st = clahe16_dev(c, s, c->d_stage_in, row, bytes, c->d_stage_out, row, bytes, width, height, 1, clip_limit, tiles_x, tiles_y);
     if (st) return st;
-    HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    for (int y = 0; y < height; ++y) memcpy((uint8_t*)dst + (size_t)y * dst_step, c->h_pin_out + (size_t)y * row, row);
-    return MI_OK;
+    return stage_out(c, s, (uint8_t*)dst, dst_step, row, (size_t)height);
 }
 
 }  // extern "C"

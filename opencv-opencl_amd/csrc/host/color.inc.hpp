@@ -181,21 +181,14 @@ mi_status color_host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t*
                         bool luma, int code_or_op, double clip, int tx, int ty)
 {
     const size_t row = (size_t)width * 3, bytes = row * height;
-    mi_status st;
-    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, bytes))) return st;
-    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     hipStream_t s = c->stream;
-    for (int y = 0; y < height; ++y) memcpy(c->h_pin_in + (size_t)y * row, src + (size_t)y * src_step, row);
-    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, c->h_pin_in, bytes, hipMemcpyHostToDevice, s));
+    mi_status st = stage_in(c, s, src, src_step, row, (size_t)height);
+    if (st) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     Color3Args a{c->d_stage_in, row, bytes, c->d_stage_out, row, bytes, width, height, 1};
     st = luma ? bgr_luma_dev(c, s, a, code_or_op, clip, tx, ty) : cvt_color_dev(c, s, a, code_or_op);
     if (st) return st;
-    HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * dst_step, c->h_pin_out + (size_t)y * row, row);
-    return MI_OK;
+    return stage_out(c, s, dst, dst_step, row, (size_t)height);
 }
 
 }  // namespace
@@ -271,22 +264,12 @@ mi_status mi_nv12_bgr_equalize(mi_ctx* c, const uint8_t* nv12_in, uint8_t* nv12_
     mi_status st = check_nv12_420(c, nv12_in, nv12_out, width, height, 1);
     if (st || width == 0 || height == 0) return st;
     const size_t bytes = (size_t)width * height * 3 / 2;
-    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     hipStream_t s = c->stream;
-    const bool in_direct = host_range_pinned(nv12_in, bytes), out_direct = host_range_pinned(nv12_out, bytes);
-    if (!in_direct) {
-        if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, bytes))) return st;
-        memcpy(c->h_pin_in, nv12_in, bytes);
-    }
-    if (!out_direct && (st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, bytes))) return st;
-    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, in_direct ? nv12_in : c->h_pin_in, bytes, hipMemcpyHostToDevice, s));
+    if ((st = stage_in(c, s, nv12_in, bytes, bytes, 1))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     st = nv12_bgr_equalize_dev(c, s, c->d_stage_in, bytes, c->d_stage_out, bytes, width, height, 1);
     if (st) return st;
-    HIPCHK(c, hipMemcpyAsync(out_direct ? nv12_out : c->h_pin_out, c->d_stage_out, bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (!out_direct) memcpy(nv12_out, c->h_pin_out, bytes);
-    return MI_OK;
+    return stage_out(c, s, nv12_out, bytes, bytes, 1);
 }
 
 mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
@@ -309,21 +292,14 @@ mi_status mi_cvt_color_420_u8(mi_ctx* c, const uint8_t* src, size_t src_step, ui
     if (st || width == 0 || height == 0) return st;
     const bool enc = code == MI_COLOR_BGR2YUV_I420;
     const size_t c3_row = (size_t)width * 3, c3_bytes = c3_row * height, pl_bytes = (size_t)width * height * 3 / 2;
-    const size_t in_row = enc ? c3_row : (size_t)width, in_rows = enc ? (size_t)height : (size_t)height * 3 / 2, in_bytes = enc ? c3_bytes : pl_bytes;
+    const size_t in_row = enc ? c3_row : (size_t)width, in_rows = enc ? (size_t)height : (size_t)height * 3 / 2;
     const size_t out_row = enc ? (size_t)width : c3_row, out_rows = enc ? (size_t)height * 3 / 2 : (size_t)height, out_bytes = enc ? pl_bytes : c3_bytes;
-    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, in_bytes))) return st;
-    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, out_bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, in_bytes))) return st;
-    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, out_bytes))) return st;
     hipStream_t s = c->stream;
-    for (size_t y = 0; y < in_rows; ++y) memcpy(c->h_pin_in + y * in_row, src + y * src_step, in_row);
-    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, c->h_pin_in, in_bytes, hipMemcpyHostToDevice, s));
+    if ((st = stage_in(c, s, src, src_step, in_row, in_rows))) return st;
+    if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, out_bytes))) return st;
     st = cvt420_dev(c, s, code, c->d_stage_in, c->d_stage_out, c3_row, c3_bytes, pl_bytes, width, height, 1);
     if (st) return st;
-    HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, out_bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    for (size_t y = 0; y < out_rows; ++y) memcpy(dst + y * dst_step, c->h_pin_out + y * out_row, out_row);
-    return MI_OK;
+    return stage_out(c, s, dst, dst_step, out_row, out_rows);
 }
 
 }  // extern "C"

@@ -31,4 +31,33 @@ void copy_rows(uint8_t* dst, size_t dst_step, const uint8_t* src, size_t src_ste
     for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * dst_step, src + (size_t)y * src_step, (size_t)width);
 }
 
+// Generic host image <-> device staging for the less travelled host forms (colour, 4:2:0, 16-bit): `rows` rows of `row`
+// bytes at pitch `step`.  Contiguous images go to the copy engine as they are (pinned or pageable, see host_op());
+// strided views are packed through the context's pinned buffers.  stage_out() synchronises the stream.
+mi_status stage_in(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t step, size_t row, size_t rows)
+{
+    const size_t bytes = row * rows;
+    mi_status st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, bytes);
+    if (st) return st;
+    const bool direct = (step == row || rows == 1) && (c->host_direct || host_range_pinned(src, bytes));
+    if (!direct) {
+        if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, bytes))) return st;
+        copy_rows(c->h_pin_in, row, src, step, (int)row, (int)rows);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_stage_in, direct ? src : c->h_pin_in, bytes, hipMemcpyHostToDevice, s));
+    return MI_OK;
+}
+
+mi_status stage_out(mi_ctx* c, hipStream_t s, uint8_t* dst, size_t step, size_t row, size_t rows)
+{
+    const size_t bytes = row * rows;
+    const bool direct = (step == row || rows == 1) && (c->host_direct || host_range_pinned(dst, bytes));
+    mi_status st;
+    if (!direct && (st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, bytes))) return st;
+    HIPCHK(c, hipMemcpyAsync(direct ? dst : c->h_pin_out, c->d_stage_out, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (!direct) copy_rows(dst, step, c->h_pin_out, row, (int)row, (int)rows);
+    return MI_OK;
+}
+
 }  // namespace

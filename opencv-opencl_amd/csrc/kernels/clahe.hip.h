@@ -308,7 +308,10 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
 #pragma unroll
                 for (int k = 0; k < kRowsInFlight; ++k) { do_row(y + k * phases, q[k]); __builtin_amdgcn_sched_barrier(0); }
             }
-            for (; y < ya_hi; y += phases) do_row(y, *reinterpret_cast<const u32x4_u*>(src + (long long)y * p.src_step + x0));
+            for (; y < ya_hi; y += phases) {
+                const u32x4 q = *reinterpret_cast<const u32x4_u*>(src + (long long)y * p.src_step + x0);
+                do_row(y, q);
+            }
         } else {
             for (; y < ya_hi; y += phases) {
                 const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
