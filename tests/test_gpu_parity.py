@@ -769,3 +769,26 @@ def test_real_photograph(ctx):
     ctx.nv12_bgr_equalize_batch_dev(d_in, d_out, w, h, 1)
     torch.cuda.synchronize()
     assert np.array_equal(d_out[0].cpu().numpy(), oracle.nv12_bgr_equalize(frames[0], w, h))
+
+
+def test_host_forms_staged_and_direct_agree(ctx):
+    """Option "host_direct": contiguous host planes go to the copy engine as they are (default) or through the context's
+    pinned staging buffers (0) -- same bytes either way, for every host-pointer form."""
+    w, h = 640, 360
+    y = synth.y_plane(w, h, "D2", 3)
+    nv = _nv12_frames(w, h, 1, 4)[0]
+    bgr = _bgr(w, h, 5)
+    s16 = (np.random.default_rng(6).integers(0, 4096, (h, w))).astype(np.uint16)
+    try:
+        outs = []
+        for direct in (1, 0):
+            ctx.set_option("host_direct", direct)
+            outs.append((ctx.equalize_hist(y), ctx.clahe(y, 2.0, 8, 8), ctx.equalize_hist_nv12(nv, w, h, mi_lumaeq.UV_COPY),
+                         ctx.clahe_nv12(nv, w, h, mi_lumaeq.UV_FILL128, 3.0, 4, 4), ctx.bgr_luma_op(bgr, mi_lumaeq.OP_EQUALIZE),
+                         ctx.cvt_color(bgr, mi_lumaeq.COLOR_BGR2YUV), ctx.cvt_color_420(bgr, mi_lumaeq.COLOR_BGR2YUV_I420),
+                         ctx.nv12_bgr_equalize(nv, w, h), ctx.clahe16(s16, 2.0, 8, 8)))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+        assert np.array_equal(outs[0][0], oracle.equalize_hist(y)) and np.array_equal(outs[1][1], oracle.clahe(y, 2.0, 8, 8))
+    finally:
+        ctx.set_option("host_direct", 1)
