@@ -413,13 +413,16 @@ public:
     CLAHE_MI(double clip, cv::Size t) : clip_(clip), tiles_(t) {}
     void apply(cv::InputArray _src, cv::OutputArray _dst) CV_OVERRIDE
     {
-        CV_Assert(_src.type() == CV_8UC1);
+        CV_Assert(_src.type() == CV_8UC1 || _src.type() == CV_16UC1);       // clahe.cpp accepts exactly these two
         if (_src.empty()) return;
         cv::Mat src = _src.getMat();
         _dst.create(src.size(), src.type());
         cv::Mat dst = _dst.getMat();
         mi_ctx* c = micv::detail::thread_ctx();
-        throw_cv(c, mi_clahe_u8(c, src.data, src.step, dst.data, dst.step, src.cols, src.rows, clip_, tiles_.width, tiles_.height), "mi_clahe_u8");
+        if (src.type() == CV_8UC1)
+            throw_cv(c, mi_clahe_u8(c, src.data, src.step, dst.data, dst.step, src.cols, src.rows, clip_, tiles_.width, tiles_.height), "mi_clahe_u8");
+        else
+            throw_cv(c, mi_clahe_u16(c, src.ptr<uint16_t>(), src.step, dst.ptr<uint16_t>(), dst.step, src.cols, src.rows, clip_, tiles_.width, tiles_.height), "mi_clahe_u16");
     }
     void setClipLimit(double v) CV_OVERRIDE { clip_ = v; }
     double getClipLimit() const CV_OVERRIDE { return clip_; }
