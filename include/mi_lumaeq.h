@@ -224,7 +224,7 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * capturable).
  * Options (mi_ctx_set_option): "fused" (1/0: single-read fused kernel vs the three-kernel path),
  * "fused_wgs_per_cu" (persistent workgroups per CU, default 4), "fused_vpt" (8/16/20/24 16-byte vectors a
- * thread keeps in registers, default 20), "fused_acquire" (1/0), "fused_timeout_ms" (bound of every
+ * thread keeps in registers, default 20; 0 restores the default), "fused_acquire" (1/0), "fused_timeout_ms" (bound of every
  * inter-workgroup wait, default 2000), "fused_fault_inject" (test hook), "clahe_float_tables" (1/0),
  * "host_direct" (1/0, default 1: the host-pointer forms hand contiguous planes to the copy engine as they are; 0 stages
  * them through the context's pinned buffers, as strided views always are). */

@@ -147,7 +147,8 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!name) return fail(c, MI_ERR_BAD_ARG, "null option name");
     if (!strcmp(name, "fused")) { c->fused_mode = value; return MI_OK; }
     if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }
-    if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
+    if (!strcmp(name, "fused_vpt") && value == 0) { c->fused_vpt = kVPT; return MI_OK; }
+    if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 0 (default), 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
     if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
     if (!strcmp(name, "fused_fault_inject")) { c->fused_fault_inject = value != 0; return MI_OK; }
     if (!strcmp(name, "fused_timeout_ms")) { c->fused_timeout_ms = std::max(1, value); return MI_OK; }

@@ -4,28 +4,38 @@
 // ---- fused single-read path -----------------------------------------------------------------------------
 // Layout of the per-call hand-off block (uint32 words), zeroed by ONE memset node before the launch:
 //   [0..31] work counter (u64) | [32..63] status | cnt[nf][32] | ready[nf][32] | ghist[nf][256] | lutpub[nf][128]
-bool fused_applicable(const mi_ctx* c, const PlaneArgs& a, const UVJob* uv)
+// Returns the slice size (16-byte vectors per thread) the fused kernel should run with, or 0 when the launch must take
+// the three-kernel path.  The co-residency allowance (see g_fused_ctx_live) is the conservative 1/8 of the chip when
+// other fused contexts exist on the device and half of the chip while this one is alone (an 8K frame is 405 tickets).
+// Smaller slices for launches of one or two frames were measured and dropped: a single 4K frame takes 23.5-24.4 us with
+// 80 / 64 / 32 KiB slices alike (fixed hand-off latency, not bandwidth), and two frames are slower in 32 KiB slices.
+int fused_pick_vpt(const mi_ctx* c, const PlaneArgs& a, const UVJob* uv)
 {
-    if (!c->fused_mode || !c->fused_slot) return false;
-    if (a.src_step != (size_t)a.width || a.dst_step != (size_t)a.width) return false;      // contiguous planes only
+    if (!c->fused_mode || !c->fused_slot) return 0;
+    if (a.src_step != (size_t)a.width || a.dst_step != (size_t)a.width) return 0;      // contiguous planes only
     const long long ysz = (long long)a.width * a.height;
-    if (ysz % 16 != 0) return false;
-    if (((uintptr_t)a.src | (uintptr_t)a.dst | a.src_frame | a.dst_frame) & 15) return false;
-    const long long slice = (long long)kThreads * c->fused_vpt;
-    const long long T = (ysz / 16 + slice - 1) / slice;
-    if (T > (long long)c->cu_count * c->fused_wgs_per_cu / (2 * kMaxFusedCtxPerDevice)) return false;   // co-residency guard (see g_fused_ctx_live)
-    if (a.n_frames > (1 << 20)) return false;
+    if (ysz % 16 != 0) return 0;
+    if (((uintptr_t)a.src | (uintptr_t)a.dst | a.src_frame | a.dst_frame) & 15) return 0;
+    if (a.n_frames > (1 << 20)) return 0;
     (void)uv;
-    return true;
+    const long long nvec = ysz / 16;
+    auto tickets = [&](int vpt) { const long long s = (long long)kThreads * vpt; return (nvec + s - 1) / s; };
+    const bool alone = c->device >= 0 && c->device < kMaxDevices && g_fused_ctx_live[c->device].load() <= 1;
+    const long long limit = (long long)c->cu_count * c->fused_wgs_per_cu / (2 * (alone ? 1 : kMaxFusedCtxPerDevice));
+    return tickets(c->fused_vpt) <= limit ? c->fused_vpt : 0;
 }
+
+bool fused_applicable(const mi_ctx* c, const PlaneArgs& a, const UVJob* uv) { return fused_pick_vpt(c, a, uv) != 0; }
 
 mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
     const long long ysz = (long long)a.width * a.height;
+    const int vpt = fused_pick_vpt(c, a, uv);
+    if (!vpt) return fail(c, MI_ERR_UNSUPPORTED, "fused path not applicable");
     FusedJob j{};
     j.src = a.src; j.dst = a.dst; j.src_frame = (long long)a.src_frame; j.dst_frame = (long long)a.dst_frame;
     j.nvec = ysz / 16; j.total = (int)ysz; j.n_frames = a.n_frames;
-    const long long slice = (long long)kThreads * c->fused_vpt;
+    const long long slice = (long long)kThreads * vpt;
     j.T = (int)((j.nvec + slice - 1) / slice);
     j.acquire = c->fused_acquire;
     j.fault_inject = c->fused_fault_inject;
@@ -73,7 +83,7 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     const long long grid = std::min<long long>(tickets, (long long)c->cu_count * c->fused_wgs_per_cu);
     c->fused_work_base += (unsigned long long)tickets + (unsigned long long)grid;   // every workgroup draws one ticket past the end
     c->fused_dirty = true;                                   // cleared below once the launch has been enqueued
-    switch (c->fused_vpt) {
+    switch (vpt) {
         case 8:  LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<8>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
         case 20: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<20>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
         case 24: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<24>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
