@@ -230,7 +230,9 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t quad[];   // [(tiles_x + 1)][256] u32 quads, or f32x4 when FT
     f32x4* quadf = reinterpret_cast<f32x4*>(quad);
-    const int t = threadIdx.x, f = blockIdx.y;
+    // frames are walked last-to-first: the histogram pass has just streamed the batch first-to-last, so its tail is what the
+    // memory-side Infinity Cache still holds
+    const int t = threadIdx.x, f = (int)gridDim.y - 1 - (int)blockIdx.y;
     const int band = blockIdx.x / subs, sub = blockIdx.x - band * subs;
     const int ty1u = band - 1;                                // unclamped ty1 of every row of the band
     const int ty1 = max(ty1u, 0), ty2 = min(ty1u + 1, g.tiles_y - 1);

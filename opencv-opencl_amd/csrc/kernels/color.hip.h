@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void bgr_luma_hist_kernel(ColorJob j, uin
 __global__ __launch_bounds__(kThreads) void bgr_luma_apply_kernel(ColorJob j, const uint8_t* __restrict__ luts)
 {
     __shared__ uint32_t lut[256 * kCopies];
-    const int f = blockIdx.z, t = threadIdx.x;
+    const int f = (int)gridDim.z - 1 - (int)blockIdx.z, t = threadIdx.x;      // last-to-first: what pass 1 read last is still cached
     const uint32_t copy = t & (kCopies - 1);
     {
         const uint32_t v = luts[(size_t)f * 256 + t];
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void nv12_bgr_hist_kernel(Nv12Job j, uint
 __global__ __launch_bounds__(kThreads) void nv12_bgr_apply_kernel(Nv12Job j, const uint8_t* __restrict__ luts)
 {
     __shared__ uint32_t lut3[256 * kCopies];            // entry v: lutB[v] | lutG[v] << 8 | lutR[v] << 16, 32 copies
-    const int t = threadIdx.x, f = blockIdx.y;
+    const int t = threadIdx.x, f = (int)gridDim.y - 1 - (int)blockIdx.y;      // last-to-first: what pass 1 read last is still cached
     const uint32_t copy = t & (kCopies - 1);
     {
         const uint8_t* lf = luts + (size_t)f * 3 * 256;

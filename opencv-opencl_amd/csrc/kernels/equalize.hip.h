@@ -145,7 +145,8 @@ __device__ __forceinline__ void uv_flat(const uint8_t* src, uint8_t* dst, long l
 __global__ __launch_bounds__(kThreads) void lut_apply_kernel(PlaneBatch p, const uint8_t* __restrict__ luts, UVJob uv)
 {
     __shared__ uint32_t lut[256 * kCopies];
-    const int t = threadIdx.x, f = blockIdx.y;
+    // frames last-to-first: the histogram pass streamed the batch first-to-last, its tail is still in the Infinity Cache
+    const int t = threadIdx.x, f = (int)gridDim.y - 1 - (int)blockIdx.y;
     {
         const uint32_t v = luts[(size_t)f * 256 + t];
 #pragma unroll

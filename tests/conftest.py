@@ -52,3 +52,16 @@ def ctx(built_lib):
     c = mi_lumaeq.Context(0)
     yield c
     c.close()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Leave nothing of ours for interpreter shutdown: destroy every live library context and drain the device while
+    the HIP runtime is certainly still up (the library also does this from an atexit hook)."""
+    try:
+        from mi_lumaeq import capi
+        capi._close_live_contexts()
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
