@@ -364,6 +364,8 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     bgr_out = torch.empty_like(bgr)
     ms = timeit(lambda: ctx.bgr_luma_op_batch_dev(bgr, bgr_out, w, h, Bc, mi_lumaeq.OP_EQUALIZE, stream=stream), 10)
     res["bgr_yuv_equalize_bgr_frames_per_s"] = round(Bc / (ms * 1e-3), 1)
+    ms = timeit(lambda: ctx.bgr_luma_op_batch_dev(bgr, bgr_out, w, h, Bc, mi_lumaeq.OP_CLAHE, 2.0, 8, 8, stream=stream), 10)
+    res["bgr_yuv_clahe8x8_bgr_frames_per_s"] = round(Bc / (ms * 1e-3), 1)      # clahe1frame.cpp:83-102 as one call
     ms = timeit(lambda: ctx.cvt_color_batch_dev(bgr, bgr_out, w, h, Bc, mi_lumaeq.COLOR_BGR2YUV, stream=stream), 10)
     res["cvtcolor_bgr2yuv_GBs"] = round(2 * 3 * w * h * Bc / (ms * 1e-3) / 1e9, 1)
     del bgr, bgr_out

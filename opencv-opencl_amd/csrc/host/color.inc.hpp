@@ -79,6 +79,42 @@ mi_status bgr_luma_dev(mi_ctx* c, hipStream_t s, const Color3Args& a, int op, do
         }
         return MI_OK;
     }
+    if (op == MI_OP_CLAHE && c->bgr_fused) {
+        // two passes over the interleaved image (9 B/px) when the shape allows it: no REFLECT_101 padding, 16-pixel groups
+        // that never straddle a tile, 16-B aligned rows, f32 pair tables (tiles_x <= 14)
+        ClaheGeom g;
+        mi_status st = clahe_geometry(c, a.width, a.height, clip, tx, ty, &g);
+        if (st) return st;
+        const int tiles = tx * ty;
+        const bool shape_ok = a.width % tx == 0 && a.height % ty == 0 && g.tile_w % 16 == 0 && tx + 1 <= kMaxPairsLdsF32 &&
+                              tiles <= kMaxGridY && a.width / kInterpPx <= kThreads * kMaxGridY &&
+                              (((uintptr_t)a.src | (uintptr_t)a.dst | a.src_step | a.dst_step | a.src_frame | a.dst_frame) & 15) == 0;
+        if (shape_ok) {
+            const ColorJob j = color_job(a);
+            for (int f0 = 0; f0 < a.n_frames; f0 += kMaxGridY) {
+                const int nf = std::min(kMaxGridY, a.n_frames - f0);
+                ColorJob q = j;
+                q.src += (long long)f0 * j.src_frame; q.dst += (long long)f0 * j.dst_frame;
+                q.src_step = (long long)a.src_step; q.dst_step = (long long)a.dst_step;       // row-wise addressing (color_job() may flatten)
+                long long want = ((long long)c->cu_count * 8 + (long long)tiles * nf - 1) / ((long long)tiles * nf);
+                const int S = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 8), 64LL}));
+                if ((st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * tiles * S * 256 * sizeof(uint32_t)))) return st;
+                if ((st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * tiles * 256))) return st;
+                LAUNCH(c, s, MI_K_TILE_HIST, bgr_tile_hist_kernel, dim3(S, tiles, nf), dim3(kThreads), 0,
+                       q.src, q.src_step, q.src_frame, g, c->d_partial);
+                LAUNCH(c, s, MI_K_TILE_LUT, tile_lut_kernel, dim3(tiles, nf), dim3(kThreads), 0, (const uint32_t*)c->d_partial, S, g, c->d_luts);
+                const int ngroups = a.width / kInterpPx;
+                const int groups = std::min(ngroups, kThreads);
+                const int segs = (ngroups + groups - 1) / groups;
+                const int bands = ty + 1;
+                want = ((long long)c->cu_count * 8 + (long long)bands * nf * segs - 1) / ((long long)bands * nf * segs);
+                const int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, (g.tile_h + 2 * kBandMargin) / 8), 64LL}));
+                LAUNCH(c, s, MI_K_CLAHE_INTERP, bgr_clahe_interp_kernel, dim3(bands * subs, nf, segs), dim3(kThreads),
+                       (size_t)(tx + 1) * 256 * 4 * sizeof(float), q, g, (const uint8_t*)c->d_luts, subs, groups);
+            }
+            return MI_OK;
+        }
+    }
     const size_t plane = ((size_t)a.width * a.height + 15) & ~(size_t)15;           // keep every plane 16-B aligned
     const size_t per_frame = plane * 4;                                             // Y, U, V, Y'
     mi_status st = grow_dev(c, &c->d_planes, &c->planes_bytes, per_frame * (size_t)a.n_frames);

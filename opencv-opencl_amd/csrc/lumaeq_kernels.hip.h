@@ -21,7 +21,8 @@
 //   kernels/equalize_fused.hip.h  KF fused single-read equalizeHist
 //   kernels/clahe.hip.h           K4 tile hist, K5 clip/redistribute/LUT, K6 interpolation
 //   kernels/clahe16.hip.h         CLAHE on CV_16UC1 (N4)
-//   kernels/color.hip.h           cvtColor BGR2YUV / YUV2BGR + fused split/merge (N3)
+//   kernels/color.hip.h           cvtColor BGR2YUV / YUV2BGR + fused split/merge, 4:2:0 codes, NV12 per-channel equalize (N3)
+//   kernels/color_clahe.hip.h     CLAHE on the luma of interleaved BGR in two passes (N3)
 #pragma once
 #include "kernels/common.hip.h"
 #include "kernels/equalize.hip.h"
@@ -29,3 +30,4 @@
 #include "kernels/clahe.hip.h"
 #include "kernels/clahe16.hip.h"
 #include "kernels/color.hip.h"
+#include "kernels/color_clahe.hip.h"

@@ -623,6 +623,18 @@ def test_bgr_luma_paths_agree(ctx):
             assert np.array_equal(ctx.bgr_luma_op(view, mi_lumaeq.OP_EQUALIZE), oracle.bgr_luma_op(np.ascontiguousarray(view), 0)), fused
             flat = np.full((64, 64, 3), (10, 200, 30), np.uint8)                      # constant luma: LUT shortcut
             assert np.array_equal(ctx.bgr_luma_op(flat, mi_lumaeq.OP_EQUALIZE), oracle.bgr_luma_op(flat, 0)), fused
+            # CLAHE: the two-pass kernels take the unpadded, 16-pixel-aligned shapes, everything else goes through planes
+            for (h, w), (clip, tx, ty) in [((1080, 1920), (2.0, 8, 8)), ((360, 640), (3.0, 4, 4)), ((96, 448), (40.0, 14, 3)),
+                                           ((64, 256), (0.0, 1, 1)), ((360, 640), (2.0, 8, 8)), ((47, 63), (3.0, 4, 4)), ((128, 480), (2.0, 15, 2))]:
+                a = _bgr(w, h, 41)
+                assert np.array_equal(ctx.bgr_luma_op(a, mi_lumaeq.OP_CLAHE, clip, tx, ty), oracle.bgr_luma_op(a, 1, clip, tx, ty)), (fused, h, w, tx, ty)
+            inplace = _bgr(640, 360, 42)
+            want = oracle.bgr_luma_op(inplace, 1, 2.0, 4, 4)
+            d = torch.from_numpy(np.stack([inplace, _bgr(640, 360, 43)])).cuda()
+            ctx.bgr_luma_op_batch_dev(d, d, 640, 360, 2, mi_lumaeq.OP_CLAHE, 2.0, 4, 4)       # batch, in place on the device
+            torch.cuda.synchronize()
+            assert np.array_equal(d[0].cpu().numpy(), want), fused
+            assert np.array_equal(d[1].cpu().numpy(), oracle.bgr_luma_op(_bgr(640, 360, 43), 1, 2.0, 4, 4)), fused
     finally:
         ctx.set_option("bgr_fused", 1)
 
