@@ -38,10 +38,13 @@ mi_status launch_tile_luts(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const C
     const uint8_t* src = a.src + (size_t)f0 * a.src_frame;
     // grid.y = tiles, grid.z = frames
     if (tiles > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "more than 65535 tiles per frame");
+    // one workgroup per tile: the LUT is computed where the histogram was built, no partials, no second launch
+    uint8_t* direct = S == 1 ? d_luts_out : nullptr;
     LAUNCH(c, s, MI_K_TILE_HIST, tile_hist_kernel, dim3(S, tiles, nf), dim3(kThreads), 0,
-           src, (long long)a.src_step, (long long)a.src_frame, g, c->d_partial);
-    LAUNCH(c, s, MI_K_TILE_LUT, tile_lut_kernel, dim3(tiles, nf), dim3(kThreads), 0,
-           (const uint32_t*)c->d_partial, S, g, d_luts_out);
+           src, (long long)a.src_step, (long long)a.src_frame, g, c->d_partial, direct);
+    if (!direct)
+        LAUNCH(c, s, MI_K_TILE_LUT, tile_lut_kernel, dim3(tiles, nf), dim3(kThreads), 0,
+               (const uint32_t*)c->d_partial, S, g, d_luts_out);
     return MI_OK;
 }
 

@@ -29,16 +29,46 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// K5's arithmetic for bin t = threadIdx.x given this bin's count c (all 256 threads call it): clip, redistribute, CDF -> LUT.
+// clahe.cpp CLAHE_CalcLut_Body: the sequential residual loop
+//     for (i = 0; i < 256 && residual > 0; i += step, --residual) ++h[i];
+// increments bin b iff b % step == 0 and b / step < residual.
+__device__ __forceinline__ uint8_t tile_lut_value(uint32_t c, const ClaheGeom& g, uint32_t* s_wave /*[4]*/)
+{
+    const int t = threadIdx.x;
+    int hv = (int)c;
+    if (g.clip > 0) {
+        const uint32_t excess = hv > g.clip ? (uint32_t)(hv - g.clip) : 0u;
+        uint32_t clipped;
+        block_incl_scan(excess, s_wave, &clipped);
+        if (hv > g.clip) hv = g.clip;
+        const int batch = (int)clipped / 256;
+        int residual = (int)clipped - batch * 256;
+        hv += batch;
+        if (residual != 0) {
+            int rstep = 256 / residual; if (rstep < 1) rstep = 1;
+            if (t % rstep == 0 && t / rstep < residual) ++hv;
+        }
+    }
+    const uint32_t sum = block_incl_scan((uint32_t)hv, s_wave, nullptr);
+    int r = __float2int_rn(__fmul_rn((float)(int)sum, g.lut_scale));
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    return (uint8_t)r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K4  per-tile histogram partials.  grid = (S, tiles, n_frames); partial[f][tile][s][256].
 // The padded image is never materialised: rows/columns beyond the frame are read by index
 // reflection.  Work items are (row, 16-byte slot) pairs walked incrementally so short tile rows
 // (480 B at 4K 8x8) still give every lane a vector load.
 // ---------------------------------------------------------------------------------------------
+// With one workgroup per tile (gridDim.x == 1, the batch case) the finished histogram never leaves the CU: the LUT is
+// computed in place and written to `luts` (K5 folded in, no partials round trip, one launch fewer).
 __global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                            ClaheGeom g, uint32_t* __restrict__ partial)
+                                                            ClaheGeom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ luts)
 {
     __shared__ uint32_t h[256 * kCopies];
+    __shared__ uint32_t s_wave[4];
     lds_hist_zero(h);
     const int t = threadIdx.x;
     const uint32_t copy = t & (kCopies - 1);
@@ -89,7 +119,9 @@ __global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __re
         }
     }
     __syncthreads();
-    partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = lds_hist_bin(h, t);
+    const uint32_t bin = lds_hist_bin(h, t);
+    if (luts) luts[((size_t)f * gridDim.y + tile) * 256 + t] = tile_lut_value(bin, g, s_wave);     // host passes luts only when S == 1
+    else partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = bin;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -107,24 +139,7 @@ __global__ __launch_bounds__(kThreads) void tile_lut_kernel(const uint32_t* __re
     const uint32_t* pp = partial + tile_id * S * 256 + t;
     uint32_t c = 0;
     for (int s = 0; s < S; ++s) c += pp[(size_t)s * 256];
-    int hv = (int)c;
-    if (g.clip > 0) {
-        const uint32_t excess = hv > g.clip ? (uint32_t)(hv - g.clip) : 0u;
-        uint32_t clipped;
-        block_incl_scan(excess, s_wave, &clipped);
-        if (hv > g.clip) hv = g.clip;
-        const int batch = (int)clipped / 256;
-        int residual = (int)clipped - batch * 256;
-        hv += batch;
-        if (residual != 0) {
-            int rstep = 256 / residual; if (rstep < 1) rstep = 1;
-            if (t % rstep == 0 && t / rstep < residual) ++hv;
-        }
-    }
-    const uint32_t sum = block_incl_scan((uint32_t)hv, s_wave, nullptr);
-    int r = __float2int_rn(__fmul_rn((float)(int)sum, g.lut_scale));
-    r = r < 0 ? 0 : (r > 255 ? 255 : r);
-    luts[tile_id * 256 + t] = (uint8_t)r;
+    luts[tile_id * 256 + t] = tile_lut_value(c, g, s_wave);
 }
 
 // ---------------------------------------------------------------------------------------------

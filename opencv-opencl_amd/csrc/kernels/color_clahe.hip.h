@@ -38,9 +38,10 @@ __device__ __forceinline__ u32x4 bgr16_to_y(const uint8_t* p, u32x4* up, u32x4* 
 
 // pass 1: per-tile luma histogram partials straight from BGR.  grid = (S, tiles, n_frames), as tile_hist_kernel.
 __global__ __launch_bounds__(kThreads) void bgr_tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                                ClaheGeom g, uint32_t* __restrict__ partial)
+                                                                ClaheGeom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ luts)
 {
     __shared__ uint32_t h[256 * kCopies];
+    __shared__ uint32_t s_wave[4];
     lds_hist_zero(h);
     const int t = threadIdx.x;
     const uint32_t copy = t & (kCopies - 1);
@@ -56,7 +57,9 @@ __global__ __launch_bounds__(kThreads) void bgr_tile_hist_kernel(const uint8_t* 
         hist_add_vec(h, y, copy);
     }
     __syncthreads();
-    partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = lds_hist_bin(h, t);
+    const uint32_t bin = lds_hist_bin(h, t);
+    if (luts) luts[((size_t)f * gridDim.y + tile) * 256 + t] = tile_lut_value(bin, g, s_wave);     // one workgroup per tile: LUT in place
+    else partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = bin;
 }
 
 // pass 2: convert, blend Y through the four neighbouring tile LUTs (f32 pair tables in LDS, as clahe_interp_kernel<true>),
