@@ -20,3 +20,22 @@ for n in (1, 2, 4):
         for _ in range(300): ctx.equalize_hist_nv12_batch_dev(nv, out, w, h, n, mi_lumaeq.UV_FILL128)
         torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 300
         print(f"frames={n} vpt={vpt or 'auto':>4}: kernel {p['total_ms'] / max(p['launches'], 1) * 1e3:7.1f} us   back-to-back {wall * 1e6:7.1f} us/call", flush=True)
+
+# where a single frame's ~22 us go: Y only (no UV tickets), the three-kernel path, and a bare launch
+nv = synth.nv12_batch_torch(w, h, 1, "D2", "cuda", seed=7)
+out = torch.empty_like(nv)
+ctx.set_option("fused_vpt", 0)
+def rate(fn, reps=300):
+    for _ in range(20): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e6
+print("fused NV12 (Y + UV fill) us/call:", round(rate(lambda: ctx.equalize_hist_nv12_batch_dev(nv, out, w, h, 1, mi_lumaeq.UV_FILL128)), 1))
+print("fused Y plane only       us/call:", round(rate(lambda: ctx.equalize_hist_batch_dev(nv, out, w, h, 1)), 1))
+ctx.set_option("fused", 0)
+print("three-kernel NV12        us/call:", round(rate(lambda: ctx.equalize_hist_nv12_batch_dev(nv, out, w, h, 1, mi_lumaeq.UV_FILL128)), 1))
+ctx.set_option("fused", 1)
+x = torch.zeros(64, device="cuda")
+print("bare torch kernel        us/call:", round(rate(lambda: x.add_(1.0)), 1))
+hist = torch.empty((1, 256), dtype=torch.int32, device="cuda")
+print("hist stage only (2 launches) us/call:", round(rate(lambda: ctx.hist_batch_dev(nv, w, h, 1, hist)), 1))
