@@ -21,12 +21,15 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)256 << 20) / per_frame));
     st = grow_dev(c, &c->d_c16, &c->c16_bytes, per_frame * (size_t)chunk);
     if (st) return st;
+    // vector path of the tile histogram: no REFLECT_101 padding, 8-pixel groups inside one tile, 16-B aligned rows
+    const int vec = width % tiles_x == 0 && height % tiles_y == 0 && g.tile_w % 8 == 0 &&
+                    (((uintptr_t)src | src_step | src_frame) & 15) == 0;
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
         uint32_t* hist = reinterpret_cast<uint32_t*>(c->d_c16);
         uint16_t* luts = reinterpret_cast<uint16_t*>(c->d_c16 + (size_t)nf * tiles * kHist16 * sizeof(uint32_t));
         LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
-               src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist);
+               src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, vec);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, g, lut_scale16, clip16, luts);
         LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
                src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,

@@ -17,8 +17,17 @@ constexpr int kHist16 = 65536;
 // two passes over the tile (the second one is served by L2), each histogramming one half of the value range in
 // 128 KiB of LDS and storing it -- no global atomics, no zeroing of the output.  steps in BYTES.
 constexpr int kHalf16 = 32768;
+__device__ __forceinline__ void hist16_add_dword(uint32_t* h16, uint32_t w, int half)
+{
+    const uint32_t a = w & 0xffffu, b = w >> 16;
+    if ((int)(a >> 15) == half) lds_inc(h16, a & (kHalf16 - 1));
+    if ((int)(b >> 15) == half) lds_inc(h16, b & (kHalf16 - 1));
+}
+
+// `vec` (host: no REFLECT_101 padding, tile_w % 8 == 0, 16-B aligned rows): a lane takes 8 pixels per 16-byte load with
+// four loads in flight; otherwise one pixel per lane per step with index reflection.
 __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                          ClaheGeom g, uint32_t* __restrict__ hist)
+                                                          ClaheGeom g, uint32_t* __restrict__ hist, int vec)
 {
     extern __shared__ uint32_t h16[];                            // [32768]
     const int t = threadIdx.x;
@@ -28,17 +37,37 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
     uint32_t* out = hist + ((size_t)f * gridDim.x + tile) * kHist16;
     const long long items = (long long)g.tile_h * g.tile_w;
     const int drow = 1024 / g.tile_w, dcol = 1024 - drow * g.tile_w;
+    const int slots = g.tile_w >> 3;                              // 8-pixel groups per tile row (vector path)
+    const int vitems = g.tile_h * slots;
+    const uint8_t* tbase = src + (long long)ty * g.tile_h * step + (long long)tx * g.tile_w * 2;
+    auto vload = [&](int it) -> u32x4 {
+        const int row = it / slots, slot = it - row * slots;
+        return *reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
+    };
+    auto vadd = [&](const u32x4& q, int half) {
+        hist16_add_dword(h16, q.x, half); hist16_add_dword(h16, q.y, half);
+        hist16_add_dword(h16, q.z, half); hist16_add_dword(h16, q.w, half);
+    };
     for (int half = 0; half < 2; ++half) {
         for (int i = t; i < kHalf16; i += 1024) h16[i] = 0;
         __syncthreads();
-        int row = t / g.tile_w, col = t - row * g.tile_w;
-        for (long long it = t; it < items; it += 1024) {
-            const int y = reflect101(ty * g.tile_h + row, g.height);
-            const int x = reflect101(tx * g.tile_w + col, g.width);
-            const uint32_t v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
-            if ((int)(v >> 15) == half) lds_inc(h16, v & (kHalf16 - 1));
-            row += drow; col += dcol;
-            if (col >= g.tile_w) { col -= g.tile_w; ++row; }
+        if (vec) {
+            int it = t;
+            for (; it + 3 * 1024 < vitems; it += 4 * 1024) {
+                const u32x4 a = vload(it), b = vload(it + 1024), c = vload(it + 2048), d = vload(it + 3072);
+                vadd(a, half); vadd(b, half); vadd(c, half); vadd(d, half);
+            }
+            for (; it < vitems; it += 1024) vadd(vload(it), half);
+        } else {
+            int row = t / g.tile_w, col = t - row * g.tile_w;
+            for (long long it = t; it < items; it += 1024) {
+                const int y = reflect101(ty * g.tile_h + row, g.height);
+                const int x = reflect101(tx * g.tile_w + col, g.width);
+                const uint32_t v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
+                if ((int)(v >> 15) == half) lds_inc(h16, v & (kHalf16 - 1));
+                row += drow; col += dcol;
+                if (col >= g.tile_w) { col -= g.tile_w; ++row; }
+            }
         }
         __syncthreads();
         for (int i = t; i < kHalf16; i += 1024) out[half * kHalf16 + i] = h16[i];
@@ -46,8 +75,9 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
     }
 }
 
-// grid = (tiles, frames), 1024 threads.  The 65 536 bins are walked in 64 chunks of 1024 (coalesced): a first sweep
-// sums the clipped excess, a second applies clip + redistribute and scans (block scan per chunk + running offset).
+// grid = (tiles, frames), 1024 threads.  The 65 536 bins are walked in 16 chunks of 4096, four consecutive bins per
+// thread (one 16-byte load, one 8-byte store): a first sweep sums the clipped excess, a second applies clip +
+// redistribute and scans (serial over a thread's four bins, block scan of the four-bin sums, running offset per chunk).
 __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, ClaheGeom g, float lut_scale16, int clip16,
                                                          uint16_t* __restrict__ luts)
 {
@@ -71,7 +101,12 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     int batch = 0, residual = 0, rstep = 1;
     if (clip16 > 0) {
         uint32_t excess = 0;
-        for (int c = 0; c < 64; ++c) { const int v = (int)h[c * 1024 + t]; if (v > clip16) excess += (uint32_t)(v - clip16); }
+        for (int c = 0; c < 16; ++c) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(h + c * 4096 + t * 4);
+            const int v[4] = {(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (v[k] > clip16) excess += (uint32_t)(v[k] - clip16);
+        }
         uint32_t clipped;
         (void)block_scan(excess, clipped);
         batch = (int)clipped / kHist16;
@@ -79,24 +114,39 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
         if (residual != 0) { rstep = kHist16 / residual; if (rstep < 1) rstep = 1; }
     }
     uint32_t running = 0;
-    for (int c = 0; c < 64; ++c) {
-        const int b = c * 1024 + t;
-        int v = (int)h[b];
-        if (clip16 > 0) {
-            if (v > clip16) v = clip16;
-            v += batch;
-            if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++v;
+    for (int c = 0; c < 16; ++c) {
+        const int b0 = c * 4096 + t * 4;
+        const u32x4 q = *reinterpret_cast<const u32x4*>(h + b0);
+        int v[4] = {(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+        uint32_t local = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (clip16 > 0) {
+                if (v[k] > clip16) v[k] = clip16;
+                v[k] += batch;
+                const int b = b0 + k;
+                if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++v[k];
+            }
+            local += (uint32_t)v[k];
+            v[k] = (int)local;                                       // inclusive prefix within the thread's four bins
         }
         uint32_t total;
-        const uint32_t sum = running + block_scan((uint32_t)v, total);
+        const uint32_t before = running + block_scan(local, total) - local;     // everything before this thread's first bin
         running += total;
-        int r = __float2int_rn(__fmul_rn((float)(int)sum, lut_scale16));
-        r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
-        lut[b] = (uint16_t)r;
+        uint32_t packed[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int r = __float2int_rn(__fmul_rn((float)(int)(before + (uint32_t)v[k]), lut_scale16));
+            r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
+            if (k & 1) packed[k >> 1] |= (uint32_t)r << 16; else packed[k >> 1] = (uint32_t)r;
+        }
+        *reinterpret_cast<uint2*>(lut + b0) = make_uint2(packed[0], packed[1]);
     }
 }
 
-// grid = (ceil(W/256), H, frames): one pixel per lane, four ushort gathers from the per-tile LUTs (L2).
+// grid = (ceil(W/256), H, frames): one pixel per lane, four ushort gathers from the per-tile LUTs (L2).  Bound by the
+// divergent gathers themselves (up to 64 cache lines per wave instruction): giving each XCD one eighth of the rows, so
+// that its L2 only has to hold two tile rows of LUTs, measured 4 % SLOWER.
 __global__ __launch_bounds__(kThreads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                  uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                  ClaheGeom g, const uint16_t* __restrict__ luts)
