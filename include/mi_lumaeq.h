@@ -228,6 +228,8 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * inter-workgroup wait, default 2000), "fused_fault_inject" (test hook), "clahe_float_tables" (1/0),
  * "bgr_fused" (1/0, default 1: mi_bgr_luma_op_u8c3 runs as two passes over the interleaved image instead of through
  * Y/U/V planes; CLAHE only for unpadded shapes with tile_w % 16 == 0),
+ * "clahe16_transposed" (1/0, default 0: value-major LUT layout for the 16-bit interpolation, faster on full-range content and
+ * slower on narrow-range content),
  * "host_direct" (1/0, default 1: the host-pointer forms hand contiguous planes to the copy engine as they are; 0 stages
  * them through the context's pinned buffers, as strided views always are). */
 mi_status mi_ctx_synchronize(mi_ctx* ctx, void* stream);

@@ -17,6 +17,7 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
     int clip16 = 0;
     if (clip_limit > 0.0) { clip16 = (int)(clip_limit * (int)area / 65536); clip16 = std::max(clip16, 1); }
     // scratch per frame: tile histograms (u32) + ushort LUTs; frames are processed in chunks that keep it <= ~256 MiB
+    // (the value-major copy of the LUTs reuses the histogram area, which is dead once the LUTs exist)
     const size_t per_frame = (size_t)tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t));
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)256 << 20) / per_frame));
     st = grow_dev(c, &c->d_c16, &c->c16_bytes, per_frame * (size_t)chunk);
@@ -31,9 +32,19 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
                src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, vec);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, g, lut_scale16, clip16, luts);
-        LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
-               src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
-               dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts);
+        if (tiles <= 64 && c->clahe16_transposed) {
+            // value-major LUTs (one cache line per pixel value): transposed into the histogram area, which is dead by now
+            uint16_t* lutT = reinterpret_cast<uint16_t*>(hist);
+            LAUNCH(c, s, MI_K_TILE_LUT, transpose_lut16_kernel, dim3(kHist16 / 256, nf), dim3(kThreads), (size_t)tiles * 256 * sizeof(uint16_t),
+                   (const uint16_t*)luts, lutT, tiles);
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16T_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
+                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
+                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)lutT);
+        } else {
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
+                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
+                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts);
+        }
     }
     return MI_OK;
 }

@@ -615,6 +615,14 @@ def test_clahe16_batch_and_errors(ctx):
     out = d_out.cpu().numpy().view(np.uint16)
     for k in range(n):
         assert np.array_equal(out[k], oracle.clahe16(frames[k], 2.0, 8, 8)), k
+    # both LUT layouts of the interpolation (value-major is an option for <= 64 tiles) and a grid too large for it
+    try:
+        for layout in (0, 1):
+            ctx.set_option("clahe16_transposed", layout)
+            for cfg in [(2.0, 8, 8), (3.0, 4, 4), (2.0, 9, 8), (40.0, 1, 1)]:
+                assert np.array_equal(ctx.clahe16(frames[1], *cfg), oracle.clahe16(frames[1], *cfg)), (layout, cfg)
+    finally:
+        ctx.set_option("clahe16_transposed", 0)
     # full-size frame through the vectorised tile histogram (tile rows of 480 pixels, no padding), 12-bit content
     big = np.random.default_rng(5).integers(0, 4096, (2160, 3840), dtype=np.uint16)
     assert np.array_equal(ctx.clahe16(big, 2.0, 8, 8), oracle.clahe16(big, 2.0, 8, 8))
