@@ -573,7 +573,10 @@ def test_fused_failure_in_host_form_is_reported(tmp_path):
     script = tmp_path / "fault_host_form.py"
     script.write_text(_FAULT_HOST_FORM.format(root=str(root), pkg=str(root / "opencv-opencl_amd" / "python")))
     env = dict(os.environ, AMD_LOG_LEVEL="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-X", "faulthandler", str(script)], capture_output=True, text=True, timeout=300, env=env)
+    tracer = root / "tests" / "cxx" / "libabrt_trace.so"           # native backtrace on SIGABRT/SIGSEGV (tests/cxx/abrt_trace.c)
+    if tracer.exists():
+        env["LD_PRELOAD"] = str(tracer)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     if r.returncode < 0:
         log = root / "gpurun_out"
         if log.is_dir():
