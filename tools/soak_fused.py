@@ -35,5 +35,27 @@ while time.time() - t0 < budget:
         for o in (oa, ob):
             if not torch.equal(o, want):
                 mismatches += 1; print("MISMATCH", (w, h, n, uv, dist))
+# alone-on-the-device phase: one context, 8K frames (405 tickets per frame: only allowed while no other fused context exists)
+cases = []
+for k in range(3):
+    n = [1, 4, 9][k]
+    d_in = synth.nv12_batch_torch(7680, 4320, n, ["D2", "D5", "D1"][k], "cuda", seed=900 + k)
+    want = torch.empty_like(d_in)
+    ref.equalize_hist_nv12_batch_dev(d_in, want, 7680, 4320, n, k % 2); ref.synchronize()
+    cases.append((d_in, want, n, k % 2))
+fused_b.close(); ref.close()
+t1 = time.time()
+while time.time() - t1 < min(10.0, budget / 4):
+    for d_in, want, n, uv in cases:
+        o = torch.zeros_like(d_in)
+        torch.cuda.synchronize()
+        fused_a.equalize_hist_nv12_batch_dev(d_in, o, 7680, 4320, n, uv, stream=mi_lumaeq.STREAM_CTX)
+        try:
+            fused_a.synchronize(mi_lumaeq.STREAM_CTX)
+        except mi_lumaeq.MiError as e:
+            errors += 1; print("ERROR (alone, 8K)", e, n)
+        launches += 1; frames += n
+        if not torch.equal(o, want):
+            mismatches += 1; print("MISMATCH (alone, 8K)", n, uv)
 print(f"soak: {launches} fused launches, {frames} frames in {time.time() - t0:.1f} s; mismatches={mismatches} errors={errors}")
 sys.exit(1 if (mismatches or errors) else 0)
