@@ -2,7 +2,8 @@
 // Included by ../mi_lumaeq.hip (one translation unit; not a stand-alone header).
 
 // ---- fused single-read path -----------------------------------------------------------------------------
-// Layout of the per-call hand-off block (uint32 words), zeroed by ONE memset node before the launch:
+// Layout of the hand-off block (uint32 words; zeroed by zero_words_kernel when first used, re-laid-out, after a reported failure or
+// in graph-replayable mode -- otherwise every launch leaves it clean for the next one):
 //   [0..31] work counter (u64) | [32..63] status | cnt[nf][32] | ready[nf][32] | ghist[nf][256] | lutpub[nf][128]
 // Returns the slice size (16-byte vectors per thread) the fused kernel should run with, or 0 when the launch must take
 // the three-kernel path.  The co-residency allowance (see g_fused_ctx_live) is the conservative 1/8 of the chip when
