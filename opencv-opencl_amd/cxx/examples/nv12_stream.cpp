@@ -8,7 +8,7 @@
 //   --clipLimit C  --tile T                                      clahevideo.cpp:374-452
 //   2 s status tick: in/out fps, queue depth, errors, backlog    OpenCVequalHist.cpp:200-234,
 //                                                                OpenCLequalHist.cpp:439-508
-// New: --op equalize|clahe, --uv fill128|copy (OpenCVequalHist.cpp:160-162 vs
+// New: --op equalize|clahe|channels (channels = NV12 -> BGR -> equalizeHist per channel -> NV12), --uv fill128|copy (OpenCVequalHist.cpp:160-162 vs
 // ColoropenCVCwqualHist.cpp:165), --frames N, --input/--output raw NV12 files, --paced.
 #include <algorithm>
 #include <chrono>
@@ -73,7 +73,7 @@ int main(int argc, char** argv)
     try {
         if (pin) for (int k = 0; k < ring; ++k) { registerHostBuffer(in[k].data(), fb); registerHostBuffer(out[k].data(), fb); }
         std::atomic<uint64_t> delivered{0};
-        FramePool pool(workers, width, height, op == "clahe" ? FramePool::CLAHE_OP : FramePool::EQUALIZE,
+        FramePool pool(workers, width, height, op == "clahe" ? FramePool::CLAHE_OP : (op == "channels" ? FramePool::CHANNELS_EQ : FramePool::EQUALIZE),
                        uv == "copy" ? UV_COPY : UV_FILL128,
                        [&](const FrameJob& j) {
                            if (!j.ok) fprintf(stderr, "frame %llu error: %s\n", (unsigned long long)j.index, j.error.c_str());

@@ -40,7 +40,7 @@ struct FrameJob {
 
 class FramePool {
 public:
-    enum Op { EQUALIZE, CLAHE_OP };
+    enum Op { EQUALIZE, CLAHE_OP, CHANNELS_EQ };   // CHANNELS_EQ: NV12 -> BGR -> equalizeHist on B, G, R -> NV12 (BASELINE config 5 read literally; ignores uv)
     using Sink = std::function<void(const FrameJob&)>;   // called in frame order, from a pool thread
 
     FramePool(int workers, int width, int height, Op op, UVMode uv, Sink sink,
@@ -101,8 +101,7 @@ private:
         try {                                                   // warm-up: context + allocations for this frame size
             const size_t fb = (size_t)width_ * height_ + (size_t)width_ * height_ / 2;
             std::vector<unsigned char> tmp(fb, 128);
-            if (op_ == EQUALIZE) equalizeHistNV12(tmp.data(), tmp.data(), width_, height_, uv_);
-            else claheNV12(tmp.data(), tmp.data(), width_, height_, uv_, clip_, tiles_);
+            process(tmp.data(), tmp.data());
         } catch (const std::exception&) {
             // reported per frame later; the pool still comes up so submit()/finish() do not hang
         }
@@ -122,8 +121,7 @@ private:
                 cv_space_.notify_all();
             }
             try {
-                if (op_ == EQUALIZE) equalizeHistNV12(j.in, j.out, width_, height_, uv_);
-                else claheNV12(j.in, j.out, width_, height_, uv_, clip_, tiles_);
+                process(j.in, j.out);
                 j.ok = true;
             } catch (const std::exception& e) {             // per-frame drop-and-count, OpenCVequalHist.cpp:189-193
                 j.ok = false; j.error = e.what();
@@ -131,6 +129,13 @@ private:
             }
             deliver(j);
         }
+    }
+
+    void process(const unsigned char* in, unsigned char* out)
+    {
+        if (op_ == EQUALIZE) equalizeHistNV12(in, out, width_, height_, uv_);
+        else if (op_ == CLAHE_OP) claheNV12(in, out, width_, height_, uv_, clip_, tiles_);
+        else equalizeHistChannelsNV12(in, out, width_, height_);
     }
 
     // re-sequencer: hold completed frames until all earlier ones have been delivered

@@ -56,7 +56,7 @@ def test_stream_demo_file_io_matches_oracle(tmp_path):
     frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 800 + k) for k in range(n)])
     src = tmp_path / "in.nv12"
     src.write_bytes(frames.tobytes())
-    for op, uv, args in (("equalize", "copy", []), ("clahe", "fill128", ["--clipLimit", "3.0", "--tile", "4"])):
+    for op, uv, args in (("equalize", "copy", []), ("clahe", "fill128", ["--clipLimit", "3.0", "--tile", "4"]), ("channels", "fill128", [])):
         dst = tmp_path / f"out_{op}.nv12"
         r = subprocess.run([str(ROOT / "opencv-opencl_amd" / "lib" / "nv12_stream"), "--input", str(src), "--output", str(dst),
                             "--width", str(w), "--height", str(h), "--frames", str(n), "--workers", "3", "--op", op, "--uv", uv] + args,
@@ -64,8 +64,11 @@ def test_stream_demo_file_io_matches_oracle(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         out = np.frombuffer(dst.read_bytes(), np.uint8).reshape(n, -1)
         for k in range(n):
-            want = oracle.nv12_frame(frames[k], w, h, uv_mode=1 if uv == "copy" else 0, op=0 if op == "equalize" else 1,
-                                     clip_limit=3.0, tiles_x=4, tiles_y=4)
+            if op == "channels":                  # NV12 -> BGR -> equalizeHist per channel -> NV12 (BASELINE config 5 read literally)
+                want = oracle.nv12_bgr_equalize(frames[k], w, h)
+            else:
+                want = oracle.nv12_frame(frames[k], w, h, uv_mode=1 if uv == "copy" else 0, op=0 if op == "equalize" else 1,
+                                         clip_limit=3.0, tiles_x=4, tiles_y=4)
             assert np.array_equal(out[k], want), (op, k)
 
 
