@@ -327,6 +327,32 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
             ctx.equalize_hist_nv12_batch_dev(hd_in, hd_out, hw, hh, hb, uvm, stream=sm)
         torch.cuda.synchronize()
         res["nv12_1080p_equalize_frames_per_s"] = round(50 * hb / (time.perf_counter() - t0), 1)
+        # every Y distribution reported separately (D1 uniform, D2 natural low-contrast, D3 constant -- the
+        # shortcut path and worst-case atomic contention, D4 two-valued checkerboard, D5 ramp), same batch shape as the
+        # headline; and BASELINE config 5's real behaviour (UV passthrough) next to the UV=128 headline
+        by_dist = {}
+        for dname in synth.DISTS:
+            dd_in = synth.nv12_batch_torch(w, h, args.batch, dname, "cuda", seed=23)
+            dd_out = torch.empty_like(dd_in)
+            for _ in range(3):
+                ctx.equalize_hist_nv12_batch_dev(dd_in, dd_out, w, h, args.batch, mi_lumaeq.UV_FILL128, stream=sm)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                ctx.equalize_hist_nv12_batch_dev(dd_in, dd_out, w, h, args.batch, mi_lumaeq.UV_FILL128, stream=sm)
+            torch.cuda.synchronize()
+            by_dist[dname] = round(30 * args.batch / (time.perf_counter() - t0), 1)
+            if dname == args.dist:
+                for _ in range(3):
+                    ctx.equalize_hist_nv12_batch_dev(dd_in, dd_out, w, h, args.batch, mi_lumaeq.UV_COPY, stream=sm)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    ctx.equalize_hist_nv12_batch_dev(dd_in, dd_out, w, h, args.batch, mi_lumaeq.UV_COPY, stream=sm)
+                torch.cuda.synchronize()
+                res["uv_copy_equalize_frames_per_s"] = round(30 * args.batch / (time.perf_counter() - t0), 1)
+            del dd_in, dd_out
+        res["equalize_frames_per_s_by_distribution"] = by_dist
         del hd_in, hd_out
     frame = synth.nv12_batch_torch(w, h, 1, args.dist, "cuda", seed=99)
     outb = torch.empty_like(frame)
