@@ -225,7 +225,8 @@ def main():
     for name, p in prof.items():
         if p["launches"]:
             avg_ms = p["total_ms"] / p["launches"]
-            e = {"avg_ms": round(avg_ms, 5), "launches": p["launches"]}
+            e = {"avg_ms": round(avg_ms, 5), "launches": p["launches"], "p10_ms": round(p["p10_ms"], 5), "p50_ms": round(p["p50_ms"], 5),
+                 "p90_ms": round(p["p90_ms"], 5)}
             if name in per_kernel_alg:
                 e["alg_GBs"] = round(per_kernel_alg[name] / (avg_ms * 1e-3) / 1e9, 1)
             kinfo[name] = e
@@ -245,6 +246,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kinfo[dom]["avg_ms"],
+                    "launch_ms_p10_p50_p90": [kinfo[dom]["p10_ms"], kinfo[dom]["p50_ms"], kinfo[dom]["p90_ms"]],
                     "frac_of_measured_copy_ceiling": round(achieved / HBM_MEASURED_COPY_GBS, 4)}
         if dom == "equalize_fused_kernel":
             min_hbm = (2 * ysz + uv_bytes) * B

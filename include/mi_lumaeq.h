@@ -244,6 +244,9 @@ enum { MI_K_HIST = 0, MI_K_EQ_LUT = 1, MI_K_LUT_APPLY = 2, MI_K_TILE_HIST = 3, M
 typedef struct mi_profile {
     double   total_ms[MI_K_COUNT];   /* summed kernel durations since the last reset */
     uint64_t launches[MI_K_COUNT];
+    double   min_ms[MI_K_COUNT], p10_ms[MI_K_COUNT], p50_ms[MI_K_COUNT], p90_ms[MI_K_COUNT], max_ms[MI_K_COUNT];
+                                     /* distribution of the per-launch durations since the last reset (over at most the
+                                      * 65 536 most recent launches of each kernel; 0 when there were none) */
 } mi_profile;
 mi_status   mi_ctx_set_profiling(mi_ctx* ctx, int enabled);
 mi_status   mi_ctx_profile_read(mi_ctx* ctx, mi_profile* out, int reset);

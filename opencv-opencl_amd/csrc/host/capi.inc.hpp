@@ -108,12 +108,26 @@ mi_status mi_ctx_profile_read(mi_ctx* c, mi_profile* out, int reset)
         HIPCHK(c, hipEventElapsedTime(&ms, p.a, p.b));
         c->prof.total_ms[p.kernel] += ms;
         c->prof.launches[p.kernel] += 1;
+        auto& sv = c->samples[p.kernel];
+        if (sv.size() < 65536) sv.push_back(ms);
+        else { sv[c->sample_pos[p.kernel]] = ms; c->sample_pos[p.kernel] = (c->sample_pos[p.kernel] + 1) & 65535; }
         c->free_events.push_back(p.a);
         c->free_events.push_back(p.b);
     }
     c->pending.clear();
+    for (int k = 0; k < MI_K_COUNT; ++k) {
+        std::vector<float> v = c->samples[k];
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        auto q = [&](double f) { return (double)v[(size_t)std::min<double>((double)v.size() - 1, f * (double)(v.size() - 1) + 0.5)]; };
+        c->prof.min_ms[k] = v.front(); c->prof.max_ms[k] = v.back();
+        c->prof.p10_ms[k] = q(0.10); c->prof.p50_ms[k] = q(0.50); c->prof.p90_ms[k] = q(0.90);
+    }
     if (out) *out = c->prof;
-    if (reset) c->prof = mi_profile{};
+    if (reset) {
+        c->prof = mi_profile{};
+        for (int k = 0; k < MI_K_COUNT; ++k) { c->samples[k].clear(); c->sample_pos[k] = 0; }
+    }
     return MI_OK;
 }
 

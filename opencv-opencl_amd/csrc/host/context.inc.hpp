@@ -74,6 +74,8 @@ struct mi_ctx {
     std::vector<hipEvent_t> free_events;
     std::vector<hipEvent_t> chunk_events;                        // D2H chunk completion (host-pointer forms)
     mi_profile prof{};
+    std::vector<float> samples[MI_K_COUNT];                      // per-launch durations since the last reset (ring of 65 536)
+    size_t sample_pos[MI_K_COUNT] = {};
 };
 
 namespace {

@@ -41,7 +41,8 @@ _K = len(KERNEL_NAMES)
 
 
 class _Profile(C.Structure):
-    _fields_ = [("total_ms", C.c_double * _K), ("launches", C.c_uint64 * _K)]
+    _fields_ = [("total_ms", C.c_double * _K), ("launches", C.c_uint64 * _K), ("min_ms", C.c_double * _K), ("p10_ms", C.c_double * _K),
+                ("p50_ms", C.c_double * _K), ("p90_ms", C.c_double * _K), ("max_ms", C.c_double * _K)]
 
 
 class MiError(RuntimeError):
@@ -433,4 +434,5 @@ class Context:
     def profile_read(self, reset: bool = True) -> dict:
         p = _Profile()
         self._chk(lib().mi_ctx_profile_read(self._h, C.byref(p), 1 if reset else 0), "mi_ctx_profile_read")
-        return {KERNEL_NAMES[k]: {"total_ms": p.total_ms[k], "launches": int(p.launches[k])} for k in range(_K)}
+        return {KERNEL_NAMES[k]: {"total_ms": p.total_ms[k], "launches": int(p.launches[k]), "min_ms": p.min_ms[k], "p10_ms": p.p10_ms[k],
+                                  "p50_ms": p.p50_ms[k], "p90_ms": p.p90_ms[k], "max_ms": p.max_ms[k]} for k in range(_K)}

@@ -214,6 +214,16 @@ def test_profiling_counters(ctx):
             for k, v in p.items():
                 assert v["launches"] == (1 if k in names else 0), (fused, k)
                 assert (v["total_ms"] > 0) == (k in names)
+        # distribution of per-launch durations: 12 launches -> ordered percentiles that bracket the mean
+        ctx.set_option("fused", 1)
+        ctx.set_profiling(True)
+        for _ in range(12):
+            ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
+        v = ctx.profile_read(reset=True)["equalize_fused_kernel"]
+        assert v["launches"] == 12
+        assert 0 < v["min_ms"] <= v["p10_ms"] <= v["p50_ms"] <= v["p90_ms"] <= v["max_ms"]
+        assert v["min_ms"] <= v["total_ms"] / 12 <= v["max_ms"]
+        assert ctx.profile_read(reset=True)["equalize_fused_kernel"]["max_ms"] == 0          # reset clears the samples
     finally:
         ctx.set_option("fused", 1)
         ctx.set_profiling(False)
