@@ -116,6 +116,25 @@ def cpu_baseline(args, w, h):
             "value_1thread": round(single, 2), "value_1080p": round(fps1080, 2)}
 
 
+def opencv_cross_check(ctx, w, h, dist_name):
+    """the oracle is a restatement (parity unpinned).  Wherever a real OpenCV is importable, compare the GPU
+    path with cv2 itself on one frame and say so in the JSON line; None when there is no cv2 (this image has none)."""
+    try:
+        import cv2
+    except Exception:
+        return None
+    import numpy as np
+    from mi_lumaeq import synth
+    y = synth.nv12_frame(w, h, dist_name, 4242)[: w * h].reshape(h, w)
+    res = {"version": cv2.__version__}
+    try:
+        res["equalizeHist_bit_exact"] = bool(np.array_equal(ctx.equalize_hist(y), cv2.equalizeHist(y)))
+        res["clahe_2.0_8x8_bit_exact"] = bool(np.array_equal(ctx.clahe(y, 2.0, 8, 8), cv2.createCLAHE(2.0, (8, 8)).apply(y)))
+    except Exception as e:                 # a broken cv2 build must not take the bench line down
+        res["error"] = repr(e)
+    return res
+
+
 def main():
     args = parse_args()
     import torch
@@ -271,6 +290,8 @@ def main():
         "kernels": kinfo,
     }
 
+    if world == 1:
+        out["opencv_cross_check"] = opencv_cross_check(ctx, w, h, args.dist)
     if world == 1 and not args.no_extras:
         out["extras"] = extras(ctx, args, torch, mi_lumaeq, synth)
     if world == 1 and not args.no_cpu_baseline:
