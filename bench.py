@@ -129,7 +129,11 @@ def opencv_cross_check(ctx, w, h, dist_name):
     res = {"version": cv2.__version__}
     try:
         res["equalizeHist_bit_exact"] = bool(np.array_equal(ctx.equalize_hist(y), cv2.equalizeHist(y)))
-        res["clahe_2.0_8x8_bit_exact"] = bool(np.array_equal(ctx.clahe(y, 2.0, 8, 8), cv2.createCLAHE(2.0, (8, 8)).apply(y)))
+        want = cv2.createCLAHE(2.0, (8, 8)).apply(y)
+        res["clahe_2.0_8x8_bit_exact"] = bool(np.array_equal(ctx.clahe(y, 2.0, 8, 8), want))          # x86-64 baseline arithmetic
+        ctx.set_option("clahe_fp_contract", 1)                                                      # GCC FMA contraction (aarch64 builds)
+        res["clahe_2.0_8x8_bit_exact_fp_contract"] = bool(np.array_equal(ctx.clahe(y, 2.0, 8, 8), want))
+        ctx.set_option("clahe_fp_contract", 0)
     except Exception as e:                 # a broken cv2 build must not take the bench line down
         res["error"] = repr(e)
     return res

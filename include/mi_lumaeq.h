@@ -228,6 +228,10 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * inter-workgroup wait, default 2000), "fused_fault_inject" (test hook), "clahe_float_tables" (1/0),
  * "bgr_fused" (1/0, default 1: mi_bgr_luma_op_u8c3 runs as two passes over the interleaved image instead of through
  * Y/U/V planes; CLAHE only for unpadded shapes with tile_w % 16 == 0),
+ * "clahe_fp_contract" (1/0, default 0: CLAHE interpolation arithmetic.  0 = every multiply and add rounded separately, what an
+ * x86-64 baseline build of OpenCV computes; 1 = the fused multiply-adds GCC forms from clahe.cpp's expressions on FMA targets
+ * under its default -ffp-contract=fast, i.e. a distribution OpenCV on aarch64 -- the reference's own board: txf = fma(x, 1/tw, -0.5),
+ * res = fma(fma(l11, xa1, l12*xa), ya1, fma(l21, xa1, l22*xa) * ya).  The two differ by 1 in about 0.03 % of the pixels),
  * "clahe16_transposed" (1/0, default 0: value-major LUT layout for the 16-bit interpolation, faster on full-range content and
  * slower on narrow-range content),
  * "host_direct" (1/0, default 1: the host-pointer forms hand contiguous planes to the copy engine as they are; 0 stages

@@ -169,6 +169,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "bgr_fused")) { c->bgr_fused = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
     if (!strcmp(name, "host_direct")) { c->host_direct = value != 0; return MI_OK; }
+    if (!strcmp(name, "clahe_fp_contract")) { c->clahe_fp_contract = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe16_transposed")) { c->clahe16_transposed = value != 0; return MI_OK; }
     return fail(c, MI_ERR_BAD_ARG, "unknown option");
 }

@@ -24,6 +24,7 @@ mi_status clahe_geometry(mi_ctx* c, int width, int height, double clip_limit, in
     g->clip = clip;
     g->inv_tw = 1.0f / (float)g->tile_w;
     g->inv_th = 1.0f / (float)g->tile_h;
+    g->contract = c->clahe_fp_contract;
     return MI_OK;
 }
 
@@ -72,12 +73,16 @@ mi_status launch_interp(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const Clah
         const int rows_per_band = g.tile_h + 2 * kBandMargin;
         int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, rows_per_band / 8), 64LL}));
         if ((long long)bands * subs > 0x7fffffffLL || segs > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "image too wide");
-        if (npairs <= kMaxPairsLdsF32 && c->clahe_float_tables)
-            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_kernel<true>, dim3(bands * subs, nf, segs), dim3(kThreads),
-                   (size_t)npairs * 256 * 4 * sizeof(float), p, g, d_luts, subs, groups, uv);
-        else
-            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_kernel<false>, dim3(bands * subs, nf, segs), dim3(kThreads),
-                   (size_t)npairs * 256 * sizeof(uint32_t), p, g, d_luts, subs, groups, uv);
+        const dim3 grid(bands * subs, nf, segs);
+        if (npairs <= kMaxPairsLdsF32 && c->clahe_float_tables) {
+            const size_t lds = (size_t)npairs * 256 * 4 * sizeof(float);
+            if (g.contract) LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<true, true>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv);
+            else            LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<true, false>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv);
+        } else {
+            const size_t lds = (size_t)npairs * 256 * sizeof(uint32_t);
+            if (g.contract) LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<false, true>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv);
+            else            LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<false, false>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv);
+        }
     } else {
         if (a.height > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "height > 65535 with tiles_x > 62");
         LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp_global_kernel,

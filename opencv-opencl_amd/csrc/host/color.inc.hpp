@@ -86,7 +86,7 @@ mi_status bgr_luma_dev(mi_ctx* c, hipStream_t s, const Color3Args& a, int op, do
         mi_status st = clahe_geometry(c, a.width, a.height, clip, tx, ty, &g);
         if (st) return st;
         const int tiles = tx * ty;
-        const bool shape_ok = a.width % tx == 0 && a.height % ty == 0 && g.tile_w % 16 == 0 && tx + 1 <= kMaxPairsLdsF32 &&
+        const bool shape_ok = !g.contract && a.width % tx == 0 && a.height % ty == 0 && g.tile_w % 16 == 0 && tx + 1 <= kMaxPairsLdsF32 &&
                               tiles <= kMaxGridY && a.width / kInterpPx <= kThreads * kMaxGridY &&
                               (((uintptr_t)a.src | (uintptr_t)a.dst | a.src_step | a.dst_step | a.src_frame | a.dst_frame) & 15) == 0;
         if (shape_ok) {

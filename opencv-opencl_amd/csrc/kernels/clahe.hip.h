@@ -15,6 +15,9 @@ struct ClaheGeom {
     int clip;                   // integer clip limit (0 = off)
     float lut_scale;            // 255.f / (tile_w*tile_h), computed on the host (IEEE division)
     float inv_tw, inv_th;       // 1.f/tile_w, 1.f/tile_h, computed on the host
+    int contract;               // 0: separately rounded mul/add (x86-64 baseline OpenCV).  1: the FMAs GCC forms from clahe.cpp's
+                                // expressions on FMA targets (distribution OpenCV on aarch64, the reference's board); see
+                                // oracle/lumaeq_oracle.c orc_set_fp_contract
 };
 
 // core/src/copy.cpp borderInterpolate(p, len, BORDER_REFLECT_101)
@@ -160,21 +163,36 @@ constexpr int kBandMargin = 4;          // rows; covers the f32 rounding of y*in
 
 __device__ __forceinline__ int floor_f32_to_int(float v) { const int i = (int)v; return i - ((float)i > v); }   // cvFloor
 
+// p * inv - 0.5f in the two arithmetic modes (ClaheGeom::contract)
+template <bool FMA>
+__device__ __forceinline__ float tile_coord(int p, float inv) { return FMA ? __fmaf_rn((float)p, inv, -0.5f) : __fsub_rn(__fmul_rn((float)p, inv), 0.5f); }
+__device__ __forceinline__ float tile_coord(int p, float inv, int contract) { return contract ? tile_coord<true>(p, inv) : tile_coord<false>(p, inv); }
+
 // res = (a*xa1 + b*xa)*ya1 + (c*xa1 + d*xa)*ya, nine individually rounded f32 ops, then round half to even.
+// contracted form (GCC, FMA target): fma(fma(a, xa1, b*xa), ya1, fma(c, xa1, d*xa) * ya)
+template <bool FMA = false>
+__device__ __forceinline__ float clahe_blend_f(float a, float b, float c, float d, float xa, float xa1, float ya, float ya1)
+{
+    if (FMA) return __fmaf_rn(__fmaf_rn(a, xa1, __fmul_rn(b, xa)), ya1, __fmul_rn(__fmaf_rn(c, xa1, __fmul_rn(d, xa)), ya));
+    const float top = __fmul_rn(__fadd_rn(__fmul_rn(a, xa1), __fmul_rn(b, xa)), ya1);
+    const float bot = __fmul_rn(__fadd_rn(__fmul_rn(c, xa1), __fmul_rn(d, xa)), ya);
+    return __fadd_rn(top, bot);
+}
+template <bool FMA = false>
 __device__ __forceinline__ float clahe_blend(uint32_t q, float xa, float xa1, float ya, float ya1)
 {
     const float a = (float)(q & 0xffu), b = (float)((q >> 8) & 0xffu), c = (float)((q >> 16) & 0xffu), d = (float)(q >> 24);
-    const float top = __fmul_rn(__fadd_rn(__fmul_rn(a, xa1), __fmul_rn(b, xa)), ya1);
-    const float bot = __fmul_rn(__fadd_rn(__fmul_rn(c, xa1), __fmul_rn(d, xa)), ya);
-    return rintf(__fadd_rn(top, bot));                               // v_rndne_f32: cvRound
+    return rintf(clahe_blend_f<FMA>(a, b, c, d, xa, xa1, ya, ya1));  // v_rndne_f32: cvRound
 }
+template <bool FMA = false>
 __device__ __forceinline__ uint32_t clahe_px(uint32_t q, float xa, float xa1, float ya, float ya1)
 {
-    int r = (int)clahe_blend(q, xa, xa1, ya, ya1);
+    int r = (int)clahe_blend<FMA>(q, xa, xa1, ya, ya1);
     r = r < 0 ? 0 : (r > 255 ? 255 : r);                             // saturate_cast<uchar>
     return (uint32_t)r;
 }
 // 16 pixels of one row: one ds_read_b32 per pixel, v_cvt_pk_u8_f32 (saturating, input already integral) packs the bytes
+template <bool FMA = false>
 __device__ __forceinline__ u32x4 clahe_vec16(const uint32_t* quad, u32x4 q, const int* poff, const float* xa, const float* xa1, float ya, float ya1)
 {
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
@@ -186,7 +204,7 @@ __device__ __forceinline__ u32x4 clahe_vec16(const uint32_t* quad, u32x4 q, cons
         for (int b = 0; b < 4; ++b) {
             const int j = k * 4 + b;
             const uint32_t v = (w[k] >> (8 * b)) & 0xffu;
-            acc = __builtin_amdgcn_cvt_pk_u8_f32(clahe_blend(quad[poff[j] + v], xa[j], xa1[j], ya, ya1), b, acc);
+            acc = __builtin_amdgcn_cvt_pk_u8_f32(clahe_blend<FMA>(quad[poff[j] + v], xa[j], xa1[j], ya, ya1), b, acc);
         }
         ow[k] = acc;
     }
@@ -211,6 +229,13 @@ __device__ __forceinline__ f32x2 pk_mul_bcast_hi(f32x2 a, f32x2 x)      // {a.x 
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(x));
     return d;
 }
+__device__ __forceinline__ f32x2 pk_fma_bcast_lo(f32x2 a, f32x2 x, f32x2 c)      // {a.x * x.x + c.x, a.y * x.x + c.y}, one rounding each
+{
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(x), "v"(c));
+    return d;
+}
+template <bool FMA = false>
 __device__ __forceinline__ u32x4 clahe_vec16_f32(const f32x4* quadf, u32x4 q, const int* poff, const f32x2* xw, float ya, float ya1)
 {
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
@@ -228,18 +253,22 @@ __device__ __forceinline__ u32x4 clahe_vec16_f32(const f32x4* quadf, u32x4 q, co
         for (int b = 0; b < 4; ++b) {
             const int j = k * 4 + b;
             const f32x2 ac = {e[b].x, e[b].y}, bd = {e[b].z, e[b].w};
-            tb[b] = (pk_mul_bcast_lo(ac, xw[j]) + pk_mul_bcast_hi(bd, xw[j])) * yv;      // pk_mul, pk_mul, pk_add, pk_mul
+            if (FMA) tb[b] = pk_fma_bcast_lo(ac, xw[j], pk_mul_bcast_hi(bd, xw[j]));     // {fma(a,xa1,b*xa), fma(c,xa1,d*xa)}
+            else tb[b] = (pk_mul_bcast_lo(ac, xw[j]) + pk_mul_bcast_hi(bd, xw[j])) * yv;  // pk_mul, pk_mul, pk_add, pk_mul
         }
         uint32_t acc = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__fadd_rn(tb[b].x, tb[b].y)), b, acc);
+        for (int b = 0; b < 4; ++b) {
+            const float r = FMA ? __fmaf_rn(tb[b].x, ya1, __fmul_rn(tb[b].y, ya)) : __fadd_rn(tb[b].x, tb[b].y);
+            acc = __builtin_amdgcn_cvt_pk_u8_f32(rintf(r), b, acc);
+        }
         ow[k] = acc;
     }
     u32x4 o; o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
     return o;
 }
 
-template <bool FT>
+template <bool FT, bool FMA>
 __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, ClaheGeom g, const uint8_t* __restrict__ luts,
                                                                int subs, int groups, UVJob uv)
 {
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
         int poff[kInterpPx];
 #pragma unroll
         for (int j = 0; j < kInterpPx; ++j) {
-            const float txf = __fsub_rn(__fmul_rn((float)(x0 + j), g.inv_tw), 0.5f);
+            const float txf = tile_coord<FMA>(x0 + j, g.inv_tw);
             const int tx1 = floor_f32_to_int(txf);
             xa[j] = __fsub_rn(txf, (float)tx1);
             xa1[j] = __fsub_rn(1.0f, xa[j]);
@@ -299,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
         const bool full = x0 + kInterpPx <= g.width;
         // ty1 is monotone in y: trim the widened range to the rows that really belong to this band, using the
         // reference's own float expression (at most kBandMargin+1 steps per end)
-        auto ty1_of = [&](int y) { return floor_f32_to_int(__fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f)); };
+        auto ty1_of = [&](int y) { return floor_f32_to_int(tile_coord<FMA>(y, g.inv_th)); };
         int ya_lo = y_lo, ya_hi = y_hi;
         while (ya_lo < ya_hi && ty1_of(ya_lo) != ty1u) ++ya_lo;
         while (ya_hi > ya_lo && ty1_of(ya_hi - 1) != ty1u) --ya_hi;
@@ -310,10 +339,10 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
             // flops, 16 LDS reads); an explicit 2-row software pipeline measured 11 % SLOWER than letting the
             // other resident waves cover the load latency, so the row loop stays simple.
             auto do_row = [&](int yy, const u32x4& q) {
-                const float tyf = __fsub_rn(__fmul_rn((float)yy, g.inv_th), 0.5f);
+                const float tyf = tile_coord<FMA>(yy, g.inv_th);
                 const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
                 *reinterpret_cast<u32x4_u*>(dst + (long long)yy * p.dst_step + x0) =
-                    FT ? clahe_vec16_f32(quadf, q, poff, xw, ya, ya1) : clahe_vec16(quad, q, poff, xa, xa1, ya, ya1);
+                    FT ? clahe_vec16_f32<FMA>(quadf, q, poff, xw, ya, ya1) : clahe_vec16<FMA>(quad, q, poff, xa, xa1, ya, ya1);
             };
             constexpr int kRowsInFlight = FT ? 4 : 2;         // register budget: stay at 4 waves/SIMD (<= 128 VGPRs)
             // kRowsInFlight rows are loaded before the first is blended: a lane then has 64 B in flight instead of 16, and a
@@ -331,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
             }
         } else {
             for (; y < ya_hi; y += phases) {
-                const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+                const float tyf = tile_coord<FMA>(y, g.inv_th);
                 const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
                 const uint8_t* sr = src + (long long)y * p.src_step + x0;
                 uint8_t* dr = dst + (long long)y * p.dst_step + x0;
@@ -345,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
                         } else {
                             e = quad[poff[j] + sr[j]];
                         }
-                        dr[j] = (uint8_t)clahe_px(e, xa[j], xa1[j], ya, ya1);
+                        dr[j] = (uint8_t)clahe_px<FMA>(e, xa[j], xa1[j], ya, ya1);
                     }
             }
         }
@@ -362,11 +391,11 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_global_kernel(PlaneBatc
     const int x = blockIdx.x * kThreads + threadIdx.x;
     if (x >= g.width) return;
     const uint8_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * 256;
-    const float txf = __fsub_rn(__fmul_rn((float)x, g.inv_tw), 0.5f);
+    const float txf = tile_coord(x, g.inv_tw, g.contract);
     int tx1 = floor_f32_to_int(txf);
     const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
     int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
-    const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+    const float tyf = tile_coord(y, g.inv_th, g.contract);
     int ty1 = floor_f32_to_int(tyf);
     const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
     int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
@@ -375,7 +404,8 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_global_kernel(PlaneBatc
                        ((uint32_t)lf[((size_t)ty1 * g.tiles_x + tx2) * 256 + v] << 8) |
                        ((uint32_t)lf[((size_t)ty2 * g.tiles_x + tx1) * 256 + v] << 16) |
                        ((uint32_t)lf[((size_t)ty2 * g.tiles_x + tx2) * 256 + v] << 24);
-    p.dst[(long long)f * p.dst_frame + (long long)y * p.dst_step + x] = (uint8_t)clahe_px(q, xa, xa1, ya, ya1);
+    p.dst[(long long)f * p.dst_frame + (long long)y * p.dst_step + x] =
+        (uint8_t)(g.contract ? clahe_px<true>(q, xa, xa1, ya, ya1) : clahe_px<false>(q, xa, xa1, ya, ya1));
 }
 
 // UV-only launch (used when the Y kernel cannot carry the UV job).

@@ -155,20 +155,18 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16_kernel(const uint8_t*
     const int x = blockIdx.x * kThreads + threadIdx.x;
     if (x >= g.width) return;
     const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
-    const float txf = __fsub_rn(__fmul_rn((float)x, g.inv_tw), 0.5f);
+    const float txf = tile_coord(x, g.inv_tw, g.contract);
     int tx1 = floor_f32_to_int(txf);
     const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
     int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
-    const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+    const float tyf = tile_coord(y, g.inv_th, g.contract);
     int ty1 = floor_f32_to_int(tyf);
     const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
     int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
     const uint32_t v = *reinterpret_cast<const uint16_t*>(src_base + (long long)f * src_frame + (long long)y * src_step + 2 * (long long)x);
     const float a = (float)lf[((size_t)ty1 * g.tiles_x + tx1) * kHist16 + v], b = (float)lf[((size_t)ty1 * g.tiles_x + tx2) * kHist16 + v];
     const float c = (float)lf[((size_t)ty2 * g.tiles_x + tx1) * kHist16 + v], d = (float)lf[((size_t)ty2 * g.tiles_x + tx2) * kHist16 + v];
-    const float top = __fmul_rn(__fadd_rn(__fmul_rn(a, xa1), __fmul_rn(b, xa)), ya1);
-    const float bot = __fmul_rn(__fadd_rn(__fmul_rn(c, xa1), __fmul_rn(d, xa)), ya);
-    int r = __float2int_rn(__fadd_rn(top, bot));
+    int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa, xa1, ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa, xa1, ya, ya1));
     r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
     *reinterpret_cast<uint16_t*>(dst_base + (long long)f * dst_frame + (long long)y * dst_step + 2 * (long long)x) = (uint16_t)r;
 }
@@ -206,11 +204,11 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16T_kernel(const uint8_t
     const int x = blockIdx.x * kThreads + threadIdx.x;
     if (x >= g.width) return;
     const int tiles = g.tiles_x * g.tiles_y;
-    const float txf = __fsub_rn(__fmul_rn((float)x, g.inv_tw), 0.5f);
+    const float txf = tile_coord(x, g.inv_tw, g.contract);
     int tx1 = floor_f32_to_int(txf);
     const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
     int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
-    const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
+    const float tyf = tile_coord(y, g.inv_th, g.contract);
     int ty1 = floor_f32_to_int(tyf);
     const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
     int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
@@ -218,9 +216,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16T_kernel(const uint8_t
     const uint16_t* e = lutT + ((size_t)f * kHist16 + v) * tiles;
     const float a = (float)e[ty1 * g.tiles_x + tx1], b = (float)e[ty1 * g.tiles_x + tx2];
     const float c = (float)e[ty2 * g.tiles_x + tx1], d = (float)e[ty2 * g.tiles_x + tx2];
-    const float top = __fmul_rn(__fadd_rn(__fmul_rn(a, xa1), __fmul_rn(b, xa)), ya1);
-    const float bot = __fmul_rn(__fadd_rn(__fmul_rn(c, xa1), __fmul_rn(d, xa)), ya);
-    int r = __float2int_rn(__fadd_rn(top, bot));
+    int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa, xa1, ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa, xa1, ya, ya1));
     r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
     *reinterpret_cast<uint16_t*>(dst_base + (long long)f * dst_frame + (long long)y * dst_step + 2 * (long long)x) = (uint16_t)r;
 }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void bgr_clahe_interp_kernel(ColorJob j, 
         const u32x4 yq = bgr16_to_y<true>(src + (long long)y * j.src_step, &u, &v);
         const float tyf = __fsub_rn(__fmul_rn((float)y, g.inv_th), 0.5f);
         const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
-        const u32x4 yo = clahe_vec16_f32(quadf, yq, poff, xw, ya, ya1);
+        const u32x4 yo = clahe_vec16_f32<false>(quadf, yq, poff, xw, ya, ya1);       // the host takes the planar path for ClaheGeom::contract
         uint32_t w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int px = 0; px < 16; ++px) {

@@ -206,6 +206,14 @@ inline void check(mi_ctx* c, mi_status st, const char* what)
 inline void setDevice(int device) { detail::tls_device() = device; }
 inline int getDevice() { return detail::tls_device(); }
 inline int getDeviceCount() { return mi_device_count(); }
+// Library option of the calling thread's context on its current device (mi_ctx_set_option), e.g.
+//   setOption("clahe_fp_contract", 1)  -- CLAHE interpolation with the fused multiply-adds a GCC build of OpenCV uses on
+//   FMA targets (the reference's aarch64 board) instead of the separately rounded x86-64 baseline arithmetic.
+inline void setOption(const char* name, int value)
+{
+    mi_ctx* c = detail::thread_ctx();
+    detail::check(c, mi_ctx_set_option(c, name, value), "mi_ctx_set_option");
+}
 
 // ---- cv::equalizeHist(InputArray src, OutputArray dst) ----
 inline void equalizeHist(const Mat& src, Mat& dst)

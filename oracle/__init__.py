@@ -219,6 +219,16 @@ def bgr_luma_op(src: np.ndarray, op: int = 0, clip_limit: float = 3.0, tiles_x: 
     return dst
 
 
+def set_fp_contract(on: bool) -> bool:
+    """CLAHE interpolation arithmetic: False (default) = separately rounded multiplies and adds (x86-64 baseline OpenCV);
+    True = the fused multiply-adds GCC forms on FMA targets (a distribution OpenCV for aarch64, the reference's own
+    platform).  Returns the previous setting.  Process-wide test switch."""
+    L = lib()
+    L.orc_set_fp_contract.argtypes = [ctypes.c_int]
+    L.orc_set_fp_contract.restype = ctypes.c_int
+    return bool(L.orc_set_fp_contract(1 if on else 0))
+
+
 def _nv12(a: np.ndarray, width: int, height: int) -> np.ndarray:
     a = np.ascontiguousarray(a, np.uint8).reshape(-1)
     if width < 0 or height < 0 or width % 2 or height % 2:

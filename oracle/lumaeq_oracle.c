@@ -74,6 +74,36 @@ int orc_set_threads(int n)
 #endif
 }
 
+/* Floating-point contraction of the CLAHE interpolation (test infrastructure switch, process-wide).
+ * 0 (default): every multiply and add rounded separately -- an x86-64 baseline build of OpenCV (no FMA).
+ * 1: the fused multiply-adds GCC forms from clahe.cpp's expressions when the target has FMA and -ffp-contract=fast is in
+ *    force (GCC's default outside ISO mode) -- what a distribution build of OpenCV 4.4 for aarch64 computes, and the
+ *    reference's own binaries ARE aarch64 (ZCU106).  The pattern is decided in GCC's target-independent widening_mul pass
+ *    and was read off `g++ -O2 -mfma -ffp-contract=fast -S` on the expressions below (tests/test_oracle.py re-checks it
+ *    against such a build whenever the host CPU has FMA):
+ *        txf = fma(x, inv_tw, -0.5f);   tyf = fma(y, inv_th, -0.5f);
+ *        res = fma(fma(l11, xa1, l12 * xa), ya1, fma(l21, xa1, l22 * xa) * ya);
+ *    sum * lutScale and sum * scale are single multiplies and do not change. */
+static int g_fp_contract = 0;
+int orc_set_fp_contract(int on) { const int old = g_fp_contract; if (on >= 0) g_fp_contract = on != 0; return old; }
+
+static inline float orc_tf(int p, float inv)                       /* p * inv - 0.5f */
+{
+    return g_fp_contract ? fmaf((float)p, inv, -0.5f) : (float)p * inv - 0.5f;
+}
+static inline float orc_blend(float l11, float l12, float l21, float l22, float xa, float xa1, float ya, float ya1)
+{
+    if (g_fp_contract) return fmaf(fmaf(l11, xa1, l12 * xa), ya1, fmaf(l21, xa1, l22 * xa) * ya);
+    return (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+}
+
+/* test hooks: the two scalar expressions on their own (tests/test_oracle.py compares them with a GCC build that contracts) */
+float orc_probe_tf(int p, float inv) { return orc_tf(p, inv); }
+float orc_probe_blend(int l11, int l12, int l21, int l22, float xa, float ya)
+{
+    return orc_blend((float)l11, (float)l12, (float)l21, (float)l22, xa, 1.0f - xa, ya, 1.0f - ya);
+}
+
 /* ------------------------------------------------------------------------------------------
  * Stage A2: histogram of a CV_8UC1 image that honours `step`.
  * histogram.cpp EqualizeHistCalcHist_Invoker: exact int32 counts; threading is row-striped and
@@ -271,7 +301,7 @@ int orc_clahe_interpolate(const uint8_t* src, size_t src_step, uint8_t* dst, siz
     float* xa1 = xa + width;
     const float inv_tw = 1.0f / (float)tile_w;
     for (int x = 0; x < width; ++x) {
-        float txf = (float)x * inv_tw - 0.5f;
+        float txf = orc_tf(x, inv_tw);
         int tx1 = orc_floor(txf);
         int tx2 = tx1 + 1;
         xa[x] = txf - (float)tx1;
@@ -288,7 +318,7 @@ int orc_clahe_interpolate(const uint8_t* src, size_t src_step, uint8_t* dst, siz
     for (int y = 0; y < height; ++y) {
         const uint8_t* s = src + (size_t)y * src_step;
         uint8_t* d = dst + (size_t)y * dst_step;
-        float tyf = (float)y * inv_th - 0.5f;
+        float tyf = orc_tf(y, inv_th);
         int ty1 = orc_floor(tyf);
         int ty2 = ty1 + 1;
         float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
@@ -299,8 +329,7 @@ int orc_clahe_interpolate(const uint8_t* src, size_t src_step, uint8_t* dst, siz
         for (int x = 0; x < width; ++x) {
             int v = s[x];
             int i1 = ind1[x] + v, i2 = ind2[x] + v;
-            float res = ((float)p1[i1] * xa1[x] + (float)p1[i2] * xa[x]) * ya1 +
-                        ((float)p2[i1] * xa1[x] + (float)p2[i2] * xa[x]) * ya;
+            float res = orc_blend((float)p1[i1], (float)p1[i2], (float)p2[i1], (float)p2[i2], xa[x], xa1[x], ya, ya1);
             d[x] = orc_sat_u8(orc_round(res));
         }
     }
@@ -393,7 +422,7 @@ int orc_clahe_u16(const uint16_t* src, size_t src_step, uint16_t* dst, size_t ds
     for (int y = 0; y < height; ++y) {
         const uint16_t* s = (const uint16_t*)((const uint8_t*)src + (size_t)y * src_step);
         uint16_t* d = (uint16_t*)((uint8_t*)dst + (size_t)y * dst_step);
-        float tyf = (float)y * inv_th - 0.5f;
+        float tyf = orc_tf(y, inv_th);
         int ty1 = orc_floor(tyf), ty2 = ty1 + 1;
         float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
         if (ty1 < 0) ty1 = 0;
@@ -401,14 +430,14 @@ int orc_clahe_u16(const uint16_t* src, size_t src_step, uint16_t* dst, size_t ds
         const uint16_t* p1 = luts + (size_t)ty1 * tiles_x * HS;
         const uint16_t* p2 = luts + (size_t)ty2 * tiles_x * HS;
         for (int x = 0; x < width; ++x) {
-            float txf = (float)x * inv_tw - 0.5f;
+            float txf = orc_tf(x, inv_tw);
             int tx1 = orc_floor(txf), tx2 = tx1 + 1;
             float xa = txf - (float)tx1, xa1 = 1.0f - xa;
             if (tx1 < 0) tx1 = 0;
             if (tx2 > tiles_x - 1) tx2 = tiles_x - 1;
             const int v = s[x];
-            float res = ((float)p1[(size_t)tx1 * HS + v] * xa1 + (float)p1[(size_t)tx2 * HS + v] * xa) * ya1 +
-                        ((float)p2[(size_t)tx1 * HS + v] * xa1 + (float)p2[(size_t)tx2 * HS + v] * xa) * ya;
+            float res = orc_blend((float)p1[(size_t)tx1 * HS + v], (float)p1[(size_t)tx2 * HS + v],
+                                  (float)p2[(size_t)tx1 * HS + v], (float)p2[(size_t)tx2 * HS + v], xa, xa1, ya, ya1);
             d[x] = orc_sat_u16(orc_round(res));
         }
     }

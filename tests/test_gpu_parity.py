@@ -864,3 +864,42 @@ def test_host_forms_staged_and_direct_agree(ctx):
         assert np.array_equal(outs[0][0], oracle.equalize_hist(y)) and np.array_equal(outs[1][1], oracle.clahe(y, 2.0, 8, 8))
     finally:
         ctx.set_option("host_direct", 1)
+
+
+def test_clahe_fp_contract_mode(ctx):
+    """Second arithmetic mode of the CLAHE interpolation (option "clahe_fp_contract"): the FMAs a GCC build of OpenCV forms on
+    FMA targets such as the reference's aarch64 board.  Bit-exact against the oracle in the same mode for every kernel
+    variant (f32 pair tables, uchar quads, global-LUT fallback, 16-bit, BGR wrapper), and really different from mode 0."""
+    rng = np.random.default_rng(77)
+    old = oracle.set_fp_contract(True)
+    try:
+        ctx.set_option("clahe_fp_contract", 1)
+        differing = 0
+        for (h, w), cfg in [((1080, 1920), (2.0, 8, 8)), ((1079, 1919), (3.0, 4, 4)), ((360, 640), (2.0, 16, 2)), ((47, 63), (40.0, 8, 8)),
+                            ((128, 1024), (2.0, 70, 3)), ((2160, 3840), (2.0, 8, 8))]:
+            y = synth.y_plane(w, h, "D2", 9)
+            got = ctx.clahe(y, *cfg)
+            assert np.array_equal(got, oracle.clahe(y, *cfg)), ((h, w), cfg)
+            oracle.set_fp_contract(False)
+            differing += int((got != oracle.clahe(y, *cfg)).sum())
+            oracle.set_fp_contract(True)
+        assert differing > 0
+        ctx.set_option("clahe_float_tables", 0)                            # uchar-quad tables
+        y = synth.y_plane(1920, 1080, "D1", 10)
+        assert np.array_equal(ctx.clahe(y, 2.0, 8, 8), oracle.clahe(y, 2.0, 8, 8))
+        ctx.set_option("clahe_float_tables", 1)
+        s16 = rng.integers(0, 65536, (360, 640), dtype=np.uint16)
+        assert np.array_equal(ctx.clahe16(s16, 2.0, 8, 8), oracle.clahe16(s16, 2.0, 8, 8))
+        bgr = _bgr(640, 360, 12)
+        assert np.array_equal(ctx.bgr_luma_op(bgr, mi_lumaeq.OP_CLAHE, 2.0, 8, 8), oracle.bgr_luma_op(bgr, 1, 2.0, 8, 8))
+        import torch
+        nv = torch.from_numpy(np.stack([synth.nv12_frame(1920, 1080, "D2", 13 + k) for k in range(3)])).cuda()
+        out = torch.empty_like(nv)
+        ctx.clahe_nv12_batch_dev(nv, out, 1920, 1080, 3, mi_lumaeq.UV_COPY, 2.0, 8, 8)
+        ctx.synchronize()
+        for k in range(3):
+            assert np.array_equal(out[k].cpu().numpy(), oracle.nv12_frame(nv[k].cpu().numpy(), 1920, 1080, uv_mode=1, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8)), k
+    finally:
+        oracle.set_fp_contract(old)
+        ctx.set_option("clahe_fp_contract", 0)
+        ctx.set_option("clahe_float_tables", 1)

@@ -299,3 +299,50 @@ def test_photo_fixture():
     assert np.array_equal(c8, oracle.np_clahe(y, 2.0, 8, 8))
     assert crc(oracle.bgr_luma_op(crop, 0)) == int(z["crc_bgr_luma_equalize_crop"])
     assert crc(oracle.bgr_luma_op(crop, 1, 3.0, 4, 4)) == int(z["crc_bgr_luma_clahe_crop"])
+
+
+def test_fp_contract_mode_matches_what_gcc_does(tmp_path):
+    """The oracle's second arithmetic mode (set_fp_contract: the FMAs GCC forms from clahe.cpp's expressions on FMA targets,
+    i.e. a distribution OpenCV on the reference's aarch64 board) against the expressions compiled by GCC itself, once with
+    -ffp-contract=off (= mode 0) and, where this CPU has FMA, once with -mfma -ffp-contract=fast (= mode 1)."""
+    import ctypes
+    import struct
+    import subprocess
+    src = Path(__file__).parent / "cxx" / "contract_probe.cpp"
+    rng = np.random.default_rng(11)
+    n = 4000
+    xs = rng.integers(0, 4096, n)
+    invs = (np.float32(1.0) / rng.choice(np.array([480, 270, 240, 135, 60, 7, 3], np.float32), n)).astype(np.float32)
+    ls = rng.integers(0, 256, (n, 4))
+    xa = rng.random(n, dtype=np.float32)
+    ya = rng.random(n, dtype=np.float32)
+    feed = "".join(f"{int(xs[i])} {float(invs[i]).hex()} {ls[i,0]} {ls[i,1]} {ls[i,2]} {ls[i,3]} {float(xa[i]).hex()} {float(ya[i]).hex()}\n"
+                   for i in range(n))
+    L = oracle.lib()
+    L.orc_probe_tf.argtypes = [ctypes.c_int, ctypes.c_float]; L.orc_probe_tf.restype = ctypes.c_float
+    L.orc_probe_blend.argtypes = [ctypes.c_int] * 4 + [ctypes.c_float] * 2; L.orc_probe_blend.restype = ctypes.c_float
+    bits = lambda f: struct.unpack("<I", struct.pack("<f", f))[0]
+    have_fma = " fma " in open("/proc/cpuinfo").read()
+    builds = [(0, ["-ffp-contract=off"])] + ([(1, ["-mfma", "-ffp-contract=fast"])] if have_fma else [])
+    differs = 0
+    for mode, flags in builds:
+        exe = tmp_path / f"probe{mode}"
+        subprocess.run(["g++", "-O2", *flags, str(src), "-o", str(exe)], check=True)
+        out = subprocess.run([str(exe)], input=feed, capture_output=True, text=True, check=True).stdout.split()
+        assert len(out) == 2 * n
+        old = oracle.set_fp_contract(bool(mode))
+        try:
+            for i in range(n):
+                want_t, want_r = int(out[2 * i], 16), int(out[2 * i + 1], 16)
+                assert bits(L.orc_probe_tf(int(xs[i]), float(invs[i]))) == want_t, (mode, i)
+                got_r = bits(L.orc_probe_blend(int(ls[i, 0]), int(ls[i, 1]), int(ls[i, 2]), int(ls[i, 3]), float(xa[i]), float(ya[i])))
+                assert got_r == want_r, (mode, i)
+        finally:
+            oracle.set_fp_contract(old)
+    if have_fma:                                   # and the two modes really are different functions
+        oracle.set_fp_contract(False)
+        a = [bits(L.orc_probe_blend(int(ls[i, 0]), int(ls[i, 1]), int(ls[i, 2]), int(ls[i, 3]), float(xa[i]), float(ya[i]))) for i in range(n)]
+        oracle.set_fp_contract(True)
+        b = [bits(L.orc_probe_blend(int(ls[i, 0]), int(ls[i, 1]), int(ls[i, 2]), int(ls[i, 3]), float(xa[i]), float(ya[i]))) for i in range(n)]
+        oracle.set_fp_contract(False)
+        assert sum(x != y for x, y in zip(a, b)) > 0
