@@ -17,6 +17,26 @@ import numpy as np
 F = np.float32
 
 
+def _fma32(a, b, c):
+    """Correctly rounded float32 fused multiply-add for float32 arrays, without an fma primitive: the product of two
+    binary32 numbers is exact in binary64; the sum is formed in binary64 with ROUND-TO-ODD (the inexact bit is kept as a sticky
+    LSB via the TwoSum residual), after which the final rounding to binary32 cannot double-round (53 >= 2*24 + 2)."""
+    a = np.asarray(a, np.float32).astype(np.float64)
+    b = np.asarray(b, np.float32).astype(np.float64)
+    c = np.asarray(c, np.float32).astype(np.float64)
+    p = a * b                                            # exact
+    s = p + c                                            # round-to-nearest binary64
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)                      # exact residual (p + c) - s
+    inexact = err != 0
+    # truncate toward zero where round-to-nearest went away from zero, then force the last bit to 1
+    away = inexact & (np.sign(err) != np.sign(s)) & (s != 0)
+    t = np.where(away, np.nextafter(s, 0.0), s)
+    bits = t.view(np.int64) if t.ndim else np.array(t).view(np.int64)
+    bits = np.where(inexact, bits | 1, bits)
+    return bits.astype(np.int64).view(np.float64).astype(np.float32)
+
+
 def np_equalize_hist(src: np.ndarray) -> np.ndarray:
     src = np.asarray(src)
     assert src.dtype == np.uint8 and src.ndim == 2
@@ -59,8 +79,9 @@ def _reflect101_index(n_ext: int, n: int) -> np.ndarray:
     return np.where(m < n, m, period - m)
 
 
-def np_clahe(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_y: int = 8) -> np.ndarray:
-    """8-bit (histSize 256) or 16-bit (histSize 65536) CLAHE."""
+def np_clahe(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_y: int = 8, fp_contract: bool = False) -> np.ndarray:
+    """8-bit (histSize 256) or 16-bit (histSize 65536) CLAHE.  fp_contract: the fused multiply-adds GCC forms on
+    FMA targets (see lumaeq_oracle.c orc_set_fp_contract) instead of separately rounded operations."""
     src = np.asarray(src)
     assert src.dtype in (np.uint8, np.uint16) and src.ndim == 2
     HS = 256 if src.dtype == np.uint8 else 65536
@@ -92,7 +113,7 @@ def np_clahe(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_
 
     def axis_tables(n, tile, ntiles):
         inv = F(1.0) / F(tile)
-        tf = np.arange(n).astype(F) * inv - F(0.5)
+        tf = _fma32(np.arange(n).astype(F), inv, F(-0.5)) if fp_contract else np.arange(n).astype(F) * inv - F(0.5)
         t1 = np.floor(tf).astype(np.int64)
         a = tf - t1.astype(F)
         a1 = F(1.0) - a
@@ -105,9 +126,16 @@ def np_clahe(src: np.ndarray, clip_limit: float = 40.0, tiles_x: int = 8, tiles_
     B = luts[ty1[:, None], tx2[None, :], v].astype(F)
     C = luts[ty2[:, None], tx1[None, :], v].astype(F)
     D = luts[ty2[:, None], tx2[None, :], v].astype(F)
-    top = (A * xa1[None, :] + B * xa[None, :]) * ya1[:, None]
-    bot = (C * xa1[None, :] + D * xa[None, :]) * ya[:, None]
-    res = top + bot
+    if fp_contract:                                     # fma(fma(A, xa1, B*xa), ya1, fma(C, xa1, D*xa) * ya)
+        shp = A.shape
+        bx = lambda v: np.broadcast_to(v, shp)
+        top = _fma32(A, bx(xa1[None, :]), B * xa[None, :])
+        bot = _fma32(C, bx(xa1[None, :]), D * xa[None, :]) * ya[:, None]
+        res = _fma32(top, bx(ya1[:, None]), bot)
+    else:
+        top = (A * xa1[None, :] + B * xa[None, :]) * ya1[:, None]
+        bot = (C * xa1[None, :] + D * xa[None, :]) * ya[:, None]
+        res = top + bot
     assert res.dtype == np.float32
     return np.clip(np.rint(res), 0, HS - 1).astype(src.dtype)
 

@@ -346,3 +346,32 @@ def test_fp_contract_mode_matches_what_gcc_does(tmp_path):
         b = [bits(L.orc_probe_blend(int(ls[i, 0]), int(ls[i, 1]), int(ls[i, 2]), int(ls[i, 3]), float(xa[i]), float(ya[i]))) for i in range(n)]
         oracle.set_fp_contract(False)
         assert sum(x != y for x, y in zip(a, b)) > 0
+
+
+def test_c_vs_numpy_clahe_fp_contract():
+    """Mode 1 of the CLAHE blend (GCC FMA contraction) in the two independent restatements: explicit fmaf() in C against numpy with an
+    emulated, correctly rounded float32 fma (round-to-odd in binary64) -- whole images, odd shapes included, 8- and 16-bit."""
+    import ctypes
+    from oracle.np_oracle import _fma32
+    m = ctypes.CDLL("libm.so.6")
+    m.fmaf.argtypes = [ctypes.c_float] * 3; m.fmaf.restype = ctypes.c_float
+    rng = np.random.default_rng(3)
+    a = (rng.random(5000, dtype=np.float32) * 255).astype(np.float32)
+    b = rng.random(5000, dtype=np.float32)
+    c = (rng.random(5000, dtype=np.float32) * 255 * rng.choice([-1, 1], 5000)).astype(np.float32)
+    want = np.array([m.fmaf(float(x), float(y), float(z)) for x, y, z in zip(a, b, c)], np.float32)
+    assert np.array_equal(_fma32(a, b, c).view(np.int32), want.view(np.int32))
+    old = oracle.set_fp_contract(True)
+    try:
+        diff = 0
+        for (w, h), cfg in [((64, 48), (2.0, 8, 8)), ((63, 47), (3.0, 4, 4)), ((640, 360), (2.0, 8, 8)), ((481, 271), (40.0, 16, 2))]:
+            for dist in ("D1", "D2"):
+                y = synth.y_plane(w, h, dist, 21)
+                got = oracle.clahe(y, *cfg)
+                assert np.array_equal(got, oracle.np_clahe(y, *cfg, fp_contract=True)), ((w, h), cfg, dist)
+                diff += int((got != oracle.np_clahe(y, *cfg)).sum())
+        assert diff > 0                                   # the modes are not the same function
+        s16 = rng.integers(0, 65536, (90, 160), dtype=np.uint16)
+        assert np.array_equal(oracle.clahe16(s16, 2.0, 8, 8), oracle.np_clahe(s16, 2.0, 8, 8, fp_contract=True))
+    finally:
+        oracle.set_fp_contract(old)
