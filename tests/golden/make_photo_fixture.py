@@ -28,6 +28,7 @@ out = {
     "crc_equalize": crc(oracle.equalize_hist(y)),
     "crc_clahe_2_8x8": crc(oracle.clahe(y, 2.0, 8, 8)),
     "crc_clahe_3_4x4": crc(oracle.clahe(y, 3.0, 4, 4)),
+    "crc_clahe_2_8x8_fp_contract": crc((oracle.set_fp_contract(True), oracle.clahe(y, 2.0, 8, 8), oracle.set_fp_contract(False))[1]),
     "crc_bgr_luma_equalize_crop": crc(oracle.bgr_luma_op(crop, 0)),
     "crc_bgr_luma_clahe_crop": crc(oracle.bgr_luma_op(crop, 1, 3.0, 4, 4)),
 }

@@ -297,6 +297,12 @@ def test_photo_fixture():
     c8 = oracle.clahe(y, 2.0, 8, 8)
     assert crc(c8) == int(z["crc_clahe_2_8x8"]) and crc(oracle.clahe(y, 3.0, 4, 4)) == int(z["crc_clahe_3_4x4"])
     assert np.array_equal(c8, oracle.np_clahe(y, 2.0, 8, 8))
+    old = oracle.set_fp_contract(True)                          # the FMA-contracted flavour of the blend has its own recorded bytes
+    try:
+        c8f = oracle.clahe(y, 2.0, 8, 8)
+    finally:
+        oracle.set_fp_contract(old)
+    assert crc(c8f) == int(z["crc_clahe_2_8x8_fp_contract"]) and not np.array_equal(c8f, c8)
     assert crc(oracle.bgr_luma_op(crop, 0)) == int(z["crc_bgr_luma_equalize_crop"])
     assert crc(oracle.bgr_luma_op(crop, 1, 3.0, 4, 4)) == int(z["crc_bgr_luma_clahe_crop"])
 
