@@ -17,6 +17,7 @@ int orc_nv12_frame(const uint8_t*, uint8_t*, int, int, int, int, double, int, in
 int orc_bgr_luma_op(const uint8_t*, uint8_t*, int, int, int, double, int, int);
 int orc_bgr2yuv_u8(const uint8_t*, size_t, uint8_t*, size_t, int, int);
 int orc_nv12_bgr_equalize(const uint8_t*, uint8_t*, int, int);
+int orc_set_fp_contract(int);
 int orc_bgr_to_i420(const uint8_t*, uint8_t*, int, int);
 int orc_nv12_to_bgr(const uint8_t*, uint8_t*, int, int);
 int orc_clahe_u16(const uint16_t*, size_t, uint16_t*, size_t, int, int, double, int, int);
@@ -142,6 +143,26 @@ int main()
         EXPECT(memcmp(fused_clahe.data, want.data(), want.size()) == 0);
         bool threw = false;
         try { Mat g(4, 4, CV_8UC1), o; cvtColor(g, o, COLOR_BGR2YUV); } catch (const std::exception&) { threw = true; }
+        EXPECT(threw);
+    }
+    // --- the other arithmetic flavour of CLAHE::apply (GCC's FMA contraction, as OpenCV is built for the reference's aarch64 board)
+    {
+        Mat y_in(H, W, CV_8UC1, nv12.data());
+        std::vector<uint8_t> r0((size_t)W * H), r1((size_t)W * H);
+        orc_clahe_u8(nv12.data(), W, r0.data(), W, W, H, 2.0, 8, 8);
+        orc_set_fp_contract(1);
+        orc_clahe_u8(nv12.data(), W, r1.data(), W, W, H, 2.0, 8, 8);
+        orc_set_fp_contract(0);
+        Ptr<CLAHE> cl = createCLAHE(2.0, Size(8, 8));
+        Mat o0, o1;
+        cl->apply(y_in, o0);
+        setOption("clahe_fp_contract", 1);
+        cl->apply(y_in, o1);
+        setOption("clahe_fp_contract", 0);
+        EXPECT(memcmp(o0.data, r0.data(), r0.size()) == 0);
+        EXPECT(memcmp(o1.data, r1.data(), r1.size()) == 0);
+        bool threw = false;
+        try { setOption("no_such_option", 1); } catch (const std::exception&) { threw = true; }
         EXPECT(threw);
     }
     // --- BASELINE config 5 read literally: NV12 -> BGR -> equalizeHist on B, G, R -> NV12 in one call
