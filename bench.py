@@ -399,6 +399,27 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
         lambda: ctx.equalize_hist_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, stream=stream), 200), 4)
     res["single_frame_dev_clahe8x8_ms"] = round(timeit(
         lambda: ctx.clahe_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 200), 4)
+    # the launch-bound case replayed from a captured HIP graph (the library switches its hand-off to replay-safe mode when it sees a
+    # capture): one graph launch instead of 1 (equalize) / 2-3 (CLAHE) kernel launches per frame
+    gctx = None
+    try:
+        gctx = mi_lumaeq.Context(torch.cuda.current_device())   # its own context: a capture switches a context's hand-off mode for good
+        for name, fn in (("equalize", lambda st: gctx.equalize_hist_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, stream=st)),
+                         ("clahe8x8", lambda st: gctx.clahe_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=st))):
+            fn(stream)                                         # size the scratch eagerly: allocations are not capturable
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn(torch.cuda.current_stream().cuda_stream)
+            res[f"single_frame_dev_{name}_graph_replay_ms"] = round(timeit(g.replay, 200), 4)
+            del g
+        torch.cuda.synchronize()
+    except Exception as e:                                   # never let an optional figure take the bench line down
+        res["graph_replay_error"] = repr(e)
+    finally:
+        if gctx is not None:
+            torch.cuda.synchronize()
+            gctx.close()
     y = frame[0, : w * h].cpu().numpy().reshape(h, w)
     dst = np.empty_like(y)
     res["host_mat_equalize_ms_pcie_inclusive"] = round(timeit(lambda: ctx.equalize_hist(y, dst), 20), 3)
