@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--graph-extras", action="store_true", help="also time single-frame launches replayed from a captured HIP graph")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (=RCCL) for real multi-GPU runs; gloo only to rehearse the N>1 path on a 1-GPU box")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
@@ -403,6 +404,8 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     # capture): one graph launch instead of 1 (equalize) / 2-3 (CLAHE) kernel launches per frame
     gctx = None
     try:
+        if not args.graph_extras:
+            raise StopIteration
         gctx = mi_lumaeq.Context(torch.cuda.current_device())   # its own context: a capture switches a context's hand-off mode for good
         for name, fn in (("equalize", lambda st: gctx.equalize_hist_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, stream=st)),
                          ("clahe8x8", lambda st: gctx.clahe_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=st))):
@@ -414,6 +417,8 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
             res[f"single_frame_dev_{name}_graph_replay_ms"] = round(timeit(g.replay, 200), 4)
             del g
         torch.cuda.synchronize()
+    except StopIteration:
+        pass
     except Exception as e:                                   # never let an optional figure take the bench line down
         res["graph_replay_error"] = repr(e)
     finally:
