@@ -295,12 +295,19 @@ def main():
         "kernels": kinfo,
     }
 
+    # secondary figures must never cost the headline its JSON line
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:
+            print(f"[bench] {fn.__name__} failed: {e!r}", file=sys.stderr, flush=True)
+            return {"error": repr(e)}
     if world == 1:
-        out["opencv_cross_check"] = opencv_cross_check(ctx, w, h, args.dist)
+        out["opencv_cross_check"] = guarded(opencv_cross_check, ctx, w, h, args.dist)
     if world == 1 and not args.no_extras:
-        out["extras"] = extras(ctx, args, torch, mi_lumaeq, synth)
+        out["extras"] = guarded(extras, ctx, args, torch, mi_lumaeq, synth)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, w, h)
+        out["cpu_baseline"] = guarded(cpu_baseline, args, w, h)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
