@@ -378,6 +378,16 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
             torch.cuda.synchronize()
             by_dist[dname] = round(30 * args.batch / (time.perf_counter() - t0), 1)
             if dname == args.dist:
+                # the Y planes alone (cv::equalizeHist and nothing else: no NV12 rebuild), same frames, in place in the NV12 batch layout
+                fs = w * h * 3 // 2
+                for _ in range(3):
+                    ctx.equalize_hist_batch_dev(dd_in, dd_out, w, h, args.batch, src_frame=fs, dst_frame=fs, stream=sm)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    ctx.equalize_hist_batch_dev(dd_in, dd_out, w, h, args.batch, src_frame=fs, dst_frame=fs, stream=sm)
+                torch.cuda.synchronize()
+                res["y_plane_only_equalize_frames_per_s"] = round(30 * args.batch / (time.perf_counter() - t0), 1)
                 for _ in range(3):
                     ctx.equalize_hist_nv12_batch_dev(dd_in, dd_out, w, h, args.batch, mi_lumaeq.UV_COPY, stream=sm)
                 torch.cuda.synchronize()
