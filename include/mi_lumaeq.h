@@ -215,17 +215,26 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
                                         void* d_dst, size_t dst_step, size_t dst_frame_stride,
                                         int width, int height, int n_frames, int code, void* stream);
 
-/* ---- stream completion + device-side status -------------------------------------------------------
+/* ---- stream completion, fail-soft behaviour of the fused kernel, statistics -------------------------------
  * The batched equalizeHist forms normally run as ONE fused launch whose workgroups hand data to each
- * other through bounded waits.  mi_ctx_synchronize() waits for `stream` and returns MI_ERR_HIP if such
- * a wait ever expired (the output of that call is then invalid).  The host-pointer forms check this
- * themselves.  A batched call issued inside a stream capture switches the context to a replay-safe mode, so
- * the captured hipGraph can be replayed (size the scratch with one eager call first: allocations are not
- * capturable).
+ * other through bounded waits (they need a frame's slices co-resident on the GPU).  If such a wait
+ * expires -- another tenant holds the compute units, a queue was preempted for longer than the bound --
+ * the launch drains, and the small finish kernel that follows EVERY fused launch on the same stream
+ * redoes exactly the parts that were not written, with no inter-workgroup dependency.  The caller's
+ * stream therefore always carries correct output, whoever synchronises it and however; the event is
+ * only counted: mi_ctx_get_stat("fused_fallbacks" | "fused_frames_repaired" | "fused_hard_errors" |
+ * "fused_last_status").  (The reference's accelerator path ignores device errors altogether:
+ * OpenCLequalHist.cpp:367 catches a type nobody throws.)
+ * mi_ctx_synchronize() waits for `stream`; it returns MI_ERR_HIP only if a frame's state contradicted the
+ * protocol and the repair refused to guess ("fused_hard_errors"; the host-pointer forms check the same).
+ * hipGraph: a batched call issued inside a stream capture is recorded as it is -- all per-launch state of
+ * the fused path lives in device memory -- and the graph can be replayed.  Size the scratch with one
+ * eager call of the same shape first: scratch growth inside a capture returns MI_ERR_UNSUPPORTED, and
+ * once a context has seen a capture it never frees scratch a graph node may reference.
  * Options (mi_ctx_set_option): "fused" (1/0: single-read fused kernel vs the three-kernel path),
  * "fused_wgs_per_cu" (persistent workgroups per CU, default 4), "fused_vpt" (8/16/20/24 16-byte vectors a
  * thread keeps in registers, default 20; 0 restores the default), "fused_acquire" (1/0), "fused_timeout_ms" (bound of every
- * inter-workgroup wait, default 2000), "fused_fault_inject" (test hook), "clahe_float_tables" (1/0),
+ * inter-workgroup wait, default 50), "fused_fault_inject" (test hook, 0..3), "clahe_float_tables" (1/0),
  * "bgr_fused" (1/0, default 1: mi_bgr_luma_op_u8c3 runs as two passes over the interleaved image instead of through
  * Y/U/V planes; CLAHE only for unpadded shapes with tile_w % 16 == 0),
  * "clahe_fp_contract" (1/0, default 0: CLAHE interpolation arithmetic.  0 = every multiply and add rounded separately, what an
@@ -238,13 +247,14 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * them through the context's pinned buffers, as strided views always are). */
 mi_status mi_ctx_synchronize(mi_ctx* ctx, void* stream);
 mi_status mi_ctx_set_option(mi_ctx* ctx, const char* name, int value);
+mi_status mi_ctx_get_stat(mi_ctx* ctx, const char* name, uint64_t* out);
 
 /* ---- timing of the library's own kernels -------------------------------------------------------
  * With profiling on, every kernel the library launches is bracketed by hipEvents on the stream
  * it is launched on (the reference brackets its kernel with CL profiling events the same way,
  * 1frameMeasure.cpp:77-85).  mi_ctx_profile_read() synchronises those events and accumulates. */
 enum { MI_K_HIST = 0, MI_K_EQ_LUT = 1, MI_K_LUT_APPLY = 2, MI_K_TILE_HIST = 3, MI_K_TILE_LUT = 4,
-       MI_K_CLAHE_INTERP = 5, MI_K_FUSED = 6, MI_K_COLOR = 7, MI_K_COUNT = 8 };
+       MI_K_CLAHE_INTERP = 5, MI_K_FUSED = 6, MI_K_COLOR = 7, MI_K_FUSED_FINISH = 8, MI_K_COUNT = 9 };
 typedef struct mi_profile {
     double   total_ms[MI_K_COUNT];   /* summed kernel durations since the last reset */
     uint64_t launches[MI_K_COUNT];

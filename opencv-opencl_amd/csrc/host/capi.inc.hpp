@@ -24,7 +24,8 @@ const char* mi_status_str(mi_status s)
 const char* mi_kernel_name(int k)
 {
     static const char* names[MI_K_COUNT] = {"hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
-                                            "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel"};
+                                            "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel",
+                                            "fused_finish_kernel"};
     return (k >= 0 && k < MI_K_COUNT) ? names[k] : "?";
 }
 
@@ -77,6 +78,8 @@ void mi_ctx_destroy(mi_ctx* c)
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_luts) (void)hipFree(c->d_luts);
     if (c->d_fused) (void)hipFree(c->d_fused);
+    if (c->d_fused_flags) (void)hipFree(c->d_fused_flags);
+    for (void* q : c->retired) (void)hipFree(q);
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_c16) (void)hipFree(c->d_c16);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -164,7 +167,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "fused_vpt") && value == 0) { c->fused_vpt = kVPT; return MI_OK; }
     if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 0 (default), 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
     if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
-    if (!strcmp(name, "fused_fault_inject")) { c->fused_fault_inject = value != 0; return MI_OK; }
+    if (!strcmp(name, "fused_fault_inject")) { if (value < 0 || value > 3) return fail(c, MI_ERR_BAD_ARG, "fused_fault_inject must be 0..3"); c->fused_fault_inject = value; return MI_OK; }
     if (!strcmp(name, "fused_timeout_ms")) { c->fused_timeout_ms = std::max(1, value); return MI_OK; }
     if (!strcmp(name, "bgr_fused")) { c->bgr_fused = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
@@ -174,22 +177,44 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     return fail(c, MI_ERR_BAD_ARG, "unknown option");
 }
 
-// Waits for `stream` and reports a device-side failure of the fused kernel's bounded waits.
+// Waits for `stream`.  A bounded-wait expiry of the fused kernel is NOT an error: the finish kernel that follows every fused
+// launch has already redone the affected tickets on the device (see kernels/equalize_fused.hip.h) and the event is only counted
+// (mi_ctx_get_stat).  MI_ERR_HIP is returned for the one case the repair refuses: a frame whose stamps contradict the protocol.
 mi_status mi_ctx_synchronize(mi_ctx* c, void* stream)
 {
     ENTER(c);
     hipStream_t s = pick_stream(c, stream);
     HIPCHK(c, hipStreamSynchronize(s));
     if (!c->d_fused) return MI_OK;
-    if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
-    HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (*c->h_status != 0) {
-        c->fused_dirty = true;                                   // hand-off block is in an unknown state: zero it before the next launch
+    uint64_t st4[4];
+    mi_status st = fused_read_stats(c, s, st4);
+    if (st) return st;
+    if (st4[2] > c->fused_seen_hard) {
+        c->fused_seen_hard = st4[2];
         c->last_hip = 0;
-        return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+        return fail(c, MI_ERR_HIP, "fused equalize kernel: a frame could not be repaired after an expired inter-workgroup wait; output invalid");
     }
     return MI_OK;
+}
+
+// Statistics: "fused_fallbacks" (fused launches in which a bounded wait expired and the finish kernel redid the missing tickets),
+// "fused_frames_repaired", "fused_hard_errors" (frames the repair refused), "fused_last_status" (1 = wait on a frame's LUT
+// flag / histogram total, 2 = LUT checksum).  Reads device words with a blocking copy on the context's stream: call it after the
+// stream the work ran on has been synchronised.
+mi_status mi_ctx_get_stat(mi_ctx* c, const char* name, uint64_t* out)
+{
+    ENTER(c);
+    if (!name || !out) return fail(c, MI_ERR_BAD_ARG, "null stat name / out");
+    static const char* names[4] = {"fused_fallbacks", "fused_frames_repaired", "fused_hard_errors", "fused_last_status"};
+    for (int k = 0; k < 4; ++k)
+        if (!strcmp(name, names[k])) {
+            uint64_t st4[4];
+            mi_status st = fused_read_stats(c, c->stream, st4);
+            if (st) return st;
+            *out = st4[k];
+            return MI_OK;
+        }
+    return fail(c, MI_ERR_BAD_ARG, "unknown stat");
 }
 
 // ---- device-resident batched forms ------------------------------------------------------------------
@@ -364,11 +389,20 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     PlaneArgs a{c->d_stage_in, (size_t)width, ybytes, c->d_stage_out, (size_t)width, ybytes, width, height, 1};
     st = is_clahe ? clahe_dev(c, s, a, clip_limit, tiles_x, tiles_y, nullptr) : equalize_dev(c, s, a, nullptr);
     if (st) return st;
+    // the "unrecoverable frame" counter of the fused path rides along behind the kernels (4 bytes, pinned): the repair itself
+    // has already happened on the device by the time the copies below run
     const bool check_status = !is_clahe && c->d_fused;
     if (check_status) {
         if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
-        HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + 32, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_status + 8, c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
+    auto hard_error = [&]() {
+        if (!check_status) return false;
+        const uint64_t hard = c->fused_stat_base[2] + c->h_status[8];
+        if (hard <= c->fused_seen_hard) return false;
+        c->fused_seen_hard = hard;
+        return true;
+    };
     auto host_uv = [&]() {                                      // runs while the GPU / DMA engines are busy with Y
         if (!uvbytes) return;
         if (nv12_mode == MI_UV_FILL128) memset(dst + ybytes, 128, uvbytes);
@@ -381,10 +415,7 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         HIPCHK(c, hipMemcpyAsync(dst, c->d_stage_out, ybytes, hipMemcpyDeviceToHost, s));
         if (out_pinned) host_uv();
         HIPCHK(c, hipStreamSynchronize(s));
-        if (check_status && *c->h_status != 0) {
-            c->fused_dirty = true;
-            return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
-        }
+        if (hard_error()) return fail(c, MI_ERR_HIP, "fused equalize kernel: a frame could not be repaired after an expired inter-workgroup wait; output invalid");
         return MI_OK;
     }
     // device -> pinned in chunks, each followed by an event; then drain chunk by chunk into the caller's rows
@@ -407,10 +438,9 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     host_uv();
     for (size_t i = 0; i < chunks.size(); ++i) {
         HIPCHK(c, hipEventSynchronize(c->chunk_events[i]));
-        if (i == 0 && check_status && *c->h_status != 0) {
-            c->fused_dirty = true;
+        if (i == 0 && hard_error()) {
             (void)hipStreamSynchronize(s);
-            return fail(c, MI_ERR_HIP, "fused equalize kernel: a bounded inter-workgroup wait expired; output invalid");
+            return fail(c, MI_ERR_HIP, "fused equalize kernel: a frame could not be repaired after an expired inter-workgroup wait; output invalid");
         }
         copy_rows(dst + (size_t)chunks[i].y0 * dst_step, dst_step, c->h_pin_out + chunks[i].off, (size_t)width, width, chunks[i].nr);
     }

@@ -42,21 +42,22 @@ struct mi_ctx {
     // device scratch, grown lazily ("allocate once per size", OpenCLequalHist.cpp:175-186)
     uint32_t* d_partial = nullptr; size_t partial_bytes = 0;     // histogram partials
     uint8_t*  d_luts = nullptr;    size_t luts_bytes = 0;        // per-frame / per-tile LUTs
-    uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (self-cleaning)
+    uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (self-cleaning; all per-launch
+                                                                 // state lives in it, so captured launches replay unchanged)
     size_t fused_cap = 0;                                        // frames the block is laid out for
-    unsigned long long fused_work_base = 0;                      // value of the device ticket counter at the next launch
-    uint32_t fused_epoch = 0;
-    bool fused_dirty = true;                                     // block must be zeroed before the next launch
-    bool fused_capture_safe = false;                             // set once a call was seen inside a stream capture (hipGraph):
-                                                                 // from then on every launch zeroes the block itself and uses
-                                                                 // constant epoch / ticket base, so a captured graph can be replayed
-    uint32_t* h_status = nullptr;                                // pinned mirror of the device status word
+    uint32_t* d_fused_flags = nullptr; size_t fused_flags_bytes = 0;   // ticket stamps of the fused kernel
+    uint64_t fused_stat_base[4] = {};                            // statistics of hand-off blocks this context has since replaced
+    uint64_t fused_seen_hard = 0;                                // unrecoverable frames already reported to the caller
+    uint32_t* h_status = nullptr;                                // pinned mirror of the device statistics words
+    bool capturing = false;                                      // the stream of the call in progress is being captured (hipGraph)
+    bool graph_captured = false;                                 // a capture has been seen: scratch referenced by graph nodes is never freed
+    std::vector<void*> retired;                                  // ... it is parked here until the context is destroyed
     int fused_mode = 1;                                          // MI_LUMAEQ_FUSED=0 forces the 3-kernel path
     int fused_wgs_per_cu = 4;                                    // MI_LUMAEQ_FUSED_WGS_PER_CU
     int fused_vpt = kVPT;                                        // MI_LUMAEQ_FUSED_VPT (8, 16, 20, 24)
     int fused_acquire = 1;                                       // MI_LUMAEQ_FUSED_ACQUIRE
-    int fused_fault_inject = 0;                                  // test hook (option "fused_fault_inject")
-    int fused_timeout_ms = 2000;                                 // option "fused_timeout_ms"
+    int fused_fault_inject = 0;                                  // test hook (option "fused_fault_inject": 0 off, 1..3 see kernels/equalize_fused.hip.h)
+    int fused_timeout_ms = 50;                                   // option "fused_timeout_ms": bound of every inter-workgroup wait
     int bgr_fused = 1;                                           // option "bgr_fused": 9 B/px two-pass BGR luma equalization / CLAHE
     int host_direct = 1;                                         // option "host_direct": contiguous host planes go to the copy engine unstaged
     int clahe_fp_contract = 0;                                   // option "clahe_fp_contract": CLAHE interpolation with GCC's FMA contraction (aarch64 OpenCV builds)
@@ -103,7 +104,13 @@ template <class T>
 mi_status grow_dev(mi_ctx* c, T** p, size_t* have, size_t need)
 {
     if (need <= *have) return MI_OK;
-    if (*p) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(*p)); *p = nullptr; *have = 0; }   // rare: scratch may be in use on a caller stream
+    // allocations are not capturable, and kernel nodes of an earlier capture keep pointing at the scratch they were recorded with
+    if (c->capturing) return fail(c, MI_ERR_UNSUPPORTED, "device scratch must grow inside a stream capture: size it with one eager call of this shape first");
+    if (*p) {
+        if (c->graph_captured) c->retired.push_back(*p);         // a captured graph may still replay into it
+        else { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(*p)); }   // rare: scratch may be in use on a caller stream
+        *p = nullptr; *have = 0;
+    }
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, need);
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(c, MI_ERR_OOM, "device allocation failed"); }
@@ -115,6 +122,7 @@ mi_status grow_dev(mi_ctx* c, T** p, size_t* have, size_t need)
 mi_status grow_pinned(mi_ctx* c, uint8_t** p, size_t* have, size_t need)
 {
     if (need <= *have) return MI_OK;
+    if (c->capturing) return fail(c, MI_ERR_UNSUPPORTED, "pinned staging must grow inside a stream capture");
     if (*p) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipHostFree(*p)); *p = nullptr; *have = 0; }
     void* q = nullptr;
     hipError_t e = hipHostMalloc(&q, need, hipHostMallocDefault);

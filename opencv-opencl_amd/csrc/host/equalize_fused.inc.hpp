@@ -2,9 +2,10 @@
 // Included by ../mi_lumaeq.hip (one translation unit; not a stand-alone header).
 
 // ---- fused single-read path -----------------------------------------------------------------------------
-// Layout of the hand-off block (uint32 words; zeroed by zero_words_kernel when first used, re-laid-out, after a reported failure or
-// in graph-replayable mode -- otherwise every launch leaves it clean for the next one):
-//   [0..31] work counter (u64) | [32..63] status | cnt[nf][32] | ready[nf][32] | ghist[nf][256] | lutpub[nf][128]
+// Layout of the hand-off block (uint32 words; zeroed once when (re)allocated -- every launch pair leaves it ready for the next):
+//   [0..127] control words (kFused*: ticket counter, status, launch sequence number, finish arrivals, sticky statistics)
+//   cnt[cap][32] | ready[cap][32] | ghist[cap][256] | lutpub[cap][128]
+// plus a separate array of ticket stamps (d_fused_flags), one word per ticket of the largest launch seen.
 // Returns the slice size (16-byte vectors per thread) the fused kernel should run with, or 0 when the launch must take
 // the three-kernel path.  The co-residency allowance (see g_fused_ctx_live) is the conservative 1/8 of the chip when
 // other fused contexts exist on the device and half of the chip while this one is alone (an 8K frame is 405 tickets).
@@ -28,6 +29,19 @@ int fused_pick_vpt(const mi_ctx* c, const PlaneArgs& a, const UVJob* uv)
 
 bool fused_applicable(const mi_ctx* c, const PlaneArgs& a, const UVJob* uv) { return fused_pick_vpt(c, a, uv) != 0; }
 
+// Sticky statistics of the hand-off block (device words) + what earlier blocks of this context had accumulated.
+mi_status fused_read_stats(mi_ctx* c, hipStream_t s, uint64_t out[4])
+{
+    for (int k = 0; k < 4; ++k) out[k] = c->fused_stat_base[k];
+    if (!c->d_fused) return MI_OK;
+    if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
+    HIPCHK(c, hipMemcpyAsync(c->h_status, c->d_fused + kFusedStats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int k = 0; k < 3; ++k) out[k] += c->h_status[k];
+    if (c->h_status[3]) out[3] = c->h_status[3];
+    return MI_OK;
+}
+
 mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
     const long long ysz = (long long)a.width * a.height;
@@ -37,6 +51,7 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     j.src = a.src; j.dst = a.dst; j.src_frame = (long long)a.src_frame; j.dst_frame = (long long)a.dst_frame;
     j.nvec = ysz / 16; j.total = (int)ysz; j.n_frames = a.n_frames;
     const long long slice = (long long)kThreads * vpt;
+    j.slice_vecs = (int)slice;
     j.T = (int)((j.nvec + slice - 1) / slice);
     j.acquire = c->fused_acquire;
     j.fault_inject = c->fused_fault_inject;
@@ -45,45 +60,55 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     // UV as stand-alone 64 KiB tickets behind each frame's Y tickets: pure streaming work that fills the gaps while
     // other workgroups sit in their hand-off (measured 5 % faster than giving every Y ticket a share of the UV plane)
     if (uv && uv->bytes > 0) { j.uv = *uv; j.U = (int)((uv->bytes + 65535) / 65536); }
+    const long long tickets = (long long)(j.T + j.U) * a.n_frames;
     // capacity-based layout so the regions never move between calls with different frame counts
+    if (c->capturing && ((size_t)a.n_frames > c->fused_cap || (size_t)tickets * sizeof(uint32_t) > c->fused_flags_bytes))
+        return fail(c, MI_ERR_UNSUPPORTED, "device scratch must grow inside a stream capture: size it with one eager call of this shape first");
     if ((size_t)a.n_frames > c->fused_cap) {
         size_t cap = std::max<size_t>(64, c->fused_cap);
         while (cap < (size_t)a.n_frames) cap *= 2;
-        const size_t words = 64 + cap * (kFlagStride + kFlagStride + 256 + kLutPubWords);
+        const size_t words = kFusedCtlWords + cap * (kFlagStride + kFlagStride + 256 + kLutPubWords);
+        if (c->d_fused) {                                        // keep what the old block had counted
+            uint64_t st4[4];
+            mi_status st = fused_read_stats(c, s, st4);
+            if (st) return st;
+            for (int k = 0; k < 4; ++k) c->fused_stat_base[k] = st4[k];
+        }
         mi_status st = grow_dev(c, &c->d_fused, &c->fused_bytes, words * sizeof(uint32_t));
         if (st) return st;
         c->fused_cap = cap;
-        c->fused_dirty = true;
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (words + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           c->d_fused, words);
+        HIPCHK(c, hipGetLastError());
+        if (c->d_fused_flags) {                                  // the new block restarts its epochs: old stamps must not match them
+            const size_t nwords = c->fused_flags_bytes / sizeof(uint32_t);
+            hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (nwords + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                               c->d_fused_flags, nwords);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) c->fused_capture_safe = true;
-        else (void)hipGetLastError();
-    }
-    if (c->fused_dirty || c->fused_capture_safe) {           // first use, re-layout, reported failure, or graph-replayable mode
-        const size_t nwords = c->fused_bytes / sizeof(uint32_t);
-        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (nwords + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                           c->d_fused, nwords);
-        HIPCHK(c, hipGetLastError());
-        c->fused_work_base = 0;
-        c->fused_dirty = false;
-        if (c->fused_capture_safe) c->fused_epoch = 0;           // -> epoch 1 below, the same for every (re)play
+        // ticket stamps: stale words are harmless (they carry other launches' epochs), so growth needs no zeroing --
+        // except once, for epoch-0 safety of a fresh allocation (hipMalloc memory is not guaranteed to be zero)
+        const size_t need = (size_t)tickets * sizeof(uint32_t);
+        if (need > c->fused_flags_bytes) {
+            mi_status st = grow_dev(c, &c->d_fused_flags, &c->fused_flags_bytes, std::max(need, (size_t)1 << 16));
+            if (st) return st;
+            const size_t nwords = c->fused_flags_bytes / sizeof(uint32_t);
+            hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (nwords + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                               c->d_fused_flags, nwords);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     const size_t cap = c->fused_cap;
     uint32_t* w = c->d_fused;
-    j.work = reinterpret_cast<unsigned long long*>(w);
-    j.status = w + 32;
-    j.cnt = w + 64;
+    j.ctl = w;
+    j.cnt = w + kFusedCtlWords;
     j.ready = j.cnt + cap * kFlagStride;
     j.ghist = j.ready + cap * kFlagStride;
     j.lutpub = j.ghist + cap * 256;
-    if (++c->fused_epoch == 0) c->fused_epoch = 1;
-    j.epoch = c->fused_epoch;
-    j.work_base = c->fused_work_base;
-    const long long tickets = (long long)(j.T + j.U) * a.n_frames;
+    j.sflag = c->d_fused_flags;
     const long long grid = std::min<long long>(tickets, (long long)c->cu_count * c->fused_wgs_per_cu);
-    c->fused_work_base += (unsigned long long)tickets + (unsigned long long)grid;   // every workgroup draws one ticket past the end
-    c->fused_dirty = true;                                   // cleared below once the launch has been enqueued
     switch (vpt) {
         case 8:  LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<8>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
         case 20: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<20>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
@@ -91,7 +116,9 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
         case 16: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<16>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
         default: return fail(c, MI_ERR_BAD_ARG, "bad fused_vpt");
     }
-    c->fused_dirty = false;
+    // always: housekeeping in the normal case, stamp-driven repair when a bounded wait expired (kernels/equalize_fused.hip.h)
+    const int fin_grid = (int)std::min<long long>(a.n_frames, (long long)c->cu_count * 4);
+    LAUNCH(c, s, MI_K_FUSED_FINISH, fused_finish_kernel, dim3((unsigned)fin_grid), dim3(kThreads), 0, j);
     return MI_OK;
 }
 

@@ -14,7 +14,7 @@ UVJob nv12_uv(const uint8_t* in, uint8_t* out, int width, int height, mi_uv_mode
 
 struct Guard {
     mi_ctx* c; std::unique_lock<std::mutex> lk; hipError_t err;
-    explicit Guard(mi_ctx* c_) : c(c_), lk(c_->mu) { err = hipSetDevice(c->device); }
+    explicit Guard(mi_ctx* c_) : c(c_), lk(c_->mu) { err = hipSetDevice(c->device); c->capturing = false; }
 };
 
 #define ENTER(ctx)                                                   \
@@ -22,7 +22,20 @@ struct Guard {
     Guard guard__(ctx);                                              \
     if (guard__.err != hipSuccess) return fail_hip((ctx), guard__.err, "hipSetDevice")
 
-hipStream_t pick_stream(mi_ctx* c, void* stream) { return stream == MI_STREAM_CTX ? c->stream : (hipStream_t)stream; }
+// Also notes whether the chosen stream is being captured into a hipGraph: scratch growth is refused then, and from the
+// first capture on no scratch a graph node may reference is ever freed (grow_dev).
+hipStream_t pick_stream(mi_ctx* c, void* stream)
+{
+    hipStream_t s = stream == MI_STREAM_CTX ? c->stream : (hipStream_t)stream;
+    c->capturing = false;
+    if (s != c->stream) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess) c->capturing = cap != hipStreamCaptureStatusNone;
+        else (void)hipGetLastError();
+    }
+    if (c->capturing) c->graph_captured = true;
+    return s;
+}
 
 // ---- host-pointer plumbing ---------------------------------------------------------------------------
 void copy_rows(uint8_t* dst, size_t dst_step, const uint8_t* src, size_t src_step, int width, int height)

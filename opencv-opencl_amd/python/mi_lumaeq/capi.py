@@ -16,7 +16,8 @@ _LIB_PATH = _ROOT / "lib" / "libmi_lumaeq.so"
 UV_FILL128, UV_COPY = 0, 1
 STREAM_CTX = C.c_void_p(-1).value      # MI_STREAM_CTX: the context's private stream; 0/None = HIP null stream
 KERNEL_NAMES = ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
-                "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel"]
+                "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel",
+                "fused_finish_kernel"]
 COLOR_BGR2YUV, COLOR_YUV2BGR = 82, 84
 COLOR_YUV2BGR_NV12, COLOR_BGR2YUV_I420 = 93, 128
 OP_EQUALIZE, OP_CLAHE = 0, 1
@@ -31,7 +32,7 @@ DECLARED_SYMBOLS = [
     "mi_hist_u8_batch_dev", "mi_equalize_lut_batch_dev", "mi_lut_apply_u8_batch_dev",
     "mi_clahe_tile_luts_batch_dev",
     "mi_ctx_set_profiling", "mi_ctx_profile_read", "mi_kernel_name",
-    "mi_ctx_synchronize", "mi_ctx_set_option",
+    "mi_ctx_synchronize", "mi_ctx_set_option", "mi_ctx_get_stat",
     "mi_host_register", "mi_host_unregister", "mi_clahe_u16", "mi_clahe_u16_batch_dev",
     "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
     "mi_nv12_bgr_equalize", "mi_nv12_bgr_equalize_batch_dev", "mi_cvt_color_420_u8", "mi_cvt_color_420_u8_batch_dev",
@@ -112,6 +113,7 @@ def lib() -> C.CDLL:
     L.mi_host_unregister.argtypes = [vp]
     L.mi_ctx_synchronize.argtypes = [vp, vp]
     L.mi_ctx_set_option.argtypes = [vp, C.c_char_p, i]
+    L.mi_ctx_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
     L.mi_ctx_set_profiling.argtypes = [vp, i]
     L.mi_ctx_profile_read.argtypes = [vp, C.POINTER(_Profile), i]
     _lib = L
@@ -421,8 +423,14 @@ class Context:
                   "mi_nv12_bgr_equalize_batch_dev")
 
     def synchronize(self, stream=0):
-        """Wait for `stream`; raises if the fused kernel reported an expired inter-workgroup wait."""
+        """Wait for `stream`; raises only if the fused path met a frame it refused to repair (see get_stat)."""
         self._chk(lib().mi_ctx_synchronize(self._h, stream), "mi_ctx_synchronize")
+
+    def get_stat(self, name: str) -> int:
+        """Sticky counters of the fused path's fail-soft machinery (mi_ctx_get_stat); synchronise the work's stream first."""
+        v = C.c_uint64(0)
+        self._chk(lib().mi_ctx_get_stat(self._h, name.encode(), C.byref(v)), "mi_ctx_get_stat")
+        return int(v.value)
 
     def set_option(self, name: str, value: int):
         self._chk(lib().mi_ctx_set_option(self._h, name.encode(), int(value)), "mi_ctx_set_option")

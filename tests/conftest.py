@@ -8,6 +8,17 @@ faulthandler.enable()        # a native crash (HIP runtime, our library) prints 
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
+
+# In front of faulthandler: the native call chain of the thread that raised a fatal signal (tests/cxx/abrt_trace.c).  Round 1
+# saw three silent SIGABRTs raised by a runtime thread in ~30 GPU sessions; with this loaded for the whole session a recurrence
+# names the library that called abort() instead of leaving only "Fatal Python error: Aborted".
+_tracer = ROOT / "tests" / "cxx" / "libabrt_trace.so"
+if _tracer.exists():
+    try:
+        import ctypes
+        ctypes.CDLL(str(_tracer))
+    except OSError:
+        pass
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "opencv-opencl_amd" / "python"))
 

@@ -30,7 +30,7 @@ def test_version_and_status_strings(built_lib):
     assert "gfx950" in mi_lumaeq.version()
     assert mi_lumaeq.status_str(0) == "MI_OK"
     assert mi_lumaeq.status_str(5) == "MI_ERR_NO_DEVICE"
-    assert [built_lib.mi_kernel_name(k).decode() for k in range(8)] == mi_lumaeq.KERNEL_NAMES
+    assert [built_lib.mi_kernel_name(k).decode() for k in range(len(mi_lumaeq.KERNEL_NAMES))] == mi_lumaeq.KERNEL_NAMES
 
 
 def test_no_cpu_fallback(built_lib):
