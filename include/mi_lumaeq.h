@@ -46,7 +46,8 @@ typedef enum mi_status {
     MI_ERR_UNSUPPORTED = 2,      /* not CV_8UC1-shaped work (the adapter maps this to cv::Exception) */
     MI_ERR_HIP = 3,              /* a HIP call failed; see mi_ctx_last_hip_error()                   */
     MI_ERR_OOM = 4,              /* host or device allocation failed                                 */
-    MI_ERR_NO_DEVICE = 5         /* no usable HIP device / device index out of range                 */
+    MI_ERR_NO_DEVICE = 5,        /* no usable HIP device / device index out of range                 */
+    MI_ERR_BUSY = 6              /* mi_pipe_submit: `depth` frames are in flight, call mi_pipe_wait   */
 } mi_status;
 
 /* UV handling of whole-NV12-frame entry points:
@@ -166,6 +167,45 @@ mi_status mi_clahe_u16_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step
 mi_status mi_host_register(void* ptr, size_t bytes);
 mi_status mi_host_unregister(void* ptr);
 
+/* ---- asynchronous in-order frame pipeline: the per-GPU worker of the frame-sharded stream ---------------------
+ * The reference's worker maps a frame, runs the op, rebuilds the NV12 frame and pushes it downstream, one frame at
+ * a time (OpenCVequalHist.cpp:102-196); its accelerator variant blocks on each of write, write, task, read
+ * (OpenCLequalHist.cpp:356-365).  A pipe is that worker's device side with up to `depth` frames in flight: the upload
+ * of frame k+2, the kernels of frame k+1 and the download of frame k run concurrently (three HIP streams, both DMA
+ * directions busy), so ONE host thread per GPU keeps the link full.  Frames are tightly packed NV12 in host memory
+ * (W*H + W*H/2 bytes), caller-owned from mi_pipe_submit until the mi_pipe_wait that returns them; completion is in
+ * submission order.  Register recycled frame buffers once with mi_host_register (a GstBufferPool's memory): their
+ * copies are then fully asynchronous.  Unregistered (pageable) memory is accepted -- its upload blocks in submit and
+ * its download in wait, as the runtime stages them.
+ *   op         MI_OP_EQUALIZE (OpenCVequalHist.cpp:145), MI_OP_CLAHE (clahevideo.cpp:195), or MI_OP_CHANNELS
+ *              (NV12 -> BGR -> equalizeHist on B, G, R -> NV12: mi_nv12_bgr_equalize; ignores uv_mode)
+ *   uv_policy  MI_PIPE_UV_HOST (= AUTO for the Y-only ops): only the Y plane crosses PCIe; the UV half is filled with
+ *              128 / copied by the calling thread inside mi_pipe_wait while the engines work (the reference's own
+ *              memset / memcpy, OpenCVequalHist.cpp:160-162, ColoropenCVCwqualHist.cpp:165);
+ *              MI_PIPE_UV_DEVICE: whole frames cross the bus and the kernels write the UV half (no host CPU work)
+ *   depth      frames in flight, 2..16 (0 = default 4)
+ * mi_pipe_submit returns MI_ERR_BUSY when `depth` frames are pending.  mi_pipe_wait blocks for the OLDEST pending
+ * frame and returns its tag and output pointer.  A pipe uses its context's scratch and lock: one pipe per context,
+ * destroy it before the context; the context's other entry points may be used while no frame is pending. */
+typedef struct mi_pipe mi_pipe;
+enum { MI_OP_EQUALIZE = 0, MI_OP_CLAHE = 1, MI_OP_CHANNELS = 2 };
+enum { MI_PIPE_UV_AUTO = 0, MI_PIPE_UV_HOST = 1, MI_PIPE_UV_DEVICE = 2 };
+typedef struct mi_pipe_config {
+    int width, height;
+    int op;                      /* MI_OP_EQUALIZE | MI_OP_CLAHE | MI_OP_CHANNELS */
+    mi_uv_mode uv_mode;
+    double clip_limit;           /* MI_OP_CLAHE */
+    int tiles_x, tiles_y;        /* MI_OP_CLAHE */
+    int depth;
+    int uv_policy;
+} mi_pipe_config;
+mi_status mi_pipe_create(mi_ctx* ctx, const mi_pipe_config* cfg, mi_pipe** out);
+void      mi_pipe_destroy(mi_pipe* pipe);
+mi_status mi_pipe_submit(mi_pipe* pipe, const uint8_t* in, uint8_t* out, uint64_t tag);
+mi_status mi_pipe_wait(mi_pipe* pipe, uint64_t* tag, uint8_t** out_frame);
+int       mi_pipe_pending(const mi_pipe* pipe);
+int       mi_pipe_depth(const mi_pipe* pipe);
+
 /* ---- colour-domain neighbours of the path (parity unpinned, see oracle/color_oracle.c) ------
  * CV_8UC3 interleaved images, row pitch >= 3*width.
  * mi_cvt_color_u8c3: cv::cvtColor(src, dst, code) for code = MI_COLOR_BGR2YUV (cv::COLOR_BGR2YUV = 82,
@@ -175,7 +215,6 @@ mi_status mi_host_unregister(void* ptr);
  *   (op = MI_OP_EQUALIZE, singlecolor.cpp:39-66) or CLAHE (op = MI_OP_CLAHE, clahe1frame.cpp:83-102) on the Y
  *   plane -> merge -> cvtColor(YUV2BGR); split/merge are fused into the conversion kernels. */
 enum { MI_COLOR_BGR2YUV = 82, MI_COLOR_YUV2BGR = 84 };
-enum { MI_OP_EQUALIZE = 0, MI_OP_CLAHE = 1 };
 mi_status mi_cvt_color_u8c3(mi_ctx* ctx, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step,
                             int width, int height, int code);
 mi_status mi_cvt_color_u8c3_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,

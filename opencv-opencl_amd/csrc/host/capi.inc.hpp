@@ -17,6 +17,7 @@ const char* mi_status_str(mi_status s)
         case MI_ERR_HIP: return "MI_ERR_HIP";
         case MI_ERR_OOM: return "MI_ERR_OOM";
         case MI_ERR_NO_DEVICE: return "MI_ERR_NO_DEVICE";
+        case MI_ERR_BUSY: return "MI_ERR_BUSY";
     }
     return "MI_ERR_?";
 }

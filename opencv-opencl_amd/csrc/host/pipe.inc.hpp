@@ -1,0 +1,256 @@
+// pipe.inc.hpp -- mi_pipe: asynchronous, in-order NV12 frame pipeline on ONE context (host frame in -> host frame out)
+// Included by ../mi_lumaeq.hip (one translation unit; not a stand-alone header).
+//
+// What it replaces: the reference's worker does map -> op -> rebuild -> push synchronously per frame
+// (OpenCVequalHist.cpp:102-196), and its accelerator variant blocks on every transfer (OpenCLequalHist.cpp:356-365:
+// write, write, task, finish, read, finish).  On a discrete GPU that serialisation leaves the link idle two thirds of the
+// time, so one worker per GPU cannot keep a GPU fed.  A pipe keeps `depth` frames in flight on three HIP streams:
+//
+//     s_h2d :  H2D(k+2)            | copy engine, host -> device
+//     s_k   :  op(k+1) [+ finish]  | compute; waits for H2D(k+1) by event
+//     s_d2h :  D2H(k)              | copy engine, device -> host; waits for op(k) by event
+//
+// so PCIe runs in both directions at once while the kernels (tens of microseconds per 4K frame) hide behind it.
+// Frames complete in submission order (mi_pipe_wait).  Host memory that was registered with mi_host_register (a recycled
+// frame pool) is DMA'd asynchronously; unregistered (pageable) memory still works -- its copies block the caller, the
+// H2D at submit and the D2H at wait, as the runtime stages them -- with correspondingly less overlap.
+// All pipes of a process on one device share the SAME three streams: a second worker on a GPU then interleaves its frames
+// into the same queues instead of adding queues (8 streams on one device were measured 30 % SLOWER than 3: HIP multiplexes
+// streams onto 4 hardware queues, and unrelated copies end up ordered behind each other); as a side effect the fused
+// kernels of different contexts never overlap on a device when they come from pipes.
+// UV handling: "host" (default for Y-only ops) moves only the Y plane over the bus and fills / copies the UV half on the
+// host inside mi_pipe_wait while the engines are busy; "device" ships whole NV12 frames and lets the kernels do it.
+
+struct PipeSlot {
+    uint8_t* d_in = nullptr; uint8_t* d_out = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_k = nullptr, ev_done = nullptr;
+    const uint8_t* in = nullptr; uint8_t* out = nullptr;
+    uint64_t tag = 0;
+    bool out_async = false;                                       // D2H was queued at submit (registered memory)
+    mi_status st = MI_OK;
+};
+
+// process-wide stream triple per device, created by the first pipe, destroyed with the last
+struct PipeStreams { hipStream_t h2d = nullptr, k = nullptr, d2h = nullptr; int users = 0; };
+static std::mutex g_pipe_streams_mu;
+static PipeStreams g_pipe_streams[kMaxDevices];
+
+struct mi_pipe {
+    mi_ctx* c = nullptr;
+    mi_pipe_config cfg{};
+    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr;
+    std::vector<PipeSlot> slots;
+    size_t head = 0, count = 0;
+    size_t ybytes = 0, uvbytes = 0, xfer_in = 0, xfer_out = 0;
+    bool uv_dev = false;
+    uint32_t* h_hard = nullptr;                                   // pinned: [slot] = device "unrecoverable frames" counter after that frame
+    uint64_t submitted = 0, completed = 0;
+};
+
+namespace {
+
+mi_status pipe_run_op(mi_pipe* p, PipeSlot& sl)
+{
+    mi_ctx* c = p->c;
+    const mi_pipe_config& g = p->cfg;
+    const size_t fstride = p->ybytes + p->uvbytes;
+    if (g.op == MI_OP_CHANNELS) return nv12_bgr_equalize_dev(c, p->s_k, sl.d_in, fstride, sl.d_out, fstride, g.width, g.height, 1);
+    PlaneArgs a{sl.d_in, (size_t)g.width, fstride, sl.d_out, (size_t)g.width, fstride, g.width, g.height, 1};
+    UVJob uv{};
+    const UVJob* puv = nullptr;
+    if (p->uv_dev) { uv = nv12_uv(sl.d_in, sl.d_out, g.width, g.height, g.uv_mode); puv = &uv; }
+    return g.op == MI_OP_CLAHE ? clahe_dev(c, p->s_k, a, g.clip_limit, g.tiles_x, g.tiles_y, puv) : equalize_dev(c, p->s_k, a, puv);
+}
+
+void pipe_free(mi_pipe* p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->c->device);
+    for (hipStream_t s : {p->s_h2d, p->s_k, p->s_d2h}) if (s) (void)hipStreamSynchronize(s);
+    for (auto& sl : p->slots) {
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_done}) if (e) (void)hipEventDestroy(e);
+    }
+    if (p->h_hard) (void)hipHostFree(p->h_hard);
+    if (p->s_k) {
+        std::lock_guard<std::mutex> lk(g_pipe_streams_mu);
+        PipeStreams& ps = g_pipe_streams[p->c->device];
+        if (--ps.users == 0) {
+            for (hipStream_t s : {ps.h2d, ps.k, ps.d2h}) if (s) (void)hipStreamDestroy(s);
+            ps = PipeStreams{};
+        }
+    }
+    delete p;
+}
+
+}  // namespace
+
+extern "C" {
+
+mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
+{
+    ENTER(c);
+    if (!cfg || !out) return fail(c, MI_ERR_BAD_ARG, "null config / out");
+    *out = nullptr;
+    if (cfg->width <= 0 || cfg->height <= 0) return fail(c, MI_ERR_BAD_ARG, "pipe needs a positive frame size");
+    if ((cfg->width & 1) || (cfg->height & 1)) return fail(c, MI_ERR_BAD_ARG, "NV12 frames have even width and height");
+    if ((long long)cfg->width * cfg->height > 0x7fffffffLL / 3) return fail(c, MI_ERR_UNSUPPORTED, "frame too large");
+    if (cfg->op != MI_OP_EQUALIZE && cfg->op != MI_OP_CLAHE && cfg->op != MI_OP_CHANNELS) return fail(c, MI_ERR_BAD_ARG, "bad op");
+    if (cfg->uv_mode != MI_UV_FILL128 && cfg->uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
+    if (cfg->op == MI_OP_CLAHE && (cfg->tiles_x <= 0 || cfg->tiles_y <= 0)) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
+    if (cfg->uv_policy < MI_PIPE_UV_AUTO || cfg->uv_policy > MI_PIPE_UV_DEVICE) return fail(c, MI_ERR_BAD_ARG, "bad uv_policy");
+    mi_pipe* p = new (std::nothrow) mi_pipe();
+    if (!p) return fail(c, MI_ERR_OOM, "pipe allocation failed");
+    p->c = c; p->cfg = *cfg;
+    p->cfg.depth = std::max(2, std::min(16, cfg->depth > 0 ? cfg->depth : 4));
+    p->ybytes = (size_t)cfg->width * cfg->height; p->uvbytes = p->ybytes / 2;
+    // the channel op needs chroma on the device; otherwise the UV half stays on the host unless asked for
+    p->uv_dev = cfg->op == MI_OP_CHANNELS || cfg->uv_policy == MI_PIPE_UV_DEVICE;
+    p->xfer_in = p->ybytes + ((p->uv_dev && (cfg->op == MI_OP_CHANNELS || cfg->uv_mode == MI_UV_COPY)) ? p->uvbytes : 0);
+    p->xfer_out = p->ybytes + (p->uv_dev ? p->uvbytes : 0);
+    auto bail = [&](mi_status st) { pipe_free(p); return st; };
+    if (c->device >= kMaxDevices) { fail(c, MI_ERR_UNSUPPORTED, "pipe: device index too large"); return bail(MI_ERR_UNSUPPORTED); }
+    {
+        std::lock_guard<std::mutex> lk(g_pipe_streams_mu);
+        PipeStreams& ps = g_pipe_streams[c->device];
+        if (ps.users == 0) {
+            for (hipStream_t* s : {&ps.h2d, &ps.k, &ps.d2h}) {
+                hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+                if (e != hipSuccess) {
+                    for (hipStream_t q : {ps.h2d, ps.k, ps.d2h}) if (q) (void)hipStreamDestroy(q);
+                    ps = PipeStreams{};
+                    fail_hip(c, e, "hipStreamCreateWithFlags");
+                    return bail(MI_ERR_HIP);
+                }
+            }
+        }
+        ++ps.users;
+        p->s_h2d = ps.h2d; p->s_k = ps.k; p->s_d2h = ps.d2h;
+    }
+    p->slots.resize((size_t)p->cfg.depth);
+    const size_t fbytes = p->ybytes + p->uvbytes;
+    for (auto& sl : p->slots) {
+        for (uint8_t** d : {&sl.d_in, &sl.d_out}) {
+            void* q = nullptr;
+            hipError_t e = hipMalloc(&q, fbytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); fail(c, MI_ERR_OOM, "pipe: device frame allocation failed"); return bail(MI_ERR_OOM); }
+            *d = (uint8_t*)q;
+        }
+        for (hipEvent_t* e : {&sl.ev_h2d, &sl.ev_k, &sl.ev_done}) {
+            hipError_t r = hipEventCreateWithFlags(e, hipEventDisableTiming);
+            if (r != hipSuccess) { fail_hip(c, r, "hipEventCreateWithFlags"); return bail(MI_ERR_HIP); }
+        }
+    }
+    {
+        void* q = nullptr;
+        hipError_t e = hipHostMalloc(&q, 64 * sizeof(uint32_t), hipHostMallocDefault);
+        if (e != hipSuccess) { fail_hip(c, e, "hipHostMalloc"); return bail(MI_ERR_HIP); }
+        p->h_hard = (uint32_t*)q;
+        memset(p->h_hard, 0, 64 * sizeof(uint32_t));
+    }
+    // warm-up: sizes the context's scratch for this shape and makes the runtime create the hardware queues / copy-engine
+    // state behind all three streams now, not under the first real frame (26 ms were measured on a first frame otherwise)
+    {
+        PipeSlot& sl = p->slots[0];
+        void* pin = nullptr;
+        const size_t wb = std::min<size_t>(fbytes, (size_t)4 << 20);
+        hipError_t e = hipHostMalloc(&pin, wb, hipHostMallocDefault);
+        if (e != hipSuccess) { fail_hip(c, e, "hipHostMalloc"); return bail(MI_ERR_HIP); }
+        memset(pin, 128, wb);
+        auto step = [&](hipError_t r, const char* what) { if (r != hipSuccess && e == hipSuccess) { e = r; fail_hip(c, r, what); } };
+        step(hipMemsetAsync(sl.d_in, 128, fbytes, p->s_h2d), "hipMemsetAsync");
+        step(hipMemcpyAsync(sl.d_in, pin, wb, hipMemcpyHostToDevice, p->s_h2d), "hipMemcpyAsync");
+        step(hipEventRecord(sl.ev_h2d, p->s_h2d), "hipEventRecord");
+        step(hipStreamWaitEvent(p->s_k, sl.ev_h2d, 0), "hipStreamWaitEvent");
+        mi_status st = e == hipSuccess ? pipe_run_op(p, sl) : MI_ERR_HIP;
+        if (st == MI_OK) {
+            step(hipEventRecord(sl.ev_k, p->s_k), "hipEventRecord");
+            step(hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0), "hipStreamWaitEvent");
+            step(hipMemcpyAsync(pin, sl.d_out, wb, hipMemcpyDeviceToHost, p->s_d2h), "hipMemcpyAsync");
+            step(hipStreamSynchronize(p->s_d2h), "hipStreamSynchronize");
+        }
+        (void)hipStreamSynchronize(p->s_k);
+        (void)hipHostFree(pin);
+        if (st) return bail(st);
+        if (e != hipSuccess) return bail(MI_ERR_HIP);
+    }
+    *out = p;
+    return MI_OK;
+}
+
+void mi_pipe_destroy(mi_pipe* p)
+{
+    if (!p) return;
+    std::unique_lock<std::mutex> lk(p->c->mu);
+    pipe_free(p);
+}
+
+int mi_pipe_pending(const mi_pipe* p) { return p ? (int)p->count : 0; }
+int mi_pipe_depth(const mi_pipe* p) { return p ? p->cfg.depth : 0; }
+
+mi_status mi_pipe_submit(mi_pipe* p, const uint8_t* in, uint8_t* out, uint64_t tag)
+{
+    if (!p) return MI_ERR_BAD_ARG;
+    mi_ctx* c = p->c;
+    ENTER(c);
+    if (!in || !out) return fail(c, MI_ERR_BAD_ARG, "null frame pointer");
+    if (p->count == p->slots.size()) return fail(c, MI_ERR_BUSY, "pipe is full: call mi_pipe_wait first");
+    PipeSlot& sl = p->slots[(p->head + p->count) % p->slots.size()];
+    sl.in = in; sl.out = out; sl.tag = tag; sl.st = MI_OK;
+    const size_t fbytes = p->ybytes + p->uvbytes;
+    // registered (pinned) memory is DMA'd asynchronously; pageable memory makes this copy block the caller while the
+    // runtime stages it, which is still correct
+    HIPCHK(c, hipMemcpyAsync(sl.d_in, in, p->xfer_in, hipMemcpyHostToDevice, p->s_h2d));
+    HIPCHK(c, hipEventRecord(sl.ev_h2d, p->s_h2d));
+    HIPCHK(c, hipStreamWaitEvent(p->s_k, sl.ev_h2d, 0));
+    mi_status st = pipe_run_op(p, sl);
+    if (st) return st;
+    HIPCHK(c, hipEventRecord(sl.ev_k, p->s_k));
+    sl.out_async = host_range_pinned(out, p->uv_dev ? fbytes : p->ybytes);
+    if (sl.out_async) {
+        HIPCHK(c, hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0));
+        HIPCHK(c, hipMemcpyAsync(out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
+        if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)
+            HIPCHK(c, hipMemcpyAsync(p->h_hard + (&sl - p->slots.data()), c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_d2h));
+        HIPCHK(c, hipEventRecord(sl.ev_done, p->s_d2h));
+    }
+    ++p->count; ++p->submitted;
+    return MI_OK;
+}
+
+mi_status mi_pipe_wait(mi_pipe* p, uint64_t* tag, uint8_t** out_frame)
+{
+    if (!p) return MI_ERR_BAD_ARG;
+    mi_ctx* c = p->c;
+    ENTER(c);
+    if (p->count == 0) return fail(c, MI_ERR_BAD_ARG, "mi_pipe_wait: nothing pending");
+    PipeSlot& sl = p->slots[p->head];
+    const size_t slot = p->head;
+    if (tag) *tag = sl.tag;
+    if (out_frame) *out_frame = sl.out;
+    // the host's share of the frame first: it overlaps whatever the copy engines are still doing
+    if (!p->uv_dev) {
+        if (p->cfg.uv_mode == MI_UV_FILL128) memset(sl.out + p->ybytes, 128, p->uvbytes);
+        else if (sl.out != sl.in) memmove(sl.out + p->ybytes, sl.in + p->ybytes, p->uvbytes);
+    }
+    if (sl.out_async) {
+        HIPCHK(c, hipEventSynchronize(sl.ev_done));
+    } else {
+        HIPCHK(c, hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0));
+        HIPCHK(c, hipMemcpyAsync(sl.out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
+        if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)
+            HIPCHK(c, hipMemcpyAsync(p->h_hard + slot, c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_d2h));
+        HIPCHK(c, hipStreamSynchronize(p->s_d2h));
+    }
+    p->head = (p->head + 1) % p->slots.size();
+    --p->count; ++p->completed;
+    const uint64_t hard = c->fused_stat_base[2] + p->h_hard[slot];
+    if (p->cfg.op == MI_OP_EQUALIZE && hard > c->fused_seen_hard) {
+        c->fused_seen_hard = hard;
+        return fail(c, MI_ERR_HIP, "fused equalize kernel: a frame could not be repaired after an expired inter-workgroup wait; output invalid");
+    }
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -30,3 +30,4 @@ using namespace mi;
 #include "host/capi.inc.hpp"
 #include "host/color.inc.hpp"
 #include "host/clahe16.inc.hpp"
+#include "host/pipe.inc.hpp"

@@ -9,7 +9,10 @@
 //   2 s status tick: in/out fps, queue depth, errors, backlog    OpenCVequalHist.cpp:200-234,
 //                                                                OpenCLequalHist.cpp:439-508
 // New: --op equalize|clahe|channels (channels = NV12 -> BGR -> equalizeHist per channel -> NV12), --uv fill128|copy (OpenCVequalHist.cpp:160-162 vs
-// ColoropenCVCwqualHist.cpp:165), --frames N, --input/--output raw NV12 files, --paced.
+// ColoropenCVCwqualHist.cpp:165), --frames N, --input/--output raw NV12 files, --paced, --depth D (frames a worker keeps in flight on
+// its GPU), --uv-policy host|device (who writes the UV half), --no-pin (leave the frame ring pageable; by default it is registered
+// once, the way a GstBufferPool's memory would be), --loop (rewind --input at its end: clahevideo.cpp:294-302), --dump-every K
+// (write only every K-th delivered frame to --output).  --workers may exceed the GPU count (worker w -> GPU w mod N), up to 64.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -32,12 +35,13 @@ static bool kv(const char* arg, const char* key, std::string& v, int& i, int arg
 int main(int argc, char** argv)
 {
     using namespace micv;
-    int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8;
+    int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8, depth = 4;
     double clip = 2.0;
-    bool paced = false, pin = false;
-    std::string op = "equalize", uv = "fill128", input, output, v;
+    bool paced = false, pin = true, loop = false;
+    int dump_every = 1;
+    std::string op = "equalize", uv = "fill128", uv_policy = "host", input, output, v;
     for (int i = 1; i < argc; ++i) {
-        if (kv(argv[i], "workers", v, i, argc, argv)) workers = std::max(1, std::min(8, atoi(v.c_str())));
+        if (kv(argv[i], "workers", v, i, argc, argv)) workers = std::max(1, std::min(64, atoi(v.c_str())));    // reference: 1..8 (OpenCVequalHist.cpp:274)
         else if (kv(argv[i], "width", v, i, argc, argv)) width = atoi(v.c_str());
         else if (kv(argv[i], "height", v, i, argc, argv)) height = atoi(v.c_str());
         else if (kv(argv[i], "fps", v, i, argc, argv)) fps = atoi(v.c_str());
@@ -49,7 +53,12 @@ int main(int argc, char** argv)
         else if (kv(argv[i], "input", v, i, argc, argv)) input = v;
         else if (kv(argv[i], "output", v, i, argc, argv)) output = v;
         else if (strcmp(argv[i], "--paced") == 0) paced = true;
-        else if (strcmp(argv[i], "--pin") == 0) pin = true;          // register the frame ring like a pinned GstBufferPool
+        else if (kv(argv[i], "depth", v, i, argc, argv)) depth = atoi(v.c_str());
+        else if (kv(argv[i], "uv-policy", v, i, argc, argv)) uv_policy = v;
+        else if (strcmp(argv[i], "--pin") == 0) pin = true;          // (default) register the frame ring like a pinned GstBufferPool
+        else if (strcmp(argv[i], "--no-pin") == 0) pin = false;
+        else if (strcmp(argv[i], "--loop") == 0) loop = true;
+        else if (kv(argv[i], "dump-every", v, i, argc, argv)) dump_every = std::max(1, atoi(v.c_str()));
         else fprintf(stderr, "Warning: ignoring unknown arg: %s\n", argv[i]);
     }
     if (width <= 0 || height <= 0 || frames <= 0) { fprintf(stderr, "bad size\n"); return 1; }
@@ -77,14 +86,15 @@ int main(int argc, char** argv)
                        uv == "copy" ? UV_COPY : UV_FILL128,
                        [&](const FrameJob& j) {
                            if (!j.ok) fprintf(stderr, "frame %llu error: %s\n", (unsigned long long)j.index, j.error.c_str());
-                           else if (fout) fwrite(j.out, 1, fb, fout);
+                           else if (fout && j.index % (uint64_t)dump_every == 0) fwrite(j.out, 1, fb, fout);
                            if (j.index < latency_ms.size())
                                latency_ms[j.index] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_submit[j.index]).count();
                            delivered.fetch_add(1);
                        },
-                       clip, Size(tile, tile), ring / (size_t)workers > 2 ? ring / (size_t)workers - 1 : 1);
-        printf("nv12_stream: %dx%d %s uv=%s workers=%d gpus=%d frames=%d%s%s\n", width, height, op.c_str(), uv.c_str(), workers,
-               getDeviceCount(), frames, paced ? " paced" : "", pin ? " pinned-ring" : "");
+                       clip, Size(tile, tile), ring / (size_t)workers > 2 ? ring / (size_t)workers - 1 : 1, depth,
+                       uv_policy == "device" ? MI_PIPE_UV_DEVICE : MI_PIPE_UV_HOST);
+        printf("nv12_stream: %dx%d %s uv=%s (uv-policy %s) workers=%d depth=%d gpus=%d frames=%d%s%s\n", width, height, op.c_str(), uv.c_str(),
+               uv_policy.c_str(), workers, depth, getDeviceCount(), frames, paced ? " paced" : "", pin ? " pinned-ring" : " pageable-ring");
         // synthetic source: the ring's frames exist before the clock starts (a camera / decoder hands over finished frames;
         // generating 12 MB of noise per frame on the submitting thread would otherwise be the slowest stage of the first lap)
         if (!fin) for (int k = 0; k < ring && k < frames; ++k) synth(in[k], k);
@@ -95,7 +105,11 @@ int main(int argc, char** argv)
             // a ring slot may be reused only after its frame was delivered
             while (delivered.load() + ring <= (uint64_t)k) std::this_thread::sleep_for(std::chrono::microseconds(50));
             auto& f = in[k % ring];
-            if (fin) { if (fread(f.data(), 1, fb, fin) != fb) { frames = k; break; } }
+            if (fin) {
+                size_t got = fread(f.data(), 1, fb, fin);
+                if (got != fb && loop && k > 0) { rewind(fin); got = fread(f.data(), 1, fb, fin); }     // --loop: seek to 0 at end of input
+                if (got != fb) { frames = k; break; }
+            }
             if (paced) std::this_thread::sleep_until(t0 + std::chrono::microseconds((int64_t)k * 1000000 / fps));
             t_submit[k] = std::chrono::steady_clock::now();
             pool.submit(f.data(), out[k % ring].data());

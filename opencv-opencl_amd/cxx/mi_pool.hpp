@@ -6,8 +6,11 @@
 //   --workers 1..8                                          OpenCVequalHist.cpp:274
 // Differences, on purpose: worker w is bound to GPU (w mod device_count) and owns one mi_ctx there
 // (the shape of the per-worker OpenCL objects, OpenCLequalHist.cpp:142-152); frames are sharded
-// frame k -> worker k mod N; and results are delivered in frame order (the reference pushes them in
-// completion order, which can reorder frames).  No collective: frames are independent.
+// frame k -> worker k mod N; results are delivered in frame order (the reference pushes them in
+// completion order, which can reorder frames); and a worker does not run its frames one blocking
+// write / task / read at a time (OpenCLequalHist.cpp:356-365): it drives an mi_pipe, so the upload of
+// frame k+2, the kernels of frame k+1 and the download of frame k overlap and ONE worker per GPU keeps
+// the PCIe link busy in both directions.  No collective: frames are independent.
 #ifndef MI_POOL_HPP_
 #define MI_POOL_HPP_
 
@@ -43,9 +46,11 @@ public:
     enum Op { EQUALIZE, CLAHE_OP, CHANNELS_EQ };   // CHANNELS_EQ: NV12 -> BGR -> equalizeHist on B, G, R -> NV12 (BASELINE config 5 read literally; ignores uv)
     using Sink = std::function<void(const FrameJob&)>;   // called in frame order, from a pool thread
 
+    // depth: frames a worker keeps in flight on its GPU (2..16); uv_policy: MI_PIPE_UV_AUTO / _HOST / _DEVICE (mi_lumaeq.h)
     FramePool(int workers, int width, int height, Op op, UVMode uv, Sink sink,
-              double clip = 2.0, Size tiles = Size(8, 8), size_t max_queue = 16)
-        : width_(width), height_(height), op_(op), uv_(uv), clip_(clip), tiles_(tiles), sink_(std::move(sink)), max_queue_(max_queue)
+              double clip = 2.0, Size tiles = Size(8, 8), size_t max_queue = 16, int depth = 4, int uv_policy = MI_PIPE_UV_AUTO)
+        : width_(width), height_(height), op_(op), uv_(uv), clip_(clip), tiles_(tiles), sink_(std::move(sink)), max_queue_(max_queue),
+          depth_(depth < 2 ? 2 : (depth > 16 ? 16 : depth)), uv_policy_(uv_policy)
     {
         if (workers < 1) workers = 1;
         if (workers > 64) workers = 64;
@@ -98,44 +103,62 @@ private:
     void run(int w, int device)
     {
         setDevice(device);
-        try {                                                   // warm-up: context + allocations for this frame size
-            const size_t fb = (size_t)width_ * height_ + (size_t)width_ * height_ / 2;
-            std::vector<unsigned char> tmp(fb, 128);
-            process(tmp.data(), tmp.data());
-        } catch (const std::exception&) {
-            // reported per frame later; the pool still comes up so submit()/finish() do not hang
+        mi_ctx* c = nullptr;
+        mi_pipe* pipe = nullptr;
+        std::string pipe_error;
+        try {                                                   // context + pipe: allocations and warm-up for this frame size happen here,
+            c = detail::thread_ctx();                           // not under the first real frame (~100 ms would blow a 16.7 ms budget)
+            mi_pipe_config cfg{};
+            cfg.width = width_; cfg.height = height_;
+            cfg.op = op_ == EQUALIZE ? MI_OP_EQUALIZE : (op_ == CLAHE_OP ? MI_OP_CLAHE : MI_OP_CHANNELS);
+            cfg.uv_mode = (mi_uv_mode)uv_; cfg.clip_limit = clip_; cfg.tiles_x = tiles_.width; cfg.tiles_y = tiles_.height;
+            cfg.depth = depth_; cfg.uv_policy = uv_policy_;
+            detail::check(c, mi_pipe_create(c, &cfg, &pipe), "mi_pipe_create");
+        } catch (const std::exception& e) {
+            pipe_error = e.what();                              // reported per frame; the pool still comes up so submit()/finish() do not hang
         }
         {
             std::lock_guard<std::mutex> lk(mu_);
             ++ready_;
             cv_done_.notify_all();
         }
+        std::deque<FrameJob> inflight;                          // submitted to the pipe, oldest first
         for (;;) {
             FrameJob j;
+            bool have = false;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_work_.wait(lk, [&] { return !queues_[w].empty() || stop_; });
-                if (queues_[w].empty()) return;
-                j = queues_[w].front();
-                queues_[w].pop_front();
-                cv_space_.notify_all();
+                if (inflight.empty()) cv_work_.wait(lk, [&] { return !queues_[w].empty() || stop_; });
+                if (!queues_[w].empty() && (int)inflight.size() < depth_) {
+                    j = queues_[w].front();
+                    queues_[w].pop_front();
+                    have = true;
+                    cv_space_.notify_all();
+                } else if (inflight.empty()) {
+                    break;                                      // stopped and drained
+                }
             }
-            try {
-                process(j.in, j.out);
-                j.ok = true;
-            } catch (const std::exception& e) {             // per-frame drop-and-count, OpenCVequalHist.cpp:189-193
-                j.ok = false; j.error = e.what();
+            if (have) {                                         // keep the pipe full before waiting for anything
+                mi_status st = pipe ? mi_pipe_submit(pipe, j.in, j.out, j.index) : MI_ERR_HIP;
+                if (st == MI_OK) { inflight.push_back(j); continue; }
+                j.ok = false;                                   // per-frame drop-and-count, OpenCVequalHist.cpp:189-193
+                j.error = pipe ? std::string("mi_pipe_submit: ") + mi_status_str(st) + " (" + mi_ctx_last_error_msg(c) + ")" : pipe_error;
+                stats_.processing_errors.fetch_add(1, std::memory_order_relaxed);
+                deliver(j);
+                continue;
+            }
+            FrameJob d = inflight.front();                      // pipe full, or nothing new to submit: complete the oldest frame
+            inflight.pop_front();
+            uint64_t tag = 0;
+            const mi_status st = mi_pipe_wait(pipe, &tag, nullptr);
+            d.ok = st == MI_OK && tag == d.index;
+            if (!d.ok) {
+                d.error = std::string("mi_pipe_wait: ") + mi_status_str(st) + " (" + mi_ctx_last_error_msg(c) + ")";
                 stats_.processing_errors.fetch_add(1, std::memory_order_relaxed);
             }
-            deliver(j);
+            deliver(d);
         }
-    }
-
-    void process(const unsigned char* in, unsigned char* out)
-    {
-        if (op_ == EQUALIZE) equalizeHistNV12(in, out, width_, height_, uv_);
-        else if (op_ == CLAHE_OP) claheNV12(in, out, width_, height_, uv_, clip_, tiles_);
-        else equalizeHistChannelsNV12(in, out, width_, height_);
+        if (pipe) mi_pipe_destroy(pipe);
     }
 
     // re-sequencer: hold completed frames until all earlier ones have been delivered
@@ -166,6 +189,7 @@ private:
     Size tiles_;
     Sink sink_;
     size_t max_queue_;
+    int depth_, uv_policy_;
     mutable std::mutex mu_;
     std::condition_variable cv_work_, cv_space_, cv_done_;
     std::vector<std::deque<FrameJob>> queues_;

@@ -20,7 +20,9 @@ KERNEL_NAMES = ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel"
                 "fused_finish_kernel"]
 COLOR_BGR2YUV, COLOR_YUV2BGR = 82, 84
 COLOR_YUV2BGR_NV12, COLOR_BGR2YUV_I420 = 93, 128
-OP_EQUALIZE, OP_CLAHE = 0, 1
+OP_EQUALIZE, OP_CLAHE, OP_CHANNELS = 0, 1, 2
+PIPE_UV_AUTO, PIPE_UV_HOST, PIPE_UV_DEVICE = 0, 1, 2
+ERR_BUSY = 6
 
 # every extern "C" symbol include/mi_lumaeq.h declares (tests check the .so exports them all)
 DECLARED_SYMBOLS = [
@@ -33,6 +35,7 @@ DECLARED_SYMBOLS = [
     "mi_clahe_tile_luts_batch_dev",
     "mi_ctx_set_profiling", "mi_ctx_profile_read", "mi_kernel_name",
     "mi_ctx_synchronize", "mi_ctx_set_option", "mi_ctx_get_stat",
+    "mi_pipe_create", "mi_pipe_destroy", "mi_pipe_submit", "mi_pipe_wait", "mi_pipe_pending", "mi_pipe_depth",
     "mi_host_register", "mi_host_unregister", "mi_clahe_u16", "mi_clahe_u16_batch_dev",
     "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
     "mi_nv12_bgr_equalize", "mi_nv12_bgr_equalize_batch_dev", "mi_cvt_color_420_u8", "mi_cvt_color_420_u8_batch_dev",
@@ -44,6 +47,11 @@ _K = len(KERNEL_NAMES)
 class _Profile(C.Structure):
     _fields_ = [("total_ms", C.c_double * _K), ("launches", C.c_uint64 * _K), ("min_ms", C.c_double * _K), ("p10_ms", C.c_double * _K),
                 ("p50_ms", C.c_double * _K), ("p90_ms", C.c_double * _K), ("max_ms", C.c_double * _K)]
+
+
+class _PipeConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("op", C.c_int), ("uv_mode", C.c_int), ("clip_limit", C.c_double),
+                ("tiles_x", C.c_int), ("tiles_y", C.c_int), ("depth", C.c_int), ("uv_policy", C.c_int)]
 
 
 class MiError(RuntimeError):
@@ -114,6 +122,12 @@ def lib() -> C.CDLL:
     L.mi_ctx_synchronize.argtypes = [vp, vp]
     L.mi_ctx_set_option.argtypes = [vp, C.c_char_p, i]
     L.mi_ctx_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
+    L.mi_pipe_create.argtypes = [vp, C.POINTER(_PipeConfig), C.POINTER(vp)]
+    L.mi_pipe_destroy.argtypes = [vp]; L.mi_pipe_destroy.restype = None
+    L.mi_pipe_submit.argtypes = [vp, vp, vp, C.c_uint64]
+    L.mi_pipe_wait.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(vp)]
+    L.mi_pipe_pending.argtypes = [vp]
+    L.mi_pipe_depth.argtypes = [vp]
     L.mi_ctx_set_profiling.argtypes = [vp, i]
     L.mi_ctx_profile_read.argtypes = [vp, C.POINTER(_Profile), i]
     _lib = L
@@ -444,3 +458,57 @@ class Context:
         self._chk(lib().mi_ctx_profile_read(self._h, C.byref(p), 1 if reset else 0), "mi_ctx_profile_read")
         return {KERNEL_NAMES[k]: {"total_ms": p.total_ms[k], "launches": int(p.launches[k]), "min_ms": p.min_ms[k], "p10_ms": p.p10_ms[k],
                                   "p50_ms": p.p50_ms[k], "p90_ms": p.p90_ms[k], "max_ms": p.max_ms[k]} for k in range(_K)}
+
+
+class Pipe:
+    """mi_pipe wrapper: asynchronous in-order NV12 frame pipeline on one context (frames are numpy uint8 arrays of W*H*3/2 bytes).
+    The arrays handed to submit() are kept alive until wait() returns them."""
+
+    def __init__(self, ctx: Context, width: int, height: int, op: int = OP_EQUALIZE, uv_mode: int = UV_FILL128,
+                 clip_limit: float = 2.0, tiles_x: int = 8, tiles_y: int = 8, depth: int = 4, uv_policy: int = PIPE_UV_AUTO):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        self._held = {}
+        cfg = _PipeConfig(int(width), int(height), int(op), int(uv_mode), float(clip_limit), int(tiles_x), int(tiles_y), int(depth), int(uv_policy))
+        ctx._chk(lib().mi_pipe_create(ctx._h, C.byref(cfg), C.byref(self._h)), "mi_pipe_create")
+        self.frame_bytes = width * height * 3 // 2
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            h, self._h = self._h, None
+            lib().mi_pipe_destroy(h)
+            self._held.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def pending(self) -> int:
+        return int(lib().mi_pipe_pending(self._h))
+
+    @property
+    def depth(self) -> int:
+        return int(lib().mi_pipe_depth(self._h))
+
+    def submit(self, frame_in: np.ndarray, frame_out: np.ndarray, tag: int) -> bool:
+        """False when the pipe is full (MI_ERR_BUSY: call wait() first)."""
+        for a in (frame_in, frame_out):
+            if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or not a.flags.c_contiguous or a.size < self.frame_bytes:
+                raise MiError(1, "mi_pipe_submit", "frames must be contiguous uint8 arrays of W*H*3/2 bytes")
+        rc = lib().mi_pipe_submit(self._h, frame_in.ctypes.data, frame_out.ctypes.data, int(tag))
+        if rc == ERR_BUSY:
+            return False
+        self._ctx._chk(rc, "mi_pipe_submit")
+        self._held[int(tag)] = (frame_in, frame_out)
+        return True
+
+    def wait(self):
+        """Blocks for the oldest pending frame; returns (tag, output array)."""
+        tag, ptr = C.c_uint64(0), C.c_void_p()
+        rc = lib().mi_pipe_wait(self._h, C.byref(tag), C.byref(ptr))
+        held = self._held.pop(int(tag.value), (None, None))
+        self._ctx._chk(rc, "mi_pipe_wait")
+        return int(tag.value), held[1]

@@ -72,6 +72,47 @@ def test_stream_demo_file_io_matches_oracle(tmp_path):
             assert np.array_equal(out[k], want), (op, k)
 
 
+@pytest.mark.gpu
+def test_stream_config4_512_frames_4k_paced_60fps(tmp_path):
+    """BASELINE.json configs[3] on one GPU: 512 3840x2160 NV12 frames released at 60 fps through ONE pool worker (host frame in ->
+    host frame out, PCIe inclusive; the reference's live pipeline OpenCVequalHist.cpp:102-196, :397-402 without the codecs).
+    No frame may miss its 16.7 ms budget, none may error, delivery is in order, and every 37th frame equals the oracle."""
+    import re
+    import sys
+    import numpy as np
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "opencv-opencl_amd" / "python"))
+    import oracle
+    from mi_lumaeq import synth
+    _build()
+    w, h, distinct, n, every = 3840, 2160, 8, 512, 37
+    frames = [synth.nv12_frame(w, h, synth.DISTS[k % 5], 4100 + k) for k in range(distinct)]
+    src = tmp_path / "in8.nv12"
+    with open(src, "wb") as f:
+        for fr in frames:
+            f.write(fr.tobytes())
+    dst = tmp_path / "out.nv12"
+    r = subprocess.run([str(ROOT / "opencv-opencl_amd" / "lib" / "nv12_stream"), "--input", str(src), "--loop", "--output", str(dst),
+                        "--dump-every", str(every), "--width", str(w), "--height", str(h), "--frames", str(n), "--workers", "1",
+                        "--paced", "--fps", "60", "--op", "equalize", "--uv", "fill128"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"done: {n} frames" in r.stdout and "errors=0" in r.stdout, r.stdout
+    m = re.search(r"frames over the [0-9.]+ ms frame budget: (\d+)", r.stdout)
+    assert m and int(m.group(1)) == 0, r.stdout
+    m = re.search(r"= ([0-9.]+) frames/s", r.stdout)
+    assert m and 59.0 <= float(m.group(1)) <= 61.0, r.stdout         # paced: the source rate, not the pipeline's ceiling
+    fb = w * h * 3 // 2
+    out = np.fromfile(dst, np.uint8)
+    ks = list(range(0, n, every))
+    assert out.size == len(ks) * fb
+    want = {}
+    for i, k in enumerate(ks):
+        j = k % distinct
+        if j not in want:
+            want[j] = oracle.nv12_frame(frames[j], w, h, uv_mode=0, op=0)
+        assert np.array_equal(out[i * fb:(i + 1) * fb], want[j]), k
+
+
 def test_adapter_mat_semantics_cpu(tmp_path):
     """Mat / ROI / create-no-realloc / split / merge / type errors of the adapter, on the CPU, under ASan + UBSan."""
     _build()

@@ -968,3 +968,93 @@ def test_clahe_fp_contract_mode(ctx):
         oracle.set_fp_contract(old)
         ctx.set_option("clahe_fp_contract", 0)
         ctx.set_option("clahe_float_tables", 1)
+
+
+def _pipe_expected(frame, w, h, op, uv_mode, cfg):
+    if op == mi_lumaeq.OP_CHANNELS:
+        return oracle.nv12_bgr_equalize(frame, w, h)
+    return oracle.nv12_frame(frame, w, h, uv_mode=uv_mode, op=op, clip_limit=cfg[0], tiles_x=cfg[1], tiles_y=cfg[2])
+
+
+@pytest.mark.parametrize("pinned", [True, False], ids=["registered", "pageable"])
+@pytest.mark.parametrize("case", [(mi_lumaeq.OP_EQUALIZE, 0, mi_lumaeq.PIPE_UV_AUTO), (mi_lumaeq.OP_EQUALIZE, 1, mi_lumaeq.PIPE_UV_HOST),
+                                  (mi_lumaeq.OP_EQUALIZE, 1, mi_lumaeq.PIPE_UV_DEVICE), (mi_lumaeq.OP_EQUALIZE, 0, mi_lumaeq.PIPE_UV_DEVICE),
+                                  (mi_lumaeq.OP_CLAHE, 0, mi_lumaeq.PIPE_UV_HOST), (mi_lumaeq.OP_CLAHE, 1, mi_lumaeq.PIPE_UV_DEVICE),
+                                  (mi_lumaeq.OP_CHANNELS, 0, mi_lumaeq.PIPE_UV_AUTO)], ids=str)
+def test_pipe_frames_in_flight_complete_in_order_and_match_oracle(case, pinned):
+    """mi_pipe (the per-GPU worker's device side, OpenCVequalHist.cpp:102-196 with frames in flight): every frame that goes
+    through -- whatever the op, the UV mode, who writes the UV half, registered or pageable host memory -- comes back in
+    submission order with the oracle's bytes; a full pipe says MI_ERR_BUSY instead of blocking or dropping."""
+    op, uv_mode, policy = case
+    w, h, n, depth = 640, 368, 11, 3
+    cfg = (3.0, 4, 4)
+    frames = [synth.nv12_frame(w, h, synth.DISTS[k % 5], 900 + k) for k in range(n)]
+    ins = [f.copy() for f in frames]
+    outs = [np.zeros_like(f) for f in frames]
+    if pinned:
+        for a in ins + outs:
+            mi_lumaeq.host_register(a)
+    c = mi_lumaeq.Context(0)
+    try:
+        with mi_lumaeq.Pipe(c, w, h, op=op, uv_mode=uv_mode, clip_limit=cfg[0], tiles_x=cfg[1], tiles_y=cfg[2], depth=depth, uv_policy=policy) as pipe:
+            assert pipe.depth == depth and pipe.pending == 0
+            done = []
+            for k in range(n):
+                while not pipe.submit(ins[k], outs[k], 1000 + k):          # full: complete the oldest first
+                    assert pipe.pending == depth
+                    done.append(pipe.wait())
+            assert pipe.pending == min(depth, n)
+            while pipe.pending:
+                done.append(pipe.wait())
+            assert [t for t, _ in done] == [1000 + k for k in range(n)]
+            for k, (_, out) in enumerate(done):
+                assert out is outs[k]
+                assert np.array_equal(out, _pipe_expected(frames[k], w, h, op, uv_mode, cfg)), (case, pinned, k)
+            with pytest.raises(mi_lumaeq.MiError):                          # nothing pending
+                pipe.wait()
+            # in place (the zero-copy variant, nextimprovement.cpp:159-168): out == in
+            buf = frames[2].copy()
+            if pinned:
+                mi_lumaeq.host_register(buf)
+            try:
+                assert pipe.submit(buf, buf, 7)
+                tag, out = pipe.wait()
+                assert tag == 7 and np.array_equal(out, _pipe_expected(frames[2], w, h, op, uv_mode, cfg))
+            finally:
+                if pinned:
+                    mi_lumaeq.host_unregister(buf)
+        # the context's synchronous entry points still work once the pipe is gone
+        y = frames[0][: w * h].reshape(h, w)
+        assert np.array_equal(c.equalize_hist(y), oracle.equalize_hist(y))
+    finally:
+        c.close()
+        if pinned:
+            for a in ins + outs:
+                mi_lumaeq.host_unregister(a)
+
+
+def test_pipe_argument_errors_and_fail_soft():
+    c = mi_lumaeq.Context(0)
+    try:
+        for bad in (dict(width=0), dict(width=641), dict(op=5), dict(uv_mode=3), dict(uv_policy=9), dict(op=mi_lumaeq.OP_CLAHE, tiles_x=0)):
+            kw = dict(width=640, height=360, op=mi_lumaeq.OP_EQUALIZE, uv_mode=0, uv_policy=0, tiles_x=8, tiles_y=8)
+            kw.update(bad)
+            with pytest.raises(mi_lumaeq.MiError):
+                mi_lumaeq.Pipe(c, kw["width"], kw["height"], op=kw["op"], uv_mode=kw["uv_mode"], tiles_x=kw["tiles_x"], tiles_y=kw["tiles_y"],
+                               uv_policy=kw["uv_policy"])
+        # a hand-off failure inside a pipelined frame is repaired on the device like anywhere else
+        w, h = 1920, 1080
+        f = synth.nv12_frame(w, h, "D2", 77)
+        o = np.zeros_like(f)
+        with mi_lumaeq.Pipe(c, w, h, depth=2) as pipe:
+            c.set_option("fused_fault_inject", 1)
+            assert pipe.submit(f, o, 1)
+            c.set_option("fused_fault_inject", 0)
+            f2, o2 = f.copy(), np.zeros_like(f)
+            assert pipe.submit(f2, o2, 2)
+            assert pipe.wait()[0] == 1 and pipe.wait()[0] == 2
+        want = oracle.nv12_frame(f, w, h, uv_mode=0, op=0)
+        assert np.array_equal(o, want) and np.array_equal(o2, want)
+        assert c.get_stat("fused_fallbacks") == 1 and c.get_stat("fused_hard_errors") == 0
+    finally:
+        c.close()
