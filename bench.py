@@ -117,6 +117,10 @@ def cpu_baseline(args, w, h):
             "value_1thread": round(single, 2), "value_1080p": round(fps1080, 2)}
 
 
+def device_for_collectives(torch, backend, local_rank):
+    return torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+
+
 def opencv_cross_check(ctx, w, h, dist_name):
     """the oracle is a restatement (parity unpinned).  Wherever a real OpenCV is importable, compare the GPU
     path with cv2 itself on one frame and say so in the JSON line; None when there is no cv2 (this image has none)."""
@@ -156,16 +160,21 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs HIP devices (no CPU fallback)")
         torch.cuda.set_device(local_rank)
+        # No silent substitution: if RCCL was asked for and does not come up with every rank, the run fails.  (gloo is only
+        # ever used when asked for by name, to rehearse the N>1 path on a one-GPU box.)
         if args.dist_backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            except Exception as e:      # the backend only carries the barrier + one scalar max: gloo can stand in
-                print(f"[bench] RCCL init failed ({e!r}); falling back to gloo for the barrier", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+        backend_used = dist.get_backend()
+        # every rank contributes 1 through the backend itself: the sum is the number of ranks the backend really connects
+        one = torch.ones(1, device=device_for_collectives(torch, backend_used, local_rank))
+        dist.all_reduce(one)
+        world_seen = int(one.item())
+        if backend_used != args.dist_backend or world_seen != world:
+            raise SystemExit(f"dist backend check failed: asked {args.dist_backend} x {world}, got {backend_used} x {world_seen}")
+    else:
+        backend_used, world_seen = None, 1
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world == 1 and args.gpus > 1:
@@ -211,20 +220,36 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
+    # The library's own verdict on the timed launches, on EVERY rank: synchronize() raises if the fused path met a frame it
+    # could not repair, and a launch that had to be repaired on the device (correct output, but slower) is disclosed.
+    run_ok, run_err = True, ""
+    try:
+        ctx.synchronize(stream)
+        fused_fallbacks = ctx.get_stat("fused_fallbacks")
+    except mi_lumaeq.MiError as e:
+        run_ok, run_err, fused_fallbacks = False, str(e), -1
     prof = ctx.profile_read(reset=True)
     elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None)
 
-    # parity spot check of the measured configuration (one frame, rank 0) -- checker only
+    # parity spot check of the measured configuration (rank 0; first, middle and last frame of the last step) -- checker only
     parity = None
-    if rank == 0:
+    if rank == 0 and run_ok:
         import numpy as np
         import oracle
-        got = d_out[B // 2].cpu().numpy()
-        want = oracle.nv12_frame(d_in[B // 2].cpu().numpy(), w, h, uv_mode=uv_mode, op=1 if args.op == "clahe" else 0,
-                                 clip_limit=2.0, tiles_x=8, tiles_y=8)
-        parity = bool(np.array_equal(got, want))
-        if not parity:
-            raise SystemExit("PARITY FAILURE: GPU output differs from the oracle; refusing to report a number")
+        parity = True
+        for k in sorted({0, B // 2, B - 1}):
+            got = d_out[k].cpu().numpy()
+            want = oracle.nv12_frame(d_in[k].cpu().numpy(), w, h, uv_mode=uv_mode, op=1 if args.op == "clahe" else 0,
+                                     clip_limit=2.0, tiles_x=8, tiles_y=8)
+            parity = parity and bool(np.array_equal(got, want))
+    # one verdict for the whole job, shared BEFORE anybody exits, so no rank is left blocked in a barrier
+    ok_local = 1.0 if (run_ok and parity is not False) else 0.0
+    ok_all = -shard.max_over_ranks(-ok_local, dist if world > 1 else None)
+    if ok_all < 1.0:
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit("REFUSING TO REPORT: " + (run_err or ("PARITY FAILURE: GPU output differs from the oracle" if parity is False
+                                                                 else "another rank failed its run or parity check")))
 
     if rank != 0:
         if world > 1:
@@ -256,11 +281,17 @@ def main():
             kinfo[name] = e
     cands = [k for k in kinfo if k in per_kernel_alg]
     dom = max(cands, key=lambda k: kinfo[k]["avg_ms"] * kinfo[k]["launches"]) if cands else None
-    traffic = None
+    # `traffic` is NOT measured by this run: PMC counters need rocprofv3 (separate --pmc passes, tools/collect_profiles.sh).
+    # It is the committed per-launch figure of the same kernel / workload, and `traffic_source` says where it came from.
+    traffic, traffic_source = None, None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists() and dom:
         try:
-            traffic = json.loads(tfile.read_text()).get(f"{dom}:{args.op}:{w}x{h}x{B}:{args.uv}")
+            ent = json.loads(tfile.read_text()).get(f"{dom}:{args.op}:{w}x{h}x{B}:{args.uv}")
+            if isinstance(ent, dict):
+                traffic, traffic_source = ent.get("bytes"), ent.get("source")
+            elif ent is not None:
+                traffic, traffic_source = ent, "profiles/traffic.json (round 1 PMC passes)"
         except Exception:
             traffic = None
     roofline = None
@@ -268,14 +299,18 @@ def main():
         alg_bytes = per_kernel_alg[dom]
         achieved = alg_bytes / (kinfo[dom]["avg_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kinfo[dom]["avg_ms"],
-                    "launch_ms_p10_p50_p90": [kinfo[dom]["p10_ms"], kinfo[dom]["p50_ms"], kinfo[dom]["p90_ms"]],
-                    "frac_of_measured_copy_ceiling": round(achieved / HBM_MEASURED_COPY_GBS, 4)}
-        if dom == "equalize_fused_kernel":
-            min_hbm = (2 * ysz + uv_bytes) * B
-            roofline["min_hbm_bytes_per_launch"] = min_hbm
-            roofline["hbm_GBs_at_min_traffic"] = round(min_hbm / (kinfo[dom]["avg_ms"] * 1e-3) / 1e9, 1)
+                    "launch_ms_p10_p50_p90": [kinfo[dom]["p10_ms"], kinfo[dom]["p50_ms"], kinfo[dom]["p90_ms"]]}
+        # the same launch priced on the bytes that MOVE: the fused kernel reads Y once (2*W*H + UV per frame), every other
+        # kernel moves its algorithmic bytes.  frac_moved_bytes is against the 8 TB/s peak, and the second figure against the
+        # 6.29 TB/s a plain copy kernel reaches on this chip (MI355X_MICROARCH.md).
+        moved = (2 * ysz + uv_bytes) * B if dom == "equalize_fused_kernel" else alg_bytes
+        moved_GBs = moved / (kinfo[dom]["avg_ms"] * 1e-3) / 1e9
+        roofline["moved_bytes_per_launch"] = moved
+        roofline["moved_GBs"] = round(moved_GBs, 1)
+        roofline["frac_moved_bytes"] = round(moved_GBs / HBM_PEAK_GBS, 4)
+        roofline["frac_moved_bytes_of_measured_copy_ceiling"] = round(moved_GBs / HBM_MEASURED_COPY_GBS, 4)
 
     out = {
         "metric": "frames/sec, 3840x2160 NV12 Y equalizeHist" if (args.op == "equalize" and (w, h) == (3840, 2160))
@@ -290,6 +325,8 @@ def main():
                    "frames_per_gpu_per_step": B, "width": w, "height": h, "uv": args.uv, "op": args.op,
                    "sharding": f"frame k -> GPU k mod {world}, no collective"},
         "parity_spot_check": parity,
+        "fused_fallbacks_in_run": fused_fallbacks,
+        "dist_backend_used": backend_used, "world_seen_by_backend": world_seen,
         "whole_path_alg_GBs": round((3 * ysz + uv_bytes) * fps / 1e9, 1),
         "roofline": roofline,
         "kernels": kinfo,
@@ -312,6 +349,32 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stream_config4(w, h):
+    """BASELINE.json configs[3] on this GPU: 512 WxH NV12 frames released at 60 fps through ONE worker of the C++ frame pool
+    (host frame in -> host frame out, PCIe inclusive; opencv-opencl_amd/cxx/examples/nv12_stream.cpp, the reference's worker
+    pipeline OpenCVequalHist.cpp:102-196 minus the codecs), plus the same pipeline unpaced.  Never the headline value."""
+    import re
+    import subprocess
+    exe = ROOT / "opencv-opencl_amd" / "lib" / "nv12_stream"
+    if not exe.exists():
+        return {"error": "nv12_stream not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    base = [str(exe), "--width", str(w), "--height", str(h), "--workers", "1", "--op", "equalize", "--uv", "fill128"]
+    r = subprocess.run(base + ["--frames", "512", "--paced", "--fps", "60"], capture_output=True, text=True, timeout=180)
+    res = {"frames": 512, "fps": 60, "workers": 1, "returncode": r.returncode,
+           "what": "host NV12 frame in -> host NV12 frame out (PCIe inclusive), one pool worker driving an mi_pipe, registered frame ring"}
+    m = re.search(r"p50=([0-9.]+) p90=([0-9.]+) p99=([0-9.]+) max=([0-9.]+); frames over the [0-9.]+ ms frame budget: (\d+)", r.stdout)
+    if m:
+        res.update(p50_ms=float(m.group(1)), p90_ms=float(m.group(2)), p99_ms=float(m.group(3)), max_ms=float(m.group(4)), late=int(m.group(5)))
+    m = re.search(r"errors=(\d+)", r.stdout)
+    if m:
+        res["errors"] = int(m.group(1))
+    u = subprocess.run(base + ["--frames", "2000"], capture_output=True, text=True, timeout=180)
+    m = re.search(r"= ([0-9.]+) frames/s", u.stdout)
+    if m:
+        res["unpaced_frames_per_s"] = float(m.group(1))
+    return res
 
 
 def extras(ctx, args, torch, mi_lumaeq, synth):
@@ -399,6 +462,11 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
             del dd_in, dd_out
         res["equalize_frames_per_s_by_distribution"] = by_dist
         del hd_in, hd_out
+    if (w, h) == (3840, 2160) and args.op == "equalize":
+        try:
+            res["stream_4k60_512"] = stream_config4(w, h)
+        except Exception as e:                                   # a secondary figure never costs the line
+            res["stream_4k60_512"] = {"error": repr(e)}
     frame = synth.nv12_batch_torch(w, h, 1, args.dist, "cuda", seed=99)
     outb = torch.empty_like(frame)
     stream = torch.cuda.current_stream().cuda_stream

@@ -41,8 +41,10 @@ mi_status launch_tile_luts(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const C
     if (tiles > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "more than 65535 tiles per frame");
     // one workgroup per tile: the LUT is computed where the histogram was built, no partials, no second launch
     uint8_t* direct = S == 1 ? d_luts_out : nullptr;
+    // XCD-aware tile order only where the round-robin placement is predictable: one workgroup per tile, tile count a multiple of 8
+    const int xcd_map = (c->clahe_xcd_map && S == 1 && tiles % 8 == 0) ? 1 : 0;
     LAUNCH(c, s, MI_K_TILE_HIST, tile_hist_kernel, dim3(S, tiles, nf), dim3(kThreads), 0,
-           src, (long long)a.src_step, (long long)a.src_frame, g, c->d_partial, direct);
+           src, (long long)a.src_step, (long long)a.src_frame, g, c->d_partial, direct, xcd_map);
     if (!direct)
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut_kernel, dim3(tiles, nf), dim3(kThreads), 0,
                (const uint32_t*)c->d_partial, S, g, d_luts_out);

@@ -16,22 +16,27 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
     const float lut_scale16 = 65535.0f / (float)(int)area;
     int clip16 = 0;
     if (clip_limit > 0.0) { clip16 = (int)(clip_limit * (int)area / 65536); clip16 = std::max(clip16, 1); }
-    // scratch per frame: tile histograms (u32) + ushort LUTs; frames are processed in chunks that keep it <= ~256 MiB
-    // (the value-major copy of the LUTs reuses the histogram area, which is dead once the LUTs exist)
-    const size_t per_frame = (size_t)tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t));
+    // scratch per frame: tile histograms (u32) + ushort LUTs + the tiles' populated ranges + the frame's range; frames are
+    // processed in chunks that keep it <= ~256 MiB (the value-major copy of the LUTs reuses the histogram area, which is
+    // dead once the LUTs exist).  Only the bins a frame populates are ever written or read (kernels/clahe16.hip.h).
+    const size_t per_frame = (size_t)tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t)) + ((size_t)tiles + 1) * sizeof(Range16);
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)256 << 20) / per_frame));
     st = grow_dev(c, &c->d_c16, &c->c16_bytes, per_frame * (size_t)chunk);
     if (st) return st;
     // vector path of the tile histogram: no REFLECT_101 padding, 8-pixel groups inside one tile, 16-B aligned rows
     const int vec = width % tiles_x == 0 && height % tiles_y == 0 && g.tile_w % 8 == 0 &&
                     (((uintptr_t)src | src_step | src_frame) & 15) == 0;
+    const int npairs = tiles_x + 1, bands = tiles_y + 1;
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
         uint32_t* hist = reinterpret_cast<uint32_t*>(c->d_c16);
         uint16_t* luts = reinterpret_cast<uint16_t*>(c->d_c16 + (size_t)nf * tiles * kHist16 * sizeof(uint32_t));
+        Range16* ranges = reinterpret_cast<Range16*>(c->d_c16 + (size_t)nf * tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t)));
+        Range16* franges = ranges + (size_t)nf * tiles;
         LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
-               src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, vec);
-        LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, g, lut_scale16, clip16, luts);
+               src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, vec);
+        LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, (const Range16*)ranges, g,
+               lut_scale16, clip16, luts, franges);
         if (tiles <= 64 && c->clahe16_transposed) {
             // value-major LUTs (one cache line per pixel value): transposed into the histogram area, which is dead by now
             uint16_t* lutT = reinterpret_cast<uint16_t*>(hist);
@@ -41,9 +46,15 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
                    dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)lutT);
         } else {
-            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
+            // one workgroup per (tile pair, band, sub-band); enough sub-bands to fill the chip, never less than ~16 rows each
+            long long want = ((long long)c->cu_count * 4 + (long long)npairs * bands * nf - 1) / ((long long)npairs * bands * nf);
+            const int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 16), 16LL}));
+            if ((long long)npairs * bands * subs > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "16-bit CLAHE: tile grid too large");
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel, dim3((unsigned)(npairs * bands * subs), nf), dim3(kInterp16Threads),
+                   (size_t)kInterp16Entries * sizeof(uint2),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
-                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts);
+                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts,
+                   (const Range16*)franges, subs);
         }
     }
     return MI_OK;

@@ -67,15 +67,22 @@ __device__ __forceinline__ uint8_t tile_lut_value(uint32_t c, const ClaheGeom& g
 // ---------------------------------------------------------------------------------------------
 // With one workgroup per tile (gridDim.x == 1, the batch case) the finished histogram never leaves the CU: the LUT is
 // computed in place and written to `luts` (K5 folded in, no partials round trip, one launch fewer).
+// XCD-aware order (xcd_map, speed only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and with the
+// plain order the horizontally adjacent tiles of an 8-wide grid land on 8 different XCDs -- every 128-byte line cut by a tile edge
+// (tile rows are 480 bytes at 4K 8x8) is then fetched from HBM twice.  With the map, dispatch slot i of a frame works on tile
+// (i % 8) * (tiles / 8) + i / 8: each XCD owns a contiguous row-major run of tiles and walks it in order, so both halves of a cut
+// line are requested through the same L2 within microseconds of each other.
 __global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                            ClaheGeom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ luts)
+                                                            ClaheGeom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ luts, int xcd_map)
 {
     __shared__ uint32_t h[256 * kCopies];
     __shared__ uint32_t s_wave[4];
     lds_hist_zero(h);
     const int t = threadIdx.x;
     const uint32_t copy = t & (kCopies - 1);
-    const int S = gridDim.x, s = blockIdx.x, tile = blockIdx.y, f = blockIdx.z;
+    const int S = gridDim.x, s = blockIdx.x, f = blockIdx.z;
+    const int ntiles = gridDim.y;
+    const int tile = xcd_map ? ((int)(blockIdx.y & 7) * (ntiles >> 3) + (int)(blockIdx.y >> 3)) : (int)blockIdx.y;
     const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const uint8_t* src = src_base + (long long)f * frame_stride;
     const int r0 = (int)((long long)g.tile_h * s / S), r1 = (int)((long long)g.tile_h * (s + 1) / S);

@@ -7,34 +7,48 @@
 namespace mi {
 // =============================================================================================
 // CLAHE on CV_16UC1 (clahe.cpp CLAHE_CalcLut_Body<ushort,65536,0> / CLAHE_Interpolation_Body<ushort,0>).
-// Not on the reference's path (OpenCV surface beyond it).  65 536 u32 bins do not fit LDS but half of them do, so a
-// tile's histogram is built in two LDS passes by one workgroup; the clip / redistribute / scan walks the bins in
-// coalesced chunks of 1024; the interpolation gathers its four ushort LUT entries from L2.
+// Not on the reference's path (OpenCV surface beyond it).  Everything is RANGE-ADAPTIVE: 16-bit video carries 10 or 12 bits,
+// so the three kernels only ever touch the bins a frame populates.
+//   tile_hist16   one workgroup per tile; ONE pass builds the histogram of values < 32768 in 128 KiB of LDS and tracks the
+//                 tile's min / max; a second pass runs only if the tile holds values >= 32768.  Only bins [lo, hi] are stored,
+//                 with the tile's range next to them (unwritten bins are never read by anyone).
+//   tile_lut16    frame range = union of its tiles' ranges; the clip excess is summed over the tile's own bins; the scan walks
+//                 [frame lo, frame hi] only, starting from the closed-form prefix of the empty bins below it (they still
+//                 receive `batch` and their share of the residual increments, exactly as the sequential loops would give them).
+//   clahe_interp16  one workgroup per (tile pair, band, sub-band): stages {LUT[ty1][tx1][v], [ty1][tx2][v], [ty2][tx1][v],
+//                 [ty2][tx2][v]} for v in the frame range as ONE 8-byte LDS entry when the range fits (<= kInterp16Entries
+//                 values: every 12- and 13-bit source), so a pixel costs one ds_read_b64 instead of four L2 gathers; frames
+//                 with a wider range gather from the LUTs in L2 as before (same kernel, uniform branch per frame).
 // =============================================================================================
 constexpr int kHist16 = 65536;
-
-// grid = (tiles, frames), 1024 threads, one workgroup per tile.  65 536 u32 counters do not fit LDS, half of them do:
-// two passes over the tile (the second one is served by L2), each histogramming one half of the value range in
-// 128 KiB of LDS and storing it -- no global atomics, no zeroing of the output.  steps in BYTES.
 constexpr int kHalf16 = 32768;
-__device__ __forceinline__ void hist16_add_dword(uint32_t* h16, uint32_t w, int half)
+constexpr int kInterp16Entries = 8192;               // LDS pair-table entries (64 KiB): two workgroups of 512 threads per CU
+constexpr int kInterp16Threads = 512;
+
+struct Range16 { uint32_t lo, hi; };                 // populated value range of a tile (lo > hi: empty -- cannot happen, a tile has pixels)
+
+__device__ __forceinline__ void hist16_add_dword(uint32_t* h16, uint32_t w, int half, uint32_t& lmin, uint32_t& lmax)
 {
     const uint32_t a = w & 0xffffu, b = w >> 16;
+    lmin = min(lmin, min(a, b)); lmax = max(lmax, max(a, b));
     if ((int)(a >> 15) == half) lds_inc(h16, a & (kHalf16 - 1));
     if ((int)(b >> 15) == half) lds_inc(h16, b & (kHalf16 - 1));
 }
 
+// grid = (tiles, frames), 1024 threads, 128 KiB dynamic LDS.  steps in BYTES.
 // `vec` (host: no REFLECT_101 padding, tile_w % 8 == 0, 16-B aligned rows): a lane takes 8 pixels per 16-byte load with
 // four loads in flight; otherwise one pixel per lane per step with index reflection.
 __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                          ClaheGeom g, uint32_t* __restrict__ hist, int vec)
+                                                          ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
 {
     extern __shared__ uint32_t h16[];                            // [32768]
+    __shared__ uint32_t s_lo, s_hi;
     const int t = threadIdx.x;
     const int tile = blockIdx.x, f = blockIdx.y;
     const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const uint8_t* src = src_base + (long long)f * frame_stride;
-    uint32_t* out = hist + ((size_t)f * gridDim.x + tile) * kHist16;
+    const size_t tile_id = (size_t)f * gridDim.x + tile;
+    uint32_t* out = hist + tile_id * kHist16;
     const long long items = (long long)g.tile_h * g.tile_w;
     const int drow = 1024 / g.tile_w, dcol = 1024 - drow * g.tile_w;
     const int slots = g.tile_w >> 3;                              // 8-pixel groups per tile row (vector path)
@@ -44,10 +58,13 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
         const int row = it / slots, slot = it - row * slots;
         return *reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
     };
+    uint32_t lmin = 0xffffu, lmax = 0;
     auto vadd = [&](const u32x4& q, int half) {
-        hist16_add_dword(h16, q.x, half); hist16_add_dword(h16, q.y, half);
-        hist16_add_dword(h16, q.z, half); hist16_add_dword(h16, q.w, half);
+        hist16_add_dword(h16, q.x, half, lmin, lmax); hist16_add_dword(h16, q.y, half, lmin, lmax);
+        hist16_add_dword(h16, q.z, half, lmin, lmax); hist16_add_dword(h16, q.w, half, lmin, lmax);
     };
+    if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
+    uint32_t lo = 0, hi = 0;
     for (int half = 0; half < 2; ++half) {
         for (int i = t; i < kHalf16; i += 1024) h16[i] = 0;
         __syncthreads();
@@ -64,26 +81,44 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
                 const int y = reflect101(ty * g.tile_h + row, g.height);
                 const int x = reflect101(tx * g.tile_w + col, g.width);
                 const uint32_t v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
+                lmin = min(lmin, v); lmax = max(lmax, v);
                 if ((int)(v >> 15) == half) lds_inc(h16, v & (kHalf16 - 1));
                 row += drow; col += dcol;
                 if (col >= g.tile_w) { col -= g.tile_w; ++row; }
             }
         }
+        if (half == 0) {                                          // the tile's range is known after the first sweep
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64)); }
+            if ((t & 63) == 0) {
+                __hip_atomic_fetch_min(&s_lo, lmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&s_hi, lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         __syncthreads();
-        for (int i = t; i < kHalf16; i += 1024) out[half * kHalf16 + i] = h16[i];
+        lo = s_lo; hi = s_hi;
+        // store the populated bins of this half only: [max(lo, base), min(hi, base + 32767)]
+        const uint32_t base = (uint32_t)half * kHalf16;
+        const uint32_t b0 = max(lo, base), b1 = min(hi, base + kHalf16 - 1);
+        if (b0 <= b1)
+            for (uint32_t i = (b0 & ~3u) + (uint32_t)t; i <= b1; i += 1024) out[i] = h16[i & (kHalf16 - 1)];   // from a 4-aligned start: the LUT kernel loads 16 B
+        if (hi < kHalf16) break;                                  // nothing in the upper half: one pass was the whole job
         __syncthreads();
     }
+    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi; ranges[tile_id] = r; }
 }
 
-// grid = (tiles, frames), 1024 threads.  The 65 536 bins are walked in 16 chunks of 4096, four consecutive bins per
-// thread (one 16-byte load, one 8-byte store): a first sweep sums the clipped excess, a second applies clip +
-// redistribute and scans (serial over a thread's four bins, block scan of the four-bin sums, running offset per chunk).
-__global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, ClaheGeom g, float lut_scale16, int clip16,
-                                                         uint16_t* __restrict__ luts)
+// grid = (tiles, frames), 1024 threads.  Bins are walked in chunks of 4096, four consecutive bins per thread (one 16-byte load,
+// one 8-byte store), over [frame lo & ~3, frame hi] only.  Semantics of clahe.cpp for histSize 65536: clip at clip16, excess / 65536
+// added to every bin, the residual spread with stride max(65536 / residual, 1); then the prefix sum scaled by lut_scale16.
+__global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, const Range16* __restrict__ ranges, ClaheGeom g,
+                                                         float lut_scale16, int clip16, uint16_t* __restrict__ luts, Range16* __restrict__ frame_ranges)
 {
     __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_flo, s_fhi;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const size_t tile_id = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int tiles = gridDim.x;
+    const size_t tile_id = (size_t)blockIdx.y * tiles + blockIdx.x;
     const uint32_t* h = hist + tile_id * kHist16;
     uint16_t* lut = luts + tile_id * kHist16;
     auto block_scan = [&](uint32_t v, uint32_t& total) -> uint32_t {     // inclusive prefix of v over the 1024 threads
@@ -98,12 +133,35 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
         total = tot;
         return off + incl;
     };
+    // frame range: union of the tiles' ranges (every workgroup of the frame computes the same two numbers)
+    if (t == 0) { s_flo = 0xffffu; s_fhi = 0; }
+    __syncthreads();
+    {
+        uint32_t l = 0xffffu, u = 0;
+        const Range16* fr = ranges + (size_t)blockIdx.y * tiles;
+        for (int i = t; i < tiles; i += 1024) { const Range16 r = fr[i]; l = min(l, r.lo); u = max(u, r.hi); }
+        if (t < tiles) {
+            __hip_atomic_fetch_min(&s_flo, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&s_fhi, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    const uint32_t flo = s_flo, fhi = s_fhi;
+    const Range16 own = ranges[tile_id];
+    if (blockIdx.x == 0 && t == 0) { Range16 r; r.lo = flo; r.hi = fhi; frame_ranges[blockIdx.y] = r; }
+    auto load4 = [&](uint32_t b0, int* v) {                       // bins b0..b0+3 of this tile, zero outside its stored range
+        if (b0 + 3 < own.lo || b0 > own.hi) { v[0] = v[1] = v[2] = v[3] = 0; return; }
+        const u32x4 q = *reinterpret_cast<const u32x4*>(h + b0);
+        const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (b0 + k >= own.lo && b0 + k <= own.hi) ? (int)x[k] : 0;
+    };
     int batch = 0, residual = 0, rstep = 1;
     if (clip16 > 0) {
         uint32_t excess = 0;
-        for (int c = 0; c < 16; ++c) {
-            const u32x4 q = *reinterpret_cast<const u32x4*>(h + c * 4096 + t * 4);
-            const int v[4] = {(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+        for (uint32_t b0 = (own.lo & ~3u) + (uint32_t)t * 4; b0 <= own.hi; b0 += 4096) {
+            int v[4];
+            load4(b0, v);
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (v[k] > clip16) excess += (uint32_t)(v[k] - clip16);
         }
@@ -113,62 +171,166 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
         residual = (int)clipped - batch * kHist16;
         if (residual != 0) { rstep = kHist16 / residual; if (rstep < 1) rstep = 1; }
     }
+    // prefix of the bins below the scan start: empty bins hold `batch`, plus 1 where b % rstep == 0 and b / rstep < residual
+    const uint32_t start = flo & ~3u;
     uint32_t running = 0;
-    for (int c = 0; c < 16; ++c) {
-        const int b0 = c * 4096 + t * 4;
-        const u32x4 q = *reinterpret_cast<const u32x4*>(h + b0);
-        int v[4] = {(int)q.x, (int)q.y, (int)q.z, (int)q.w};
+    if (clip16 > 0) {
+        const uint32_t ninc = residual == 0 ? 0u : min((uint32_t)residual, (start + (uint32_t)rstep - 1) / (uint32_t)rstep);
+        running = (uint32_t)batch * start + ninc;
+    }
+    for (uint32_t c0 = start; c0 <= fhi; c0 += 4096) {
+        const uint32_t b0 = c0 + (uint32_t)t * 4;
+        const bool active = b0 <= fhi;
+        int v[4] = {0, 0, 0, 0};
         uint32_t local = 0;
+        if (active) {
+            load4(b0, v);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (clip16 > 0) {
-                if (v[k] > clip16) v[k] = clip16;
-                v[k] += batch;
-                const int b = b0 + k;
-                if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++v[k];
+            for (int k = 0; k < 4; ++k) {
+                if (clip16 > 0) {
+                    if (v[k] > clip16) v[k] = clip16;
+                    v[k] += batch;
+                    const int b = (int)b0 + k;
+                    if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++v[k];
+                }
+                local += (uint32_t)v[k];
+                v[k] = (int)local;                                   // inclusive prefix within the thread's four bins
             }
-            local += (uint32_t)v[k];
-            v[k] = (int)local;                                       // inclusive prefix within the thread's four bins
         }
         uint32_t total;
         const uint32_t before = running + block_scan(local, total) - local;     // everything before this thread's first bin
         running += total;
-        uint32_t packed[2];
+        if (active) {
+            uint32_t packed[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int r = __float2int_rn(__fmul_rn((float)(int)(before + (uint32_t)v[k]), lut_scale16));
-            r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
-            if (k & 1) packed[k >> 1] |= (uint32_t)r << 16; else packed[k >> 1] = (uint32_t)r;
+            for (int k = 0; k < 4; ++k) {
+                int r = __float2int_rn(__fmul_rn((float)(int)(before + (uint32_t)v[k]), lut_scale16));
+                r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
+                if (k & 1) packed[k >> 1] |= (uint32_t)r << 16; else packed[k >> 1] = (uint32_t)r;
+            }
+            *reinterpret_cast<uint2*>(lut + b0) = make_uint2(packed[0], packed[1]);
         }
-        *reinterpret_cast<uint2*>(lut + b0) = make_uint2(packed[0], packed[1]);
     }
 }
 
-// grid = (ceil(W/256), H, frames): one pixel per lane, four ushort gathers from the per-tile LUTs (L2).  Bound by the
-// divergent gathers themselves (up to 64 cache lines per wave instruction): giving each XCD one eighth of the rows, so
-// that its L2 only has to hold two tile rows of LUTs, measured 4 % SLOWER.
-__global__ __launch_bounds__(kThreads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
-                                                                 uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
-                                                                 ClaheGeom g, const uint16_t* __restrict__ luts)
+// grid = (pairs * bands * subs, frames), 512 threads, 64 KiB dynamic LDS.  A workgroup owns the pixels whose horizontal tile pair
+// is p (unclamped tx1 = p - 1) and whose unclamped ty1 is band - 1, so its four LUTs are fixed; a lane owns one 8-pixel group (16 B)
+// of fixed columns -- column weights and ownership are lane constants -- and walks down the band's rows.  Ownership is decided by
+// the reference's own float expressions on ranges widened by a few pixels, so a pair / band edge can never be mis-assigned;
+// an 8-pixel group cut by a pair edge is visited by both neighbours, each storing only its own pixels.
+__global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
+                                                                         uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
+                                                                         ClaheGeom g, const uint16_t* __restrict__ luts,
+                                                                         const Range16* __restrict__ frame_ranges, int subs)
 {
-    const int f = blockIdx.z, y = blockIdx.y;
-    const int x = blockIdx.x * kThreads + threadIdx.x;
-    if (x >= g.width) return;
+    extern __shared__ __attribute__((aligned(16))) uint2 tab[];      // [kInterp16Entries] {a | b << 16, c | d << 16}
+    const int t = threadIdx.x, f = blockIdx.y;
+    const int npairs = g.tiles_x + 1;
+    int id = blockIdx.x;
+    const int sub = id % subs; id /= subs;
+    const int pr = id % npairs, band = id / npairs;
+    const int ty1u = band - 1;
+    const int ty1 = max(ty1u, 0), ty2 = min(ty1u + 1, g.tiles_y - 1);
+    const int tx1 = max(pr - 1, 0), tx2 = min(pr, g.tiles_x - 1);
     const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
-    const float txf = tile_coord(x, g.inv_tw, g.contract);
-    int tx1 = floor_f32_to_int(txf);
-    const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
-    int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
-    const float tyf = tile_coord(y, g.inv_th, g.contract);
-    int ty1 = floor_f32_to_int(tyf);
-    const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
-    int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
-    const uint32_t v = *reinterpret_cast<const uint16_t*>(src_base + (long long)f * src_frame + (long long)y * src_step + 2 * (long long)x);
-    const float a = (float)lf[((size_t)ty1 * g.tiles_x + tx1) * kHist16 + v], b = (float)lf[((size_t)ty1 * g.tiles_x + tx2) * kHist16 + v];
-    const float c = (float)lf[((size_t)ty2 * g.tiles_x + tx1) * kHist16 + v], d = (float)lf[((size_t)ty2 * g.tiles_x + tx2) * kHist16 + v];
-    int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa, xa1, ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa, xa1, ya, ya1));
-    r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
-    *reinterpret_cast<uint16_t*>(dst_base + (long long)f * dst_frame + (long long)y * dst_step + 2 * (long long)x) = (uint16_t)r;
+    const uint16_t* la = lf + ((size_t)ty1 * g.tiles_x + tx1) * kHist16;
+    const uint16_t* lb = lf + ((size_t)ty1 * g.tiles_x + tx2) * kHist16;
+    const uint16_t* lc = lf + ((size_t)ty2 * g.tiles_x + tx1) * kHist16;
+    const uint16_t* ld = lf + ((size_t)ty2 * g.tiles_x + tx2) * kHist16;
+    const Range16 fr = frame_ranges[f];
+    const uint32_t start = fr.lo & ~3u;
+    const bool in_lds = fr.hi - start < (uint32_t)kInterp16Entries;
+    if (in_lds) {
+        const uint32_t n4 = (fr.hi - start) / 4 + 1;                 // groups of four consecutive values
+        for (uint32_t i = t; i < n4; i += kInterp16Threads) {
+            const uint32_t v = start + 4 * i;
+            const uint2 qa = *reinterpret_cast<const uint2*>(la + v), qb = *reinterpret_cast<const uint2*>(lb + v);
+            const uint2 qc = *reinterpret_cast<const uint2*>(lc + v), qd = *reinterpret_cast<const uint2*>(ld + v);
+            uint2 e0, e1, e2, e3;
+            e0.x = (qa.x & 0xffffu) | (qb.x << 16);        e0.y = (qc.x & 0xffffu) | (qd.x << 16);
+            e1.x = (qa.x >> 16) | (qb.x & 0xffff0000u);    e1.y = (qc.x >> 16) | (qd.x & 0xffff0000u);
+            e2.x = (qa.y & 0xffffu) | (qb.y << 16);        e2.y = (qc.y & 0xffffu) | (qd.y << 16);
+            e3.x = (qa.y >> 16) | (qb.y & 0xffff0000u);    e3.y = (qc.y >> 16) | (qd.y & 0xffff0000u);
+            tab[4 * i] = e0; tab[4 * i + 1] = e1; tab[4 * i + 2] = e2; tab[4 * i + 3] = e3;
+        }
+    }
+    __syncthreads();
+
+    // rows of the band (as clahe_interp_kernel): ideal range widened, then trimmed with the float expression
+    const int y_lo_band = (int)max(0LL, ((long long)(2 * band - 1) * g.tile_h) / 2 - kBandMargin);
+    const int y_hi_band = (int)min((long long)g.height, ((long long)(2 * band + 1) * g.tile_h + 1) / 2 + kBandMargin);
+    const int nrows = max(0, y_hi_band - y_lo_band);
+    int y_lo = y_lo_band + (int)((long long)nrows * sub / subs);
+    int y_hi = y_lo_band + (int)((long long)nrows * (sub + 1) / subs);
+    auto ty1_of = [&](int y) { return floor_f32_to_int(tile_coord(y, g.inv_th, g.contract)); };
+    while (y_lo < y_hi && ty1_of(y_lo) != ty1u) ++y_lo;
+    while (y_hi > y_lo && ty1_of(y_hi - 1) != ty1u) --y_hi;
+    // columns of the pair, in 8-pixel groups
+    const int x_lo = (int)max(0LL, ((long long)(2 * pr - 1) * g.tile_w) / 2 - kBandMargin);
+    const int x_hi = (int)min((long long)g.width, ((long long)(2 * pr + 1) * g.tile_w + 1) / 2 + kBandMargin);
+    if (x_lo >= x_hi || y_lo >= y_hi) return;
+    const int g_lo = x_lo >> 3, ngroups = ((x_hi + 7) >> 3) - g_lo;
+    const int phases = max(1, kInterp16Threads / ngroups);
+    const int passes = (ngroups + kInterp16Threads - 1) / kInterp16Threads;          // > 1 only for tiles wider than 4096 pixels
+    const uint8_t* src = src_base + (long long)f * src_frame;
+    uint8_t* dst = dst_base + (long long)f * dst_frame;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int gi = pass * kInterp16Threads + (passes > 1 ? t : t % ngroups);
+        const int phase = passes > 1 ? 0 : t / ngroups;
+        if (gi >= ngroups || phase >= phases) continue;
+        const int x0 = (g_lo + gi) << 3;
+        float xa[8], xa1[8];
+        uint32_t own = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float txf = tile_coord(x0 + j, g.inv_tw, g.contract);
+            const int txu = floor_f32_to_int(txf);
+            xa[j] = __fsub_rn(txf, (float)txu);
+            xa1[j] = __fsub_rn(1.0f, xa[j]);
+            int q = txu + 1; q = q < 0 ? 0 : (q > g.tiles_x ? g.tiles_x : q);
+            if (q == pr && x0 + j < g.width) own |= 1u << j;
+        }
+        if (!own) continue;
+        const bool vec_ok = own == 0xffu && ((((uintptr_t)src | (uintptr_t)dst | (unsigned long long)src_step | (unsigned long long)dst_step) & 15) == 0);
+        for (int y = y_lo + phase; y < y_hi; y += phases) {
+            const float tyf = tile_coord(y, g.inv_th, g.contract);
+            const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
+            const uint8_t* sp = src + (long long)y * src_step + 2 * (long long)x0;
+            uint8_t* dp = dst + (long long)y * dst_step + 2 * (long long)x0;
+            uint32_t px[8];
+            if (vec_ok) {
+                const u32x4 q = *reinterpret_cast<const u32x4*>(sp);
+                px[0] = q.x & 0xffffu; px[1] = q.x >> 16; px[2] = q.y & 0xffffu; px[3] = q.y >> 16;
+                px[4] = q.z & 0xffffu; px[5] = q.z >> 16; px[6] = q.w & 0xffffu; px[7] = q.w >> 16;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) px[j] = (own >> j) & 1u ? *reinterpret_cast<const uint16_t*>(sp + 2 * j) : 0u;
+            }
+            uint32_t res[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a, b, c, d;
+                if (in_lds) {
+                    // values outside the frame range cannot occur for owned pixels; masked lanes may carry anything: clamp the index
+                    const uint32_t idx = min(px[j] - start, (uint32_t)kInterp16Entries - 1);
+                    const uint2 e = tab[idx];
+                    a = (float)(e.x & 0xffffu); b = (float)(e.x >> 16); c = (float)(e.y & 0xffffu); d = (float)(e.y >> 16);
+                } else {
+                    a = (float)la[px[j]]; b = (float)lb[px[j]]; c = (float)lc[px[j]]; d = (float)ld[px[j]];
+                }
+                int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa[j], xa1[j], ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa[j], xa1[j], ya, ya1));
+                res[j] = (uint32_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+            }
+            if (vec_ok) {
+                u32x4 o;
+                o.x = res[0] | (res[1] << 16); o.y = res[2] | (res[3] << 16); o.z = res[4] | (res[5] << 16); o.w = res[6] | (res[7] << 16);
+                *reinterpret_cast<u32x4*>(dp) = o;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if ((own >> j) & 1u) *reinterpret_cast<uint16_t*>(dp + 2 * j) = (uint16_t)res[j];
+            }
+        }
+    }
 }
 
 // ---- value-major LUT layout for the interpolation ---------------------------------------------------------------

@@ -676,6 +676,37 @@ def test_clahe16(ctx, shape, cfg):
         assert np.array_equal(ctx.clahe16(s, clip, tx, ty), oracle.clahe16(s, clip, tx, ty)), kind
 
 
+@pytest.mark.parametrize("cfg", [(2.0, 8, 8), (40.0, 3, 5), (0.0, 4, 4)], ids=str)
+def test_clahe16_value_ranges(ctx, cfg):
+    """The 16-bit kernels only touch the bins a frame populates: ranges below / above / across 32768 (one or two histogram
+    passes), ranges that fit the LDS pair table and ranges that do not (8192 values is the edge), MSB-aligned 10-bit video
+    (sparse values over the whole 16-bit range), shapes that need REFLECT_101 padding, and a batch whose frames differ."""
+    clip, tx, ty = cfg
+    rng = np.random.default_rng(int(clip) + tx)
+    h, w = 272, 480
+    ranges = [(0, 4096), (100, 101), (30000, 34000), (32768, 36864), (61000, 65536), (5000, 5000 + 8192), (5001, 5001 + 8193),
+              (3, 3 + 8191), (0, 65536), (20000, 45000)]
+    frames = [rng.integers(lo, hi, (h, w), dtype=np.uint16) for lo, hi in ranges]
+    frames.append((rng.integers(0, 1024, (h, w), dtype=np.uint16) << 6).astype(np.uint16))         # P010-style MSB-aligned samples
+    for k, s in enumerate(frames):
+        assert np.array_equal(ctx.clahe16(s, clip, tx, ty), oracle.clahe16(s, clip, tx, ty)), (cfg, k)
+    odd = rng.integers(700, 3000, (271, 479), dtype=np.uint16)                                        # padded tiles, unaligned rows
+    assert np.array_equal(ctx.clahe16(odd, clip, tx, ty), oracle.clahe16(odd, clip, tx, ty))
+    batch = np.stack(frames)
+    d_in = torch.from_numpy(batch.view(np.int16)).to("cuda:0")
+    d_out = torch.empty_like(d_in)
+    ctx.clahe16_batch_dev(d_in, d_out, w, h, len(frames), clip, tx, ty)
+    ctx.synchronize()
+    out = d_out.cpu().numpy().view(np.uint16)
+    for k, s in enumerate(frames):
+        assert np.array_equal(out[k], oracle.clahe16(s, clip, tx, ty)), (cfg, "batch", k)
+    # in place
+    d = torch.from_numpy(batch.view(np.int16)).to("cuda:0")
+    ctx.clahe16_batch_dev(d, d, w, h, len(frames), clip, tx, ty)
+    ctx.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint16), out)
+
+
 def test_clahe16_batch_and_errors(ctx):
     w, h, n = 320, 180, 3
     rng = np.random.default_rng(3)

@@ -51,7 +51,8 @@ def main():
         t = json.loads(tfile.read_text()) if tfile.exists() else {}
         match = [k for k in res if k.endswith(kname)]
         if match and res[match[0]]["hbm_bytes_per_launch"] is not None:
-            t[key] = round(res[match[0]]["hbm_bytes_per_launch"])
+            t[key] = {"bytes": round(res[match[0]]["hbm_bytes_per_launch"]),
+                      "source": f"{out} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
             tfile.write_text(json.dumps(t, indent=1))
 
 

@@ -1,15 +1,24 @@
-import sys, torch
+"""16-bit CLAHE: per-kernel HIP-event averages and frames/s by content, 4K 8x8 clip 2.0:  python tools/prof16.py [frames]"""
+import sys, time, torch
 sys.path.insert(0, "opencv-opencl_amd/python"); sys.path.insert(0, ".")
 import mi_lumaeq
 ctx = mi_lumaeq.Context(0)
-w, h, n = 3840, 2160, 4
-for name, s16 in (("uniform15", torch.randint(0, 32768, (n, h, w), dtype=torch.int16, device="cuda")),
-                  ("narrow", torch.randint(1000, 1400, (n, h, w), dtype=torch.int16, device="cuda")),
-                  ("const", torch.full((n, h, w), 777, dtype=torch.int16, device="cuda"))):
+w, h = 3840, 2160
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+def u16(lo, hi): return torch.randint(lo, hi, (n, h, w), dtype=torch.int32, device="cuda").to(torch.int16)   # bit pattern of the ushort
+cases = (("12-bit 0..4095", u16(0, 4096)), ("10-bit 0..1023", u16(0, 1024)), ("narrow 1000..1399", u16(1000, 1400)), ("13-bit 0..8191", u16(0, 8192)),
+         ("15-bit 0..32767", u16(0, 32768)), ("16-bit full", u16(0, 65536)), ("const 777", torch.full((n, h, w), 777, dtype=torch.int16, device="cuda")))
+for name, s16 in cases:
     o16 = torch.empty_like(s16)
-    ctx.clahe16_batch_dev(s16, o16, w, h, n, 2.0, 8, 8); ctx.synchronize()
+    for _ in range(2): ctx.clahe16_batch_dev(s16, o16, w, h, n, 2.0, 8, 8)
+    ctx.synchronize()
     ctx.profile_read(True); ctx.set_profiling(True)
-    for _ in range(3): ctx.clahe16_batch_dev(s16, o16, w, h, n, 2.0, 8, 8)
+    t0 = time.perf_counter()
+    for _ in range(5): ctx.clahe16_batch_dev(s16, o16, w, h, n, 2.0, 8, 8)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / 5
     ctx.set_profiling(False)
     p = ctx.profile_read(True)
-    print(name, {k: round(v["total_ms"] / max(v["launches"], 1), 3) for k, v in p.items() if v["launches"]})
+    print(f"{name:20s} {n / dt:9.0f} frames/s  ({3 * w * h * 2 * n / dt / 1e12:.2f} TB/s of 3*W*H*2 B)  kernels(us):",
+          {k: round(v["total_ms"] / max(v["launches"], 1) * 1e3, 1) for k, v in p.items() if v["launches"]}, flush=True)
+    del s16, o16
