@@ -541,25 +541,23 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     res["nv12_bgr_channels_equalize_frames_per_s"] = round(Bn / (ms * 1e-3), 1)
     res["nv12_bgr_channels_equalize_GBs"] = round(4.5 * w * h * Bn / (ms * 1e-3) / 1e9, 1)
     del nv, nv_out
-    # a real photograph instead of synthetic noise (the reference's own bench image, luma plane tiled to 4K;
-    # tests/golden/make_photo_fixture.py): hot histogram bins, smooth neighbourhoods (LDS broadcasts in the CLAHE gather)
-    photo = Path(__file__).resolve().parent / "tests" / "golden" / "photo_luma_1919x1079.npz"
-    if photo.exists():
-        yp = np.load(photo)["y"]
-        reps = (-(-(h + 13 * 32) // yp.shape[0]), -(-(w + 29 * 32) // yp.shape[1]))
-        big = np.tile(yp, reps)
-        Bp = 32
-        fr = np.empty((Bp, w * h * 3 // 2), np.uint8)
-        for k in range(Bp):                                        # every frame a different window of the tiling
-            fr[k, : w * h] = big[13 * k: 13 * k + h, 29 * k: 29 * k + w].reshape(-1)
-            fr[k, w * h:] = 128
-        d_in = torch.from_numpy(fr).cuda()
-        d_out = torch.empty_like(d_in)
-        ms = timeit(lambda: ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, Bp, mi_lumaeq.UV_FILL128, stream=stream), 20)
-        res["photo_equalize_frames_per_s"] = round(Bp / (ms * 1e-3), 1)
-        ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, Bp, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 10)
-        res["photo_clahe8x8_frames_per_s"] = round(Bp / (ms * 1e-3), 1)
-        del d_in, d_out
+    # a photo-like scene instead of noise (mi_lumaeq.synth.photo_like: piecewise-smooth gradients, flat and saturated regions, tiled
+    # to 4K with a different window per frame): hot histogram bins, smooth neighbourhoods (LDS broadcasts in the CLAHE gather)
+    yp = synth.photo_like(1919, 1079, 20261004)
+    reps = (-(-(h + 13 * 32) // yp.shape[0]), -(-(w + 29 * 32) // yp.shape[1]))
+    big = np.tile(yp, reps)
+    Bp = 32
+    fr = np.empty((Bp, w * h * 3 // 2), np.uint8)
+    for k in range(Bp):                                        # every frame a different window of the tiling
+        fr[k, : w * h] = big[13 * k: 13 * k + h, 29 * k: 29 * k + w].reshape(-1)
+        fr[k, w * h:] = 128
+    d_in = torch.from_numpy(fr).cuda()
+    d_out = torch.empty_like(d_in)
+    ms = timeit(lambda: ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, Bp, mi_lumaeq.UV_FILL128, stream=stream), 20)
+    res["photo_like_equalize_frames_per_s"] = round(Bp / (ms * 1e-3), 1)
+    ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, Bp, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 10)
+    res["photo_like_clahe8x8_frames_per_s"] = round(Bp / (ms * 1e-3), 1)
+    del d_in, d_out
     # equalizeHist on a strided ROI (generic path: row by row, unaligned starts) and 16-bit CLAHE
     Br = 16
     pitch = w + 64
@@ -569,10 +567,13 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     ms = timeit(lambda: ctx.equalize_hist_batch_dev(big.data_ptr() + off, big_out.data_ptr() + off, w, h, Br, src_step=pitch,
                                                     src_frame=(h + 8) * pitch, dst_step=pitch, dst_frame=(h + 8) * pitch, stream=stream), 10)
     res["strided_roi_equalize_frames_per_s"] = round(Br / (ms * 1e-3), 1)
-    s16 = torch.randint(0, 32768, (4, h, w), dtype=torch.int16, device="cuda")
-    o16 = torch.empty_like(s16)
-    ms = timeit(lambda: ctx.clahe16_batch_dev(s16, o16, w, h, 4, 2.0, 8, 8, stream=stream), 5)
-    res["clahe16_8x8_frames_per_s"] = round(4 / (ms * 1e-3), 1)
+    # 12-bit content (what 16-bit video carries: the range fits the LDS pair tables) and full-range 16-bit content (L2 gathers)
+    for name, hi, nb in (("clahe16_8x8_12bit_frames_per_s", 4096, 16), ("clahe16_8x8_fullrange_frames_per_s", 65536, 4)):
+        s16 = torch.randint(0, hi, (nb, h, w), dtype=torch.int32, device="cuda").to(torch.int16)     # bit pattern of the ushort
+        o16 = torch.empty_like(s16)
+        ms = timeit(lambda: ctx.clahe16_batch_dev(s16, o16, w, h, nb, 2.0, 8, 8, stream=stream), 5)
+        res[name] = round(nb / (ms * 1e-3), 1)
+        del s16, o16
     return res
 
 

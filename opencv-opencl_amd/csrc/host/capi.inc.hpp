@@ -37,12 +37,36 @@ int mi_device_count(void)
     return n;
 }
 
+// Once per process: were the kernels built with separately rounded float steps?  (0 = not yet known, 1 = yes, -1 = no)
+static std::atomic<int> g_contract_ok{0};
+static int contract_probe()
+{
+    int v = g_contract_ok.load();
+    if (v != 0) return v;
+    float* d = nullptr;
+    float h = 1.0f;
+    if (hipMalloc((void**)&d, sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const float a = 1.0f + 1.0f / 4096.0f;
+    hipLaunchKernelGGL(contract_probe_kernel, dim3(1), dim3(1), 0, nullptr, a, a, -(1.0f + 1.0f / 2048.0f), d);
+    const bool ran = hipGetLastError() == hipSuccess && hipMemcpy(&h, d, sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ran) { (void)hipGetLastError(); return 0; }
+    v = h == 0.0f ? 1 : -1;
+    g_contract_ok.store(v);
+    return v;
+}
+
 mi_status mi_ctx_create(int device, mi_ctx** out)
 {
     if (!out) return MI_ERR_BAD_ARG;
     *out = nullptr;
     const int n = mi_device_count();
     if (n <= 0 || device < 0 || device >= n) return MI_ERR_NO_DEVICE;
+    if (hipSetDevice(device) == hipSuccess && contract_probe() < 0) {
+        fprintf(stderr, "mi_lumaeq: this library was built without -ffp-contract=off (float multiply-adds are fused): its CLAHE / LUT "
+                        "arithmetic would not be bit-exact; rebuild with opencv-opencl_amd/csrc/Makefile\n");
+        return MI_ERR_UNSUPPORTED;
+    }
     mi_ctx* c = new (std::nothrow) mi_ctx();
     if (!c) return MI_ERR_OOM;
     c->device = device;

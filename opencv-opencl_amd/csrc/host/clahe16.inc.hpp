@@ -17,10 +17,10 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
     int clip16 = 0;
     if (clip_limit > 0.0) { clip16 = (int)(clip_limit * (int)area / 65536); clip16 = std::max(clip16, 1); }
     // scratch per frame: tile histograms (u32) + ushort LUTs + the tiles' populated ranges + the frame's range; frames are
-    // processed in chunks that keep it <= ~256 MiB (the value-major copy of the LUTs reuses the histogram area, which is
+    // processed in chunks that keep it <= ~2 GiB (address space, not traffic: 288 GB of HBM) (the value-major copy of the LUTs reuses the histogram area, which is
     // dead once the LUTs exist).  Only the bins a frame populates are ever written or read (kernels/clahe16.hip.h).
     const size_t per_frame = (size_t)tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t)) + ((size_t)tiles + 1) * sizeof(Range16);
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)256 << 20) / per_frame));
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)2 << 30) / per_frame));
     st = grow_dev(c, &c->d_c16, &c->c16_bytes, per_frame * (size_t)chunk);
     if (st) return st;
     // vector path of the tile histogram: no REFLECT_101 padding, 8-pixel groups inside one tile, 16-B aligned rows
@@ -55,6 +55,11 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
                    dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts,
                    (const Range16*)franges, subs);
+            // frames whose range does not fit the LDS table (their workgroups above returned at once); a no-op otherwise
+            const long long wide_items = (long long)((width + kThreads - 1) / kThreads) * height;
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_wide_kernel, dim3((unsigned)std::min<long long>(wide_items, 2048), 1, nf), dim3(kThreads), 0,
+                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
+                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges);
         }
     }
     return MI_OK;

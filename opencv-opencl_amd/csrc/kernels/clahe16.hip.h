@@ -27,12 +27,41 @@ constexpr int kInterp16Threads = 512;
 
 struct Range16 { uint32_t lo, hi; };                 // populated value range of a tile (lo > hi: empty -- cannot happen, a tile has pixels)
 
+__device__ __forceinline__ void lds_add(uint32_t* h, uint32_t idx, uint32_t n)
+{
+    __hip_atomic_fetch_add(h + idx, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32
+}
+
 __device__ __forceinline__ void hist16_add_dword(uint32_t* h16, uint32_t w, int half, uint32_t& lmin, uint32_t& lmax)
 {
     const uint32_t a = w & 0xffffu, b = w >> 16;
     lmin = min(lmin, min(a, b)); lmax = max(lmax, max(a, b));
+    if (a == b) { if ((int)(a >> 15) == half) lds_add(h16, a & (kHalf16 - 1), 2u); return; }
     if ((int)(a >> 15) == half) lds_inc(h16, a & (kHalf16 - 1));
     if ((int)(b >> 15) == half) lds_inc(h16, b & (kHalf16 - 1));
+}
+
+// Eight pixels of one 16-byte load.  There is no room to replicate 32 768 counters per LDS bank, so equal values meeting in one
+// ds_add serialise; flat image regions (borders, saturated areas) are the bad case and are caught before they reach the LDS:
+// all eight pixels equal -> one add of 8; the same value in every active lane of the wave -> one lane adds for the whole wave.
+__device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, int half, uint32_t& lmin, uint32_t& lmax)
+{
+    const uint32_t v0 = q.x & 0xffffu;
+    const bool flat = q.x == q.y && q.y == q.z && q.z == q.w && v0 == (q.x >> 16);
+    if (__builtin_expect(flat, 0)) {
+        lmin = min(lmin, v0); lmax = max(lmax, v0);
+        const unsigned long long active = __ballot(1);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
+        if (__ballot(v0 == first) == active) {                      // wave-uniform value (only lanes with flat vectors are here)
+            if ((int)(v0 >> 15) == half && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(active))
+                lds_add(h16, v0 & (kHalf16 - 1), 8u * (uint32_t)__builtin_popcountll(active));
+        } else if ((int)(v0 >> 15) == half) {
+            lds_add(h16, v0 & (kHalf16 - 1), 8u);
+        }
+        return;
+    }
+    hist16_add_dword(h16, q.x, half, lmin, lmax); hist16_add_dword(h16, q.y, half, lmin, lmax);
+    hist16_add_dword(h16, q.z, half, lmin, lmax); hist16_add_dword(h16, q.w, half, lmin, lmax);
 }
 
 // grid = (tiles, frames), 1024 threads, 128 KiB dynamic LDS.  steps in BYTES.
@@ -59,10 +88,7 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
         return *reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
     };
     uint32_t lmin = 0xffffu, lmax = 0;
-    auto vadd = [&](const u32x4& q, int half) {
-        hist16_add_dword(h16, q.x, half, lmin, lmax); hist16_add_dword(h16, q.y, half, lmin, lmax);
-        hist16_add_dword(h16, q.z, half, lmin, lmax); hist16_add_dword(h16, q.w, half, lmin, lmax);
-    };
+    auto vadd = [&](const u32x4& q, int half) { hist16_add_vec(h16, q, half, lmin, lmax); };
     if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
     uint32_t lo = 0, hi = 0;
     for (int half = 0; half < 2; ++half) {
@@ -239,8 +265,8 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const uint16_t* ld = lf + ((size_t)ty2 * g.tiles_x + tx2) * kHist16;
     const Range16 fr = frame_ranges[f];
     const uint32_t start = fr.lo & ~3u;
-    const bool in_lds = fr.hi - start < (uint32_t)kInterp16Entries;
-    if (in_lds) {
+    if (fr.hi - start >= (uint32_t)kInterp16Entries) return;         // wide range: clahe_interp16_wide_kernel does this frame
+    {
         const uint32_t n4 = (fr.hi - start) / 4 + 1;                 // groups of four consecutive values
         for (uint32_t i = t; i < n4; i += kInterp16Threads) {
             const uint32_t v = start + 4 * i;
@@ -292,44 +318,90 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
         }
         if (!own) continue;
         const bool vec_ok = own == 0xffu && ((((uintptr_t)src | (uintptr_t)dst | (unsigned long long)src_step | (unsigned long long)dst_step) & 15) == 0);
-        for (int y = y_lo + phase; y < y_hi; y += phases) {
+        auto blend_row = [&](int y, const uint32_t* px, uint32_t* res) {
             const float tyf = tile_coord(y, g.inv_th, g.contract);
             const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
-            const uint8_t* sp = src + (long long)y * src_step + 2 * (long long)x0;
-            uint8_t* dp = dst + (long long)y * dst_step + 2 * (long long)x0;
-            uint32_t px[8];
-            if (vec_ok) {
-                const u32x4 q = *reinterpret_cast<const u32x4*>(sp);
-                px[0] = q.x & 0xffffu; px[1] = q.x >> 16; px[2] = q.y & 0xffffu; px[3] = q.y >> 16;
-                px[4] = q.z & 0xffffu; px[5] = q.z >> 16; px[6] = q.w & 0xffffu; px[7] = q.w >> 16;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) px[j] = (own >> j) & 1u ? *reinterpret_cast<const uint16_t*>(sp + 2 * j) : 0u;
-            }
-            uint32_t res[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float a, b, c, d;
-                if (in_lds) {
-                    // values outside the frame range cannot occur for owned pixels; masked lanes may carry anything: clamp the index
-                    const uint32_t idx = min(px[j] - start, (uint32_t)kInterp16Entries - 1);
-                    const uint2 e = tab[idx];
-                    a = (float)(e.x & 0xffffu); b = (float)(e.x >> 16); c = (float)(e.y & 0xffffu); d = (float)(e.y >> 16);
-                } else {
-                    a = (float)la[px[j]]; b = (float)lb[px[j]]; c = (float)lc[px[j]]; d = (float)ld[px[j]];
-                }
+                // values outside the frame range cannot occur for owned pixels; masked lanes may carry anything: clamp the index
+                const uint32_t idx = min(px[j] - start, (uint32_t)kInterp16Entries - 1);
+                const uint2 e = tab[idx];
+                const float a = (float)(e.x & 0xffffu), b = (float)(e.x >> 16), c = (float)(e.y & 0xffffu), d = (float)(e.y >> 16);
                 int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa[j], xa1[j], ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa[j], xa1[j], ya, ya1));
                 res[j] = (uint32_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
             }
-            if (vec_ok) {
+        };
+        int y = y_lo + phase;
+        if (vec_ok) {
+            // four rows are loaded before the first is blended: 64 B in flight per lane instead of 16 (the kernel runs at two
+            // workgroups per CU, too few waves to hide the HBM latency otherwise)
+            constexpr int kRows = 4;
+            auto do_vec_row = [&](int yy, const u32x4& q) {
+                const uint32_t px[8] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, q.z & 0xffffu, q.z >> 16, q.w & 0xffffu, q.w >> 16};
+                uint32_t res[8];
+                blend_row(yy, px, res);
                 u32x4 o;
                 o.x = res[0] | (res[1] << 16); o.y = res[2] | (res[3] << 16); o.z = res[4] | (res[5] << 16); o.w = res[6] | (res[7] << 16);
-                *reinterpret_cast<u32x4*>(dp) = o;
-            } else {
+                *reinterpret_cast<u32x4*>(dst + (long long)yy * dst_step + 2 * (long long)x0) = o;
+            };
+            for (; y + (kRows - 1) * phases < y_hi; y += kRows * phases) {
+                u32x4 q[kRows];
+#pragma unroll
+                for (int k = 0; k < kRows; ++k) q[k] = *reinterpret_cast<const u32x4*>(src + (long long)(y + k * phases) * src_step + 2 * (long long)x0);
+#pragma unroll
+                for (int k = 0; k < kRows; ++k) { do_vec_row(y + k * phases, q[k]); __builtin_amdgcn_sched_barrier(0); }
+            }
+            for (; y < y_hi; y += phases) do_vec_row(y, *reinterpret_cast<const u32x4*>(src + (long long)y * src_step + 2 * (long long)x0));
+        } else {
+            for (; y < y_hi; y += phases) {
+                const uint8_t* sp = src + (long long)y * src_step + 2 * (long long)x0;
+                uint8_t* dp = dst + (long long)y * dst_step + 2 * (long long)x0;
+                uint32_t px[8], res[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) px[j] = (own >> j) & 1u ? *reinterpret_cast<const uint16_t*>(sp + 2 * j) : 0u;
+                blend_row(y, px, res);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if ((own >> j) & 1u) *reinterpret_cast<uint16_t*>(dp + 2 * j) = (uint16_t)res[j];
             }
         }
+    }
+}
+
+// Frames whose populated range does not fit the LDS table (full-range 16-bit sources, MSB-aligned video): one pixel per lane, four
+// ushort gathers from the per-tile LUTs in L2 -- bound by the divergent gathers themselves (up to 64 cache lines per wave
+// instruction).  Launched after clahe_interp16_kernel on every call; a workgroup whose frame was handled there returns at once, so
+// the grid is kept small: grid = (min(items, 2048), 1, frames) workgroups walking (row, 256-pixel block) items in row-major order
+// with stride gridDim.x -- the rows in flight at any moment are neighbours, so the LUTs they gather from (two tile rows) stay in L2
+// (rows strided over the whole image measured 2x slower: all 64 tiles' LUTs in use at once).
+__global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
+                                                                      uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
+                                                                      ClaheGeom g, const uint16_t* __restrict__ luts,
+                                                                      const Range16* __restrict__ frame_ranges)
+{
+    const int f = blockIdx.z;
+    const Range16 fr = frame_ranges[f];
+    if (fr.hi - (fr.lo & ~3u) < (uint32_t)kInterp16Entries) return;  // narrow range: done from LDS tables
+    const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
+    const int bx = (g.width + kThreads - 1) / kThreads;
+    const long long items = (long long)bx * g.height;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int y = (int)(it / bx);
+        const int x = (int)(it - (long long)y * bx) * kThreads + threadIdx.x;
+        if (x >= g.width) continue;
+        const float txf = tile_coord(x, g.inv_tw, g.contract);
+        int tx1 = floor_f32_to_int(txf);
+        const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
+        int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
+        const float tyf = tile_coord(y, g.inv_th, g.contract);
+        int ty1 = floor_f32_to_int(tyf);
+        const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
+        int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
+        const uint32_t v = *reinterpret_cast<const uint16_t*>(src_base + (long long)f * src_frame + (long long)y * src_step + 2 * (long long)x);
+        const float a = (float)lf[((size_t)ty1 * g.tiles_x + tx1) * kHist16 + v], b = (float)lf[((size_t)ty1 * g.tiles_x + tx2) * kHist16 + v];
+        const float c = (float)lf[((size_t)ty2 * g.tiles_x + tx1) * kHist16 + v], d = (float)lf[((size_t)ty2 * g.tiles_x + tx2) * kHist16 + v];
+        int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa, xa1, ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa, xa1, ya, ya1));
+        r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
+        *reinterpret_cast<uint16_t*>(dst_base + (long long)f * dst_frame + (long long)y * dst_step + 2 * (long long)x) = (uint16_t)r;
     }
 }
 

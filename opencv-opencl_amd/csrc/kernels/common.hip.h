@@ -44,6 +44,10 @@ __device__ __forceinline__ Split16 split16(const void* p, long long n)
     return s;
 }
 
+// Build self-test (mi_ctx_create): (1 + 2^-12)^2 - (1 + 2^-11) is 0 when the product is rounded before the add (ties to even)
+// and 2^-24 when the compiler fused them into an FMA -- i.e. when this file was built without -ffp-contract=off.
+__global__ void contract_probe_kernel(float a, float b, float c, float* out) { *out = __fadd_rn(__fmul_rn(a, b), c); }
+
 __device__ __forceinline__ void lds_inc(uint32_t* h, uint32_t idx)
 {
     __hip_atomic_fetch_add(h + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32

@@ -9,8 +9,13 @@
 //     whatever the pixel values are (a constant frame costs the same as noise);
 //   * the equalizeHist LUT is replicated the same way (lut[value][32]) so the per-pixel gather is
 //     conflict free as well;
-//   * float steps (LUT scale, CLAHE blend) use explicit __fmul_rn/__fadd_rn/__fsub_rn/__fdiv_rn so
-//     no FMA contraction can change a rounding (the file is also built with -ffp-contract=off).
+//   * float steps (LUT scale, CLAHE blend) must round every multiply and add separately.  What guarantees
+//     it is the BUILD FLAG -ffp-contract=off (csrc/Makefile forces it with `override`): ROCm 7.2's
+//     __fmul_rn/__fadd_rn are plain `*` / `+` unless OCML_BASIC_ROUNDED_OPERATIONS is defined, so on their
+//     own they contract to v_fma under hipcc's default -ffp-contract=fast (checked in the ISA: 125 FMAs in
+//     the interpolation kernel), and that mode also disregards `#pragma clang fp contract(off)`.  They are
+//     kept as documentation of intent; a library built without the flag refuses to create a context
+//     (contract_probe_kernel, run once per process by mi_ctx_create).
 // The staged kernels (K1..K6) never synchronise between workgroups inside a launch: stage results
 // cross kernel boundaries only (partials -> LUT -> apply).  The fused equalizeHist kernel (KF) is the
 // one exception: its workgroups hand a frame's histogram/LUT to each other through a bounded,

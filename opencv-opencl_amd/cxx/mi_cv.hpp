@@ -361,7 +361,9 @@ inline void claheLumaBGR(const Mat& bgr, Mat& dst, double clipLimit, Size tiles)
 inline void registerHostBuffer(void* ptr, size_t bytes)
 {
     const mi_status st = mi_host_register(ptr, bytes);
-    if (st != MI_OK) MI_CV_ERROR(st == MI_ERR_NO_DEVICE ? GpuNotSupported : GpuApiCallError, std::string("mi_host_register: ") + mi_status_str(st));
+    if (st != MI_OK)
+        MI_CV_ERROR(st == MI_ERR_NO_DEVICE ? GpuNotSupported : GpuApiCallError,
+                    std::string("mi_host_register: ") + mi_status_str(st) + (st == MI_ERR_NO_DEVICE ? " (no HIP device: this backend has no CPU fallback)" : ""));
 }
 inline void unregisterHostBuffer(void* ptr) { (void)mi_host_unregister(ptr); }
 
@@ -398,6 +400,7 @@ inline void equalizeHistChannelsNV12(const unsigned char* in, unsigned char* out
 #if __has_include(<opencv2/core.hpp>) && __has_include(<opencv2/imgproc.hpp>)
 #include <opencv2/core.hpp>
 #include <opencv2/imgproc.hpp>      // cv::CLAHE
+#define MI_CV_HAVE_OPENCV_FRONT_END 1
 namespace mi_cv {
 inline void throw_cv(mi_ctx* c, mi_status st, const char* what)
 {

@@ -55,6 +55,55 @@ def y_plane(width: int, height: int, dist: str = "D1", frame_index: int = 0) -> 
     raise ValueError(f"unknown distribution {dist!r}")
 
 
+def photo_like(width: int, height: int, seed: int = 1, channels: int = 1) -> np.ndarray:
+    """A synthetic stand-in for a photograph (`hun.png` row: regenerate, do not ship the reference's image):
+    piecewise-smooth gradients, large flat regions (some saturated at 0 / 255), soft blobs and fine texture in part of the
+    scene -- hot histogram bins, runs of equal neighbours, smooth neighbourhoods, i.e. what the noise distributions D1..D5
+    do not produce.  Integer arithmetic on a counter-based hash only, so the bytes are the same on every platform.
+    Returns HxW (channels == 1) or HxWx3 uint8 (each channel its own gradients over the same geometry)."""
+    w, h = int(width), int(height)
+    par = splitmix64(np.arange(512, dtype=np.uint64), seed).astype(np.uint64)
+    pi = [0]
+
+    def nxt(lo, hi):                                                # next parameter in [lo, hi)
+        v = int(par[pi[0] % 512] % np.uint64(max(hi - lo, 1))) + lo
+        pi[0] += 1
+        return v
+    xs = np.arange(w, dtype=np.int64)[None, :]
+    ys = np.arange(h, dtype=np.int64)[:, None]
+    # geometry shared by all channels: three cutting lines -> up to 8 cells, flat rectangles / ellipses, soft blobs
+    lines = [(nxt(-8, 9), nxt(-8, 9), nxt(0, w), nxt(0, h)) for _ in range(3)]
+    cell = np.zeros((h, w), np.int64)
+    for k, (a, b, cx, cy) in enumerate(lines):
+        if a == 0 and b == 0:
+            a = 1
+        cell |= (((xs - cx) * a + (ys - cy) * b) > 0).astype(np.int64) << k
+    rects = [(nxt(0, w), nxt(0, h), nxt(w // 16 + 1, w // 4 + 2), nxt(h // 16 + 1, h // 4 + 2)) for _ in range(6)]
+    ells = [(nxt(0, w), nxt(0, h), nxt(w // 20 + 2, w // 6 + 3), nxt(h // 20 + 2, h // 6 + 3)) for _ in range(4)]
+    blobs = [(nxt(0, w), nxt(0, h), nxt(max(w, h) // 8 + 2, max(w, h) // 3 + 3)) for _ in range(5)]
+    flat_vals = [0, 255, 16, 235, nxt(30, 220), nxt(30, 220), nxt(30, 220), nxt(30, 220), nxt(30, 220), nxt(30, 220)]
+    tex = (splitmix64((ys * w + xs).astype(np.uint64).reshape(-1), seed ^ 0x7E57).reshape(h, w) % np.uint64(5)).astype(np.int64) - 2
+    planes = []
+    for c in range(max(1, channels)):
+        img = np.zeros((h, w), np.int64)
+        for cid in range(8):                                        # every cell its own gradient plane
+            gx, gy, off = nxt(-90, 91), nxt(-90, 91), nxt(50, 200)
+            plane = off + (xs - w // 2) * gx // max(w, 1) + (ys - h // 2) * gy // max(h, 1)
+            img = np.where(cell == cid, plane, img)
+        for (cx, cy, r) in blobs:                                   # soft light / shadow: quadratic falloff, integer
+            amp = nxt(-50, 51)
+            d2 = (xs - cx) ** 2 + (ys - cy) ** 2
+            img = img + np.where(d2 < r * r, amp * (r * r - d2) // (r * r), 0)
+        img = img + np.where((cell & 1) == 1, tex, 0)               # fine texture in half of the cells only
+        for k, (x0, y0, rw, rh) in enumerate(rects):
+            img = np.where((xs >= x0) & (xs < x0 + rw) & (ys >= y0) & (ys < y0 + rh), flat_vals[k] if c == 0 else (flat_vals[k] * (c + 2) // 3) , img)
+        for k, (cx, cy, rx, ry) in enumerate(ells):
+            inside = ((xs - cx) ** 2) * (ry * ry) + ((ys - cy) ** 2) * (rx * rx) < (rx * rx) * (ry * ry)
+            img = np.where(inside, flat_vals[6 + k], img)
+        planes.append(np.clip(img, 0, 255).astype(np.uint8))
+    return planes[0] if channels == 1 else np.ascontiguousarray(np.stack(planes, axis=-1))
+
+
 def uv_plane(width: int, height: int, frame_index: int = 0) -> np.ndarray:
     return random_bytes((width * height) // 2, frame_seed(frame_index) ^ 0xA5A5)
 

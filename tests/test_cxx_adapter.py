@@ -113,6 +113,53 @@ def test_stream_config4_512_frames_4k_paced_60fps(tmp_path):
         assert np.array_equal(out[i * fb:(i + 1) * fb], want[j]), k
 
 
+_FRONT_END_TU = r"""
+#define MI_CV_WITH_OPENCV
+#include "mi_cv.hpp"
+#ifndef MI_CV_HAVE_OPENCV_FRONT_END
+#error "the cv::Mat front end of mi_cv.hpp was not enabled"
+#endif
+// what INTEGRATION.md tells a maintainer to write in place of OpenCVequalHist.cpp:145 and clahevideo.cpp:184-195
+void use(cv::Mat& y_in, cv::Mat& y_out)
+{
+    mi_cv::equalizeHist(y_in, y_out);
+    cv::Ptr<cv::CLAHE> clahe = mi_cv::createCLAHE(2.0, cv::Size(8, 8));
+    clahe->setClipLimit(3.0);
+    clahe->setTilesGridSize(cv::Size(4, 4));
+    (void)clahe->getClipLimit();
+    (void)clahe->getTilesGridSize();
+    clahe->apply(y_in, y_out);
+    clahe->collectGarbage();
+}
+"""
+
+
+def test_opencv_front_end_and_interposer_compile(tmp_path):
+    """The real-cv::Mat front end (namespace mi_cv in cxx/mi_cv.hpp) and the LD_PRELOAD interposer go through a compiler against
+    DECLARATION-ONLY OpenCV 4.4 headers (tests/cxx/opencv_decl: not OpenCV, pins nothing): CLAHE_MI must override every pure
+    virtual of cv::CLAHE, the InputArray / OutputArray / cv::error calls must exist with those signatures, and the interposer
+    object must define exactly the two mangled symbols the reference's prebuilt binaries import."""
+    decl = ROOT / "tests" / "cxx" / "opencv_decl"
+    cxx = ROOT / "opencv-opencl_amd" / "cxx"
+    tu = tmp_path / "front_end.cpp"
+    tu.write_text(_FRONT_END_TU)
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c", f"-I{decl}", f"-I{cxx}", str(tu), "-o", str(tmp_path / "fe.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    obj = tmp_path / "interpose.o"
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fPIC", "-c", f"-I{decl}",
+                        str(cxx / "interpose" / "mi_cv_interpose.cpp"), "-o", str(obj)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    syms = subprocess.run(["nm", str(obj)], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in syms.splitlines() if " T " in ln}
+    assert defined == {"_ZN2cv12equalizeHistERKNS_11_InputArrayERKNS_12_OutputArrayE", "_ZN2cv11createCLAHEEdNS_5Size_IiEE"}, defined
+    # without the define (or without OpenCV on the include path) the header stays OpenCV-free
+    tu2 = tmp_path / "plain.cpp"
+    tu2.write_text('#include "mi_cv.hpp"\n#ifdef MI_CV_HAVE_OPENCV_FRONT_END\n#error "front end leaked"\n#endif\nint main() { return 0; }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", f"-I{cxx}", str(tu2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_adapter_mat_semantics_cpu(tmp_path):
     """Mat / ROI / create-no-realloc / split / merge / type errors of the adapter, on the CPU, under ASan + UBSan."""
     _build()

@@ -899,13 +899,12 @@ def test_cvt_color_420_errors(ctx):
     ctx.cvt_color_420_batch_dev(0, 0, 0, 0, 0, mi_lumaeq.COLOR_BGR2YUV_I420)
 
 
-def test_real_photograph(ctx):
-    """The reference's own bench image (luma plane, 1919 x 1079; tests/golden/make_photo_fixture.py): smooth gradients and
-    large flat areas -- hot histogram bins and LDS broadcasts that the synthetic distributions do not produce."""
+def test_photo_like_scene(ctx):
+    """A synthetic photo-like scene (mi_lumaeq.synth.photo_like, 1919 x 1079: piecewise-smooth gradients, large flat and saturated
+    areas) -- hot histogram bins, runs of equal neighbours and LDS broadcasts that the noise distributions do not produce."""
     import torch
-    from pathlib import Path
-    z = np.load(Path(__file__).parent / "golden" / "photo_luma_1919x1079.npz")
-    y, crop = z["y"], z["bgr_crop"]
+    y = synth.photo_like(1919, 1079, 20261004)
+    crop = synth.photo_like(384, 256, 20261005, channels=3)
     assert np.array_equal(ctx.equalize_hist(y), oracle.equalize_hist(y))
     for cfg in [(2.0, 8, 8), (3.0, 4, 4), (40.0, 16, 2)]:
         assert np.array_equal(ctx.clahe(y, *cfg), oracle.clahe(y, *cfg)), cfg
