@@ -514,11 +514,12 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     dst = np.empty_like(y)
     res["host_mat_equalize_ms_pcie_inclusive"] = round(timeit(lambda: ctx.equalize_hist(y, dst), 20), 3)
     res["host_mat_clahe8x8_ms_pcie_inclusive"] = round(timeit(lambda: ctx.clahe(y, 2.0, 8, 8, dst), 20), 3)
-    B = min(args.batch, 32)
+    B = args.batch
     d_in = synth.nv12_batch_torch(w, h, B, args.dist, "cuda", seed=5)
     d_out = torch.empty_like(d_in)
-    ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 10)
+    ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 20)
     res["clahe8x8_batch_frames_per_s"] = round(B / (ms * 1e-3), 1)
+    res["clahe8x8_batch_whole_path_frac_of_8TBs"] = round((3 * w * h + w * h // 2) * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     del d_in, d_out
     # BASELINE.json configs[4] taken literally (parity unpinned): BGR -> YUV -> equalize Y -> BGR on
     # 3-channel 4K images (the sequence of singlecolor.cpp:39-66); the file that config names,

@@ -72,13 +72,17 @@ __device__ __forceinline__ uint8_t tile_lut_value(uint32_t c, const ClaheGeom& g
 // (tile rows are 480 bytes at 4K 8x8) is then fetched from HBM twice.  With the map, dispatch slot i of a frame works on tile
 // (i % 8) * (tiles / 8) + i / 8: each XCD owns a contiguous row-major run of tiles and walks it in order, so both halves of a cut
 // line are requested through the same L2 within microseconds of each other.
-__global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                            ClaheGeom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ luts, int xcd_map)
+// NT = 256 or 512 threads: the histogram is shared by the whole workgroup either way (32 KiB), so 512 threads put 32 waves on a CU
+// (4 workgroups) instead of 20 (5 workgroups of 4 waves); waves 4..7 leave before the 256-thread fold / LUT stage.
+template <int NT>
+__global__ __launch_bounds__(NT) void tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                      ClaheGeom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ luts, int xcd_map)
 {
-    __shared__ uint32_t h[256 * kCopies];
-    __shared__ uint32_t s_wave[4];
-    lds_hist_zero(h);
+    __shared__ uint32_t h[256 * kCopies];                       // exactly 32 KiB: five workgroups per CU (a 16-byte scan scratch
+    uint32_t* const s_wave = h;                                 // next to it made it four); the scans reuse h[0..3] once h is folded
     const int t = threadIdx.x;
+    for (int i = t; i < 256 * kCopies; i += NT) h[i] = 0;
+    __syncthreads();
     const uint32_t copy = t & (kCopies - 1);
     const int S = gridDim.x, s = blockIdx.x, f = blockIdx.z;
     const int ntiles = gridDim.y;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __re
         const int rows = r1 - r0;
         const long long items = (long long)rows * slots;
         int row = t / slots, slot = t - row * slots;
-        const int drow = kThreads / slots, dslot = kThreads - drow * slots;
+        const int drow = NT / slots, dslot = NT - drow * slots;
         auto item_ptr = [&]() -> const u32x4_u* {             // address of the current (row, slot), then advance by 256 items
             const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
             const u32x4_u* p = reinterpret_cast<const u32x4_u*>(src + (long long)y * step + x0 + (slot << 4));
@@ -102,17 +106,17 @@ __global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __re
             return p;
         };
         long long it = t;
-        for (; it + 3 * kThreads < items; it += 4 * kThreads) {          // 4 x 16 B in flight per lane
+        for (; it + 3 * NT < items; it += 4 * NT) {          // 4 x 16 B in flight per lane
             const u32x4_u* p0 = item_ptr(); const u32x4_u* p1 = item_ptr(); const u32x4_u* p2 = item_ptr(); const u32x4_u* p3 = item_ptr();
             const u32x4 a = *p0, b = *p1, c = *p2, d = *p3;
             hist_add_vec(h, a, copy); hist_add_vec(h, b, copy); hist_add_vec(h, c, copy); hist_add_vec(h, d, copy);
         }
-        for (; it < items; it += kThreads) hist_add_vec(h, *item_ptr(), copy);
+        for (; it < items; it += NT) hist_add_vec(h, *item_ptr(), copy);
     }
     if ((in_w & 15) != 0) {                                     // ragged right edge of the in-frame part: byte loads
         const int pw = in_w & 15, xs = x0 + (slots << 4);
         const long long items = (long long)(r1 - r0) * pw;
-        for (long long it = t; it < items; it += kThreads) {
+        for (long long it = t; it < items; it += NT) {
             const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
             const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
             lds_inc(h, ((uint32_t)src[(long long)y * step + xs + c] << kCopyShift) + copy);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __re
     if (in_w < g.tile_w) {                                      // reflected columns (right border tiles only)
         const int pw = g.tile_w - in_w;
         const long long items = (long long)(r1 - r0) * pw;
-        for (long long it = t; it < items; it += kThreads) {
+        for (long long it = t; it < items; it += NT) {
             const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
             const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
             const int x = reflect101(x0 + in_w + c, g.width);
@@ -129,7 +133,9 @@ __global__ __launch_bounds__(kThreads) void tile_hist_kernel(const uint8_t* __re
         }
     }
     __syncthreads();
+    if (NT > kThreads && t >= kThreads) return;                 // the fold and the LUT are 256-thread stages (terminated waves leave the barriers)
     const uint32_t bin = lds_hist_bin(h, t);
+    __syncthreads();                                            // everybody has folded its bin: h[0..3] becomes the scan scratch
     if (luts) luts[((size_t)f * gridDim.y + tile) * 256 + t] = tile_lut_value(bin, g, s_wave);     // host passes luts only when S == 1
     else partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = bin;
 }

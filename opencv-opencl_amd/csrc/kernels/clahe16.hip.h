@@ -384,24 +384,48 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uin
     const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
     const int bx = (g.width + kThreads - 1) / kThreads;
     const long long items = (long long)bx * g.height;
-    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
-        const int y = (int)(it / bx);
-        const int x = (int)(it - (long long)y * bx) * kThreads + threadIdx.x;
-        if (x >= g.width) continue;
-        const float txf = tile_coord(x, g.inv_tw, g.contract);
-        int tx1 = floor_f32_to_int(txf);
-        const float xa = __fsub_rn(txf, (float)tx1), xa1 = __fsub_rn(1.0f, xa);
-        int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
-        const float tyf = tile_coord(y, g.inv_th, g.contract);
-        int ty1 = floor_f32_to_int(tyf);
-        const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
-        int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
-        const uint32_t v = *reinterpret_cast<const uint16_t*>(src_base + (long long)f * src_frame + (long long)y * src_step + 2 * (long long)x);
-        const float a = (float)lf[((size_t)ty1 * g.tiles_x + tx1) * kHist16 + v], b = (float)lf[((size_t)ty1 * g.tiles_x + tx2) * kHist16 + v];
-        const float c = (float)lf[((size_t)ty2 * g.tiles_x + tx1) * kHist16 + v], d = (float)lf[((size_t)ty2 * g.tiles_x + tx2) * kHist16 + v];
-        int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa, xa1, ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa, xa1, ya, ya1));
-        r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
-        *reinterpret_cast<uint16_t*>(dst_base + (long long)f * dst_frame + (long long)y * dst_step + 2 * (long long)x) = (uint16_t)r;
+    const uint8_t* src = src_base + (long long)f * src_frame;
+    uint8_t* dst = dst_base + (long long)f * dst_frame;
+    constexpr int kChains = 4;                                       // independent pixel -> gather -> store chains per lane and iteration:
+    for (long long it0 = blockIdx.x; it0 < items; it0 += (long long)kChains * gridDim.x) {   // the kernel is bound by memory latency
+        int xs[kChains], ys[kChains];
+        uint32_t v[kChains];
+        bool on[kChains];
+#pragma unroll
+        for (int k = 0; k < kChains; ++k) {
+            const long long it = it0 + (long long)k * gridDim.x;
+            ys[k] = (int)(it / bx);
+            xs[k] = (int)(it - (long long)ys[k] * bx) * kThreads + threadIdx.x;
+            on[k] = it < items && xs[k] < g.width;
+            v[k] = on[k] ? *reinterpret_cast<const uint16_t*>(src + (long long)ys[k] * src_step + 2 * (long long)xs[k]) : 0u;
+        }
+        float a[kChains], b[kChains], c[kChains], d[kChains], xa[kChains], ya[kChains];
+#pragma unroll
+        for (int k = 0; k < kChains; ++k) {
+            const float txf = tile_coord(xs[k], g.inv_tw, g.contract);
+            int tx1 = floor_f32_to_int(txf);
+            xa[k] = __fsub_rn(txf, (float)tx1);
+            int tx2 = tx1 + 1; tx1 = max(tx1, 0); tx2 = min(tx2, g.tiles_x - 1);
+            const float tyf = tile_coord(ys[k], g.inv_th, g.contract);
+            int ty1 = floor_f32_to_int(tyf);
+            ya[k] = __fsub_rn(tyf, (float)ty1);
+            int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
+            if (on[k]) {
+                a[k] = (float)lf[((size_t)ty1 * g.tiles_x + tx1) * kHist16 + v[k]]; b[k] = (float)lf[((size_t)ty1 * g.tiles_x + tx2) * kHist16 + v[k]];
+                c[k] = (float)lf[((size_t)ty2 * g.tiles_x + tx1) * kHist16 + v[k]]; d[k] = (float)lf[((size_t)ty2 * g.tiles_x + tx2) * kHist16 + v[k]];
+            } else {
+                a[k] = b[k] = c[k] = d[k] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kChains; ++k) {
+            if (!on[k]) continue;
+            const float xa1 = __fsub_rn(1.0f, xa[k]), ya1 = __fsub_rn(1.0f, ya[k]);
+            int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a[k], b[k], c[k], d[k], xa[k], xa1, ya[k], ya1)
+                                              : clahe_blend_f<false>(a[k], b[k], c[k], d[k], xa[k], xa1, ya[k], ya1));
+            r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
+            *reinterpret_cast<uint16_t*>(dst + (long long)ys[k] * dst_step + 2 * (long long)xs[k]) = (uint16_t)r;
+        }
     }
 }
 
