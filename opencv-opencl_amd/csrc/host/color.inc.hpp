@@ -168,11 +168,11 @@ mi_status nv12_bgr_equalize_dev(mi_ctx* c, hipStream_t s, const uint8_t* in, siz
         mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * 3 * B * 256 * sizeof(uint32_t));
         if (st) return st;
         if ((st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * 3 * 256))) return st;
-        LAUNCH(c, s, MI_K_COLOR, nv12_bgr_hist_kernel, dim3(B, nf), dim3(kThreads), 0, j, c->d_partial);
+        LAUNCH(c, s, MI_K_COLOR, nv12_bgr_hist_kernel, dim3(B, nf), dim3(kNv12Threads), 0, j, c->d_partial);
         LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf * 3), dim3(kThreads), 0,
                (const uint32_t*)c->d_partial, B, (int)ysz, c->d_luts, (int32_t*)nullptr);
         const int B2 = blocks_per_frame(c, ysz * 3 / 2, 1, nf, 2048);
-        LAUNCH(c, s, MI_K_COLOR, nv12_bgr_apply_kernel, dim3(B2, nf), dim3(kThreads), 0, j, (const uint8_t*)c->d_luts);
+        LAUNCH(c, s, MI_K_COLOR, nv12_bgr_apply_kernel, dim3(B2, nf), dim3(kNv12Threads), 0, j, (const uint8_t*)c->d_luts);
     }
     return MI_OK;
 }

@@ -224,7 +224,7 @@ mi_status launch_hist_partials(mi_ctx* c, hipStream_t s, const PlaneArgs& a, int
     const int B = blocks_per_frame(c, (long long)a.width * a.height, p.rows, nf, 256);
     mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * B * 256 * sizeof(uint32_t));
     if (st) return st;
-    LAUNCH(c, s, MI_K_HIST, hist_partial_kernel, dim3(B, nf), dim3(kThreads), 0, p, c->d_partial);
+    LAUNCH(c, s, MI_K_HIST, hist_partial_kernel, dim3(B, nf), dim3(kHistThreads), 0, p, c->d_partial);
     *nparts_out = B;
     return MI_OK;
 }

@@ -264,12 +264,16 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4& q, int i)       // i is
     return (w >> (8 * (i & 3))) & 0xffu;
 }
 
+// Both passes run 512-thread workgroups: their LDS tables (48 KiB of channel histograms / 32 KiB of LUTs) are per workgroup, so eight
+// waves sharing one table put 24 / 32 waves on a CU where 256-thread workgroups gave 12 / 20 -- these kernels wait on memory and LDS
+// latency (105 s_waitcnt per 32 pixels in the apply pass), not on issue slots.
+constexpr int kNv12Threads = 512;
 // pass 1: partial[((f*3 + ch) * B + part) * 256 + bin], ch = 0 (B), 1 (G), 2 (R).  grid = (B, n_frames)
-__global__ __launch_bounds__(kThreads) void nv12_bgr_hist_kernel(Nv12Job j, uint32_t* __restrict__ partial)
+__global__ __launch_bounds__(kNv12Threads) void nv12_bgr_hist_kernel(Nv12Job j, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t h[3 * 256 * kChCopies];
     const int t = threadIdx.x, f = blockIdx.y;
-    for (int i = t; i < 3 * 256 * kChCopies; i += kThreads) h[i] = 0;
+    for (int i = t; i < 3 * 256 * kChCopies; i += kNv12Threads) h[i] = 0;
     __syncthreads();
     uint32_t* hb = h; uint32_t* hg = h + 256 * kChCopies; uint32_t* hr = h + 2 * 256 * kChCopies;
     const uint32_t copy = t & (kChCopies - 1);
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void nv12_bgr_hist_kernel(Nv12Job j, uint
     if (j.vec) {
         const int gx_n = j.width >> 4;
         const long long groups = (long long)gx_n * (j.height >> 1);
-        for (long long gi = (long long)blockIdx.x * kThreads + t; gi < groups; gi += (long long)gridDim.x * kThreads) {
+        for (long long gi = (long long)blockIdx.x * kNv12Threads + t; gi < groups; gi += (long long)gridDim.x * kNv12Threads) {
             const int by = (int)(gi / gx_n), gx = (int)(gi - (long long)by * gx_n);
             const u32x4 y0 = *reinterpret_cast<const u32x4*>(yp + (long long)(2 * by) * j.width + (gx << 4));
             const u32x4 y1 = *reinterpret_cast<const u32x4*>(yp + (long long)(2 * by + 1) * j.width + (gx << 4));
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void nv12_bgr_hist_kernel(Nv12Job j, uint
     } else {                                            // one 2x2 block per lane
         const int bx_n = j.width >> 1;
         const long long blocks = (long long)bx_n * (j.height >> 1);
-        for (long long bi = (long long)blockIdx.x * kThreads + t; bi < blocks; bi += (long long)gridDim.x * kThreads) {
+        for (long long bi = (long long)blockIdx.x * kNv12Threads + t; bi < blocks; bi += (long long)gridDim.x * kNv12Threads) {
             const int by = (int)(bi / bx_n), bx = (int)(bi - (long long)by * bx_n);
             const uint8_t* r0 = yp + (long long)(2 * by) * j.width + 2 * bx;
             const uint8_t* uv = uvp + (long long)by * j.width + 2 * bx;
@@ -310,6 +314,7 @@ __global__ __launch_bounds__(kThreads) void nv12_bgr_hist_kernel(Nv12Job j, uint
         }
     }
     __syncthreads();
+    if (t >= 256) return;                               // one bin per thread from here on
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         uint32_t s = 0;
@@ -320,12 +325,12 @@ __global__ __launch_bounds__(kThreads) void nv12_bgr_hist_kernel(Nv12Job j, uint
 }
 
 // pass 2: luts[(f*3 + ch) * 256 + v].  grid = (B, n_frames).  in == out allowed (a lane reads its group before writing it).
-__global__ __launch_bounds__(kThreads) void nv12_bgr_apply_kernel(Nv12Job j, const uint8_t* __restrict__ luts)
+__global__ __launch_bounds__(kNv12Threads) void nv12_bgr_apply_kernel(Nv12Job j, const uint8_t* __restrict__ luts)
 {
     __shared__ uint32_t lut3[256 * kCopies];            // entry v: lutB[v] | lutG[v] << 8 | lutR[v] << 16, 32 copies
     const int t = threadIdx.x, f = (int)gridDim.y - 1 - (int)blockIdx.y;      // last-to-first: what pass 1 read last is still cached
     const uint32_t copy = t & (kCopies - 1);
-    {
+    if (t < 256) {
         const uint8_t* lf = luts + (size_t)f * 3 * 256;
         const uint32_t v = (uint32_t)lf[t] | ((uint32_t)lf[256 + t] << 8) | ((uint32_t)lf[512 + t] << 16);
 #pragma unroll
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void nv12_bgr_apply_kernel(Nv12Job j, con
     if (j.vec) {
         const int gx_n = j.width >> 4;
         const long long groups = (long long)gx_n * (j.height >> 1);
-        for (long long gi = (long long)blockIdx.x * kThreads + t; gi < groups; gi += (long long)gridDim.x * kThreads) {
+        for (long long gi = (long long)blockIdx.x * kNv12Threads + t; gi < groups; gi += (long long)gridDim.x * kNv12Threads) {
             const int by = (int)(gi / gx_n), gx = (int)(gi - (long long)by * gx_n);
             const long long o0 = (long long)(2 * by) * j.width + (gx << 4), o1 = o0 + j.width, ouv = (long long)by * j.width + (gx << 4);
             const u32x4 y0 = *reinterpret_cast<const u32x4*>(yp + o0);
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void nv12_bgr_apply_kernel(Nv12Job j, con
     } else {
         const int bx_n = j.width >> 1;
         const long long blocks = (long long)bx_n * (j.height >> 1);
-        for (long long bi = (long long)blockIdx.x * kThreads + t; bi < blocks; bi += (long long)gridDim.x * kThreads) {
+        for (long long bi = (long long)blockIdx.x * kNv12Threads + t; bi < blocks; bi += (long long)gridDim.x * kNv12Threads) {
             const int by = (int)(bi / bx_n), bx = (int)(bi - (long long)by * bx_n);
             const long long o0 = (long long)(2 * by) * j.width + 2 * bx, ouv = (long long)by * j.width + 2 * bx;
             const uint32_t Y00 = yp[o0], Y01 = yp[o0 + 1], Y10 = yp[o0 + j.width], Y11 = yp[o0 + j.width + 1];

@@ -69,7 +69,8 @@ __device__ __forceinline__ void hist_add_vec(uint32_t* h, u32x4 q, uint32_t copy
     hist_add_dword(h, q.w, copy);
 }
 
-// Histogram of the bytes [p, p+n) shared between `nparts` workgroups; this one is `part`.
+// Histogram of the bytes [p, p+n) shared between `nparts` workgroups of NT threads; this one is `part`.
+template <int NT = kThreads>
 __device__ __forceinline__ void hist_flat(uint32_t* h, const uint8_t* p, long long n, int part, int nparts)
 {
     const int t = threadIdx.x;
@@ -80,11 +81,11 @@ __device__ __forceinline__ void hist_flat(uint32_t* h, const uint8_t* p, long lo
     const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
     const u32x4* vp = reinterpret_cast<const u32x4*>(p + s.head);
     long long i = v0 + t;
-    for (; i + 3 * kThreads < v1; i += 4 * kThreads) {      // 4 x 16 B in flight per lane
-        const u32x4 a = vp[i], b = vp[i + kThreads], c = vp[i + 2 * kThreads], d = vp[i + 3 * kThreads];
+    for (; i + 3 * NT < v1; i += 4 * NT) {      // 4 x 16 B in flight per lane
+        const u32x4 a = vp[i], b = vp[i + NT], c = vp[i + 2 * NT], d = vp[i + 3 * NT];
         hist_add_vec(h, a, copy); hist_add_vec(h, b, copy); hist_add_vec(h, c, copy); hist_add_vec(h, d, copy);
     }
-    for (; i < v1; i += kThreads) hist_add_vec(h, vp[i], copy);
+    for (; i < v1; i += NT) hist_add_vec(h, vp[i], copy);
 }
 
 __device__ __forceinline__ void lds_hist_zero(uint32_t* h)

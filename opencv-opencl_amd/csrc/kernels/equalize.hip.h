@@ -8,18 +8,23 @@ namespace mi {
 // K1  histogram partials.  grid = (B, n_frames); partial[f][b][256].
 // Reads W*H bytes per frame once; writes B KiB per frame.  Bound: HBM read.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void hist_partial_kernel(PlaneBatch p, uint32_t* __restrict__ partial)
+// kHistThreads = 512: eight waves share one 32 KiB histogram, so four workgroups put 32 waves on a CU instead of the 20 that five
+// 256-thread workgroups give -- the same change that took the CLAHE tile histograms from 132 to 124 us per 64 4K frames.
+constexpr int kHistThreads = 512;
+__global__ __launch_bounds__(kHistThreads) void hist_partial_kernel(PlaneBatch p, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t h[256 * kCopies];
-    lds_hist_zero(h);
+    const int t = threadIdx.x;
+    for (int i = t; i < 256 * kCopies; i += kHistThreads) h[i] = 0;
+    __syncthreads();
     const uint8_t* base = p.src + (long long)blockIdx.y * p.src_frame;
     if (p.rows == 1) {
-        hist_flat(h, base, p.row_bytes, blockIdx.x, gridDim.x);
+        hist_flat<kHistThreads>(h, base, p.row_bytes, blockIdx.x, gridDim.x);
     } else {
-        for (int r = blockIdx.x; r < p.rows; r += gridDim.x) hist_flat(h, base + (long long)r * p.src_step, p.row_bytes, 0, 1);
+        for (int r = blockIdx.x; r < p.rows; r += gridDim.x) hist_flat<kHistThreads>(h, base + (long long)r * p.src_step, p.row_bytes, 0, 1);
     }
     __syncthreads();
-    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = lds_hist_bin(h, threadIdx.x);
+    if (t < 256) partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + t] = lds_hist_bin(h, t);
 }
 
 // ---------------------------------------------------------------------------------------------

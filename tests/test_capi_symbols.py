@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_version_and_status_strings(built_lib):
     assert "gfx950" in mi_lumaeq.version()
     assert mi_lumaeq.status_str(0) == "MI_OK"
-    assert mi_lumaeq.status_str(5) == "MI_ERR_NO_DEVICE"
+    assert mi_lumaeq.status_str(5) == "MI_ERR_NO_DEVICE" and mi_lumaeq.status_str(6) == "MI_ERR_BUSY"
     assert [built_lib.mi_kernel_name(k).decode() for k in range(len(mi_lumaeq.KERNEL_NAMES))] == mi_lumaeq.KERNEL_NAMES
 
 
