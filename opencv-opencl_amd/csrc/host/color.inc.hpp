@@ -71,11 +71,11 @@ mi_status bgr_luma_dev(mi_ctx* c, hipStream_t s, const Color3Args& a, int op, do
             mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * B * 256 * sizeof(uint32_t));
             if (st) return st;
             if ((st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * 256))) return st;
-            LAUNCH(c, s, MI_K_COLOR, bgr_luma_hist_kernel, dim3(B, 1, nf), dim3(kThreads), 0, q, c->d_partial);
+            LAUNCH(c, s, MI_K_COLOR, bgr_luma_hist_kernel, dim3(B, 1, nf), dim3(kBgrThreads), 0, q, c->d_partial);
             LAUNCH(c, s, MI_K_EQ_LUT, equalize_lut_kernel, dim3(nf), dim3(kThreads), 0,
                    (const uint32_t*)c->d_partial, B, (int)((long long)a.width * a.height), c->d_luts, (int32_t*)nullptr);
             const int B2 = blocks_per_frame(c, (long long)a.width * a.height * 3, 1, nf, 2048);
-            LAUNCH(c, s, MI_K_COLOR, bgr_luma_apply_kernel, dim3(B2, 1, nf), dim3(kThreads), 0, q, (const uint8_t*)c->d_luts);
+            LAUNCH(c, s, MI_K_COLOR, bgr_luma_apply_kernel, dim3(B2, 1, nf), dim3(kBgrThreads), 0, q, (const uint8_t*)c->d_luts);
         }
         return MI_OK;
     }

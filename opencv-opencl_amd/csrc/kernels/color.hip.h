@@ -145,16 +145,20 @@ __device__ __forceinline__ void load_bgr16(const uint8_t* p, uint32_t* c0, uint3
     }
 }
 
-__global__ __launch_bounds__(kThreads) void bgr_luma_hist_kernel(ColorJob j, uint32_t* __restrict__ partial)
+// 512-thread workgroups for both passes: eight waves share one 32 KiB LDS table (histogram / replicated LUT), 24 waves per CU at
+// ~70 VGPRs instead of 20.
+constexpr int kBgrThreads = 512;
+__global__ __launch_bounds__(kBgrThreads) void bgr_luma_hist_kernel(ColorJob j, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t h[256 * kCopies];
-    lds_hist_zero(h);
     const int f = blockIdx.z, t = threadIdx.x;
+    for (int i = t; i < 256 * kCopies; i += kBgrThreads) h[i] = 0;
+    __syncthreads();
     const uint32_t copy = t & (kCopies - 1);
     for (int row = 0; row < j.rows; ++row) {
         const uint8_t* s3 = j.src + (long long)f * j.src_frame + (long long)row * j.src_step;
         const long long groups = (((uintptr_t)s3 & 15) == 0) ? (j.row_px >> 4) : 0;
-        for (long long gidx = (long long)blockIdx.x * kThreads + t; gidx < groups; gidx += (long long)gridDim.x * kThreads) {
+        for (long long gidx = (long long)blockIdx.x * kBgrThreads + t; gidx < groups; gidx += (long long)gridDim.x * kBgrThreads) {
             uint32_t c0[16], c1[16], c2[16];
             load_bgr16(s3 + gidx * 48, c0, c1, c2);
 #pragma unroll
@@ -164,22 +168,22 @@ __global__ __launch_bounds__(kThreads) void bgr_luma_hist_kernel(ColorJob j, uin
                 lds_inc(h, (Y << kCopyShift) + copy);
             }
         }
-        for (long long x = (groups << 4) + (long long)blockIdx.x * kThreads + t; x < j.row_px; x += (long long)gridDim.x * kThreads) {
+        for (long long x = (groups << 4) + (long long)blockIdx.x * kBgrThreads + t; x < j.row_px; x += (long long)gridDim.x * kBgrThreads) {
             uint32_t Y, U, V;
             px_bgr2yuv(s3[3 * x], s3[3 * x + 1], s3[3 * x + 2], Y, U, V);
             lds_inc(h, (Y << kCopyShift) + copy);
         }
     }
     __syncthreads();
-    partial[((size_t)f * gridDim.x + blockIdx.x) * 256 + t] = lds_hist_bin(h, t);
+    if (t < 256) partial[((size_t)f * gridDim.x + blockIdx.x) * 256 + t] = lds_hist_bin(h, t);
 }
 
-__global__ __launch_bounds__(kThreads) void bgr_luma_apply_kernel(ColorJob j, const uint8_t* __restrict__ luts)
+__global__ __launch_bounds__(kBgrThreads) void bgr_luma_apply_kernel(ColorJob j, const uint8_t* __restrict__ luts)
 {
     __shared__ uint32_t lut[256 * kCopies];
     const int f = (int)gridDim.z - 1 - (int)blockIdx.z, t = threadIdx.x;      // last-to-first: what pass 1 read last is still cached
     const uint32_t copy = t & (kCopies - 1);
-    {
+    if (t < 256) {
         const uint32_t v = luts[(size_t)f * 256 + t];
 #pragma unroll
         for (int k = 0; k < kCopies; ++k) lut[(t << kCopyShift) + ((k + t) & (kCopies - 1))] = v;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void bgr_luma_apply_kernel(ColorJob j, co
         const uint8_t* s3 = j.src + (long long)f * j.src_frame + (long long)row * j.src_step;
         uint8_t* d3 = j.dst + (long long)f * j.dst_frame + (long long)row * j.dst_step;
         const long long groups = ((((uintptr_t)s3 | (uintptr_t)d3) & 15) == 0) ? (j.row_px >> 4) : 0;
-        for (long long gidx = (long long)blockIdx.x * kThreads + t; gidx < groups; gidx += (long long)gridDim.x * kThreads) {
+        for (long long gidx = (long long)blockIdx.x * kBgrThreads + t; gidx < groups; gidx += (long long)gridDim.x * kBgrThreads) {
             uint32_t c0[16], c1[16], c2[16];
             load_bgr16(s3 + gidx * 48, c0, c1, c2);
             uint32_t w[12];
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void bgr_luma_apply_kernel(ColorJob j, co
             const u32x4 r0 = {w[0], w[1], w[2], w[3]}, r1 = {w[4], w[5], w[6], w[7]}, r2 = {w[8], w[9], w[10], w[11]};
             dp[0] = r0; dp[1] = r1; dp[2] = r2;
         }
-        for (long long x = (groups << 4) + (long long)blockIdx.x * kThreads + t; x < j.row_px; x += (long long)gridDim.x * kThreads) {
+        for (long long x = (groups << 4) + (long long)blockIdx.x * kBgrThreads + t; x < j.row_px; x += (long long)gridDim.x * kBgrThreads) {
             uint32_t Y, U, V, b, g, r;
             px_bgr2yuv(s3[3 * x], s3[3 * x + 1], s3[3 * x + 2], Y, U, V);
             px_yuv2bgr(lut[(Y << kCopyShift) + copy], U, V, b, g, r);

@@ -8,9 +8,10 @@ namespace mi {
 // K1  histogram partials.  grid = (B, n_frames); partial[f][b][256].
 // Reads W*H bytes per frame once; writes B KiB per frame.  Bound: HBM read.
 // ---------------------------------------------------------------------------------------------
-// kHistThreads = 512: eight waves share one 32 KiB histogram, so four workgroups put 32 waves on a CU instead of the 20 that five
-// 256-thread workgroups give -- the same change that took the CLAHE tile histograms from 132 to 124 us per 64 4K frames.
-constexpr int kHistThreads = 512;
+// 256 threads: 512-thread workgroups (the change that took the CLAHE tile histograms from 132 to 124 us) bought nothing here
+// (137.6 vs 139 us per 64 4K frames behind the previous launch's write drain) and cost the strided-ROI path 12 %, whose rows are
+// shorter than 512 x 16 bytes.
+constexpr int kHistThreads = kThreads;
 __global__ __launch_bounds__(kHistThreads) void hist_partial_kernel(PlaneBatch p, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t h[256 * kCopies];

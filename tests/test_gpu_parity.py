@@ -1088,3 +1088,28 @@ def test_pipe_argument_errors_and_fail_soft():
         assert c.get_stat("fused_fallbacks") == 1 and c.get_stat("fused_hard_errors") == 0
     finally:
         c.close()
+
+
+def test_clahe_tuning_options_do_not_change_bytes(ctx):
+    """The speed-only knobs of the CLAHE tile-histogram pass (XCD-aware tile order, 256- or 512-thread workgroups) give the oracle's
+    bytes in every combination, for batches (one workgroup per tile, LUT folded in) and single frames (split tiles + LUT kernel)."""
+    try:
+        for (w, h, n, cfg) in ((1920, 1080, 5, (2.0, 8, 8)), (640, 368, 1, (3.0, 4, 4)), (1280, 720, 2, (2.0, 16, 8))):
+            frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 1200 + k) for k in range(n)])
+            want = [oracle.nv12_frame(frames[k], w, h, uv_mode=1, op=1, clip_limit=cfg[0], tiles_x=cfg[1], tiles_y=cfg[2]) for k in range(n)]
+            d_in = dev(frames)
+            for xcd in (0, 1):
+                for threads in (256, 512):
+                    ctx.set_option("clahe_xcd_map", xcd)
+                    ctx.set_option("clahe_hist_threads", threads)
+                    d_out = torch.zeros_like(d_in)
+                    ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 1, *cfg)
+                    ctx.synchronize()
+                    out = d_out.cpu().numpy()
+                    for k in range(n):
+                        assert np.array_equal(out[k], want[k]), (w, h, xcd, threads, k)
+        with pytest.raises(mi_lumaeq.MiError):
+            ctx.set_option("clahe_hist_threads", 300)
+    finally:
+        ctx.set_option("clahe_xcd_map", 1)
+        ctx.set_option("clahe_hist_threads", 512)
