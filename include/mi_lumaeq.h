@@ -273,7 +273,8 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * Options (mi_ctx_set_option): "fused" (1/0: single-read fused kernel vs the three-kernel path),
  * "fused_wgs_per_cu" (persistent workgroups per CU, default 4), "fused_vpt" (8/16/20/24 16-byte vectors a
  * thread keeps in registers, default 20; 0 restores the default), "fused_acquire" (1/0), "fused_timeout_ms" (bound of every
- * inter-workgroup wait, default 50), "fused_fault_inject" (test hook, 0..3), "clahe_float_tables" (1/0),
+ * inter-workgroup wait, default 50), "fused_timeout_us" (test hook: the same bound in microseconds, so that ordinary waits expire),
+ * "fused_fault_inject" (test hook, 0..3), "clahe_float_tables" (1/0),
  * "bgr_fused" (1/0, default 1: mi_bgr_luma_op_u8c3 runs as two passes over the interleaved image instead of through
  * Y/U/V planes; CLAHE only for unpadded shapes with tile_w % 16 == 0),
  * "clahe_fp_contract" (1/0, default 0: CLAHE interpolation arithmetic.  0 = every multiply and add rounded separately, what an

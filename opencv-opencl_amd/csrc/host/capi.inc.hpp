@@ -194,7 +194,8 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 0 (default), 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
     if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
     if (!strcmp(name, "fused_fault_inject")) { if (value < 0 || value > 3) return fail(c, MI_ERR_BAD_ARG, "fused_fault_inject must be 0..3"); c->fused_fault_inject = value; return MI_OK; }
-    if (!strcmp(name, "fused_timeout_ms")) { c->fused_timeout_ms = std::max(1, value); return MI_OK; }
+    if (!strcmp(name, "fused_timeout_ms")) { c->fused_timeout_ms = std::max(1, value); c->fused_timeout_us = 0; return MI_OK; }
+    if (!strcmp(name, "fused_timeout_us")) { c->fused_timeout_us = std::max(0, value); return MI_OK; }
     if (!strcmp(name, "bgr_fused")) { c->bgr_fused = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_hist_threads")) { if (value != 256 && value != 512) return fail(c, MI_ERR_BAD_ARG, "clahe_hist_threads must be 256 or 512"); c->clahe_hist_threads = value; return MI_OK; }
     if (!strcmp(name, "clahe_xcd_map")) { c->clahe_xcd_map = value != 0; return MI_OK; }

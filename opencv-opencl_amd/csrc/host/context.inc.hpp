@@ -57,6 +57,7 @@ struct mi_ctx {
     int fused_vpt = kVPT;                                        // MI_LUMAEQ_FUSED_VPT (8, 16, 20, 24)
     int fused_acquire = 1;                                       // MI_LUMAEQ_FUSED_ACQUIRE
     int fused_fault_inject = 0;                                  // test hook (option "fused_fault_inject": 0 off, 1..3 see kernels/equalize_fused.hip.h)
+    int fused_timeout_us = 0;                                    // test hook (option "fused_timeout_us"): > 0 overrides fused_timeout_ms
     int fused_timeout_ms = 50;                                   // option "fused_timeout_ms": bound of every inter-workgroup wait
     int bgr_fused = 1;                                           // option "bgr_fused": 9 B/px two-pass BGR luma equalization / CLAHE
     int host_direct = 1;                                         // option "host_direct": contiguous host planes go to the copy engine unstaged

@@ -55,7 +55,8 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     j.T = (int)((j.nvec + slice - 1) / slice);
     j.acquire = c->fused_acquire;
     j.fault_inject = c->fused_fault_inject;
-    j.timeout_ticks = (unsigned long long)std::max(1, c->fused_timeout_ms) * 100000ull;
+    j.timeout_ticks = c->fused_timeout_us > 0 ? (unsigned long long)c->fused_timeout_us * 100ull     // s_memrealtime ticks at 100 MHz
+                                              : (unsigned long long)std::max(1, c->fused_timeout_ms) * 100000ull;
     j.U = 0;
     // UV as stand-alone 64 KiB tickets behind each frame's Y tickets: pure streaming work that fills the gaps while
     // other workgroups sit in their hand-off (measured 5 % faster than giving every Y ticket a share of the UV plane)

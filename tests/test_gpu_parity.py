@@ -574,6 +574,43 @@ def test_fused_bounded_wait_expiry_is_repaired_on_device(mode, in_place):
         c.close()
 
 
+@pytest.mark.parametrize("in_place", [False, True], ids=["out_of_place", "in_place"])
+def test_fused_repair_under_naturally_expiring_waits(in_place):
+    """No injected fault: the bound of the inter-workgroup waits is set to a few MICROseconds, so ordinary hand-offs expire at
+    whatever point the timing of that launch puts them -- consumers give up while their frame's LUT is being published, frames are
+    left partly written, tickets are never drawn.  Whatever state a launch ends in, the finish kernel must turn it into the
+    oracle's bytes (in place included), launch after launch, and the next launch must start from a clean hand-off block."""
+    w, h, n = 1920, 1080, 6
+    frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 1500 + k) for k in range(n)])
+    want = [[oracle.nv12_frame(frames[k], w, h, uv_mode=uv, op=0) for k in range(n)] for uv in (0, 1)]
+    c = mi_lumaeq.Context(0)
+    try:
+        total_fallbacks = 0
+        for us in (1, 2, 4, 8, 16, 40):
+            c.set_option("fused_timeout_us", us)
+            for rep in range(6):
+                uv = rep & 1
+                d_in = dev(frames)
+                d_out = d_in if in_place else torch.zeros_like(d_in)
+                c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv)
+                c.synchronize()
+                out = d_out.cpu().numpy()
+                for k in range(n):
+                    assert np.array_equal(out[k], want[uv][k]), (us, rep, k)
+            fb = c.get_stat("fused_fallbacks")
+            assert c.get_stat("fused_hard_errors") == 0
+            total_fallbacks = fb
+        assert total_fallbacks > 0                                  # the scenario did exercise the repair path
+        c.set_option("fused_timeout_ms", 50)                        # back to the default bound: fast path, no new fallback
+        d_in = dev(frames); d_out = torch.zeros_like(d_in)
+        c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
+        c.synchronize()
+        assert c.get_stat("fused_fallbacks") == total_fallbacks
+        assert np.array_equal(d_out[n - 1].cpu().numpy(), want[0][n - 1])
+    finally:
+        c.close()
+
+
 def test_fused_failure_statistics_survive_later_launches_and_block_growth():
     """A failure in launch N must still be visible after launch N+1 ... N+k (the statistics words are never cleared by the
     per-launch housekeeping) and after the hand-off block was re-allocated for a larger batch."""
