@@ -213,7 +213,8 @@ def main():
         step()
     barrier()
     ctx.profile_read(reset=True)
-    ctx.set_profiling(True)          # HIP events around every kernel, on the launch stream
+    # HIP events stamped by the kernel dispatches themselves (hipExtLaunchKernelGGL start / stop events), on the launch stream
+    ctx.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -290,9 +290,9 @@ mi_status mi_ctx_set_option(mi_ctx* ctx, const char* name, int value);
 mi_status mi_ctx_get_stat(mi_ctx* ctx, const char* name, uint64_t* out);
 
 /* ---- timing of the library's own kernels -------------------------------------------------------
- * With profiling on, every kernel the library launches is bracketed by hipEvents on the stream
- * it is launched on (the reference brackets its kernel with CL profiling events the same way,
- * 1frameMeasure.cpp:77-85).  mi_ctx_profile_read() synchronises those events and accumulates. */
+ * With profiling on, every kernel the library launches carries a start and a stop hipEvent stamped by
+ * its own dispatch on the stream it is launched on (hipExtLaunchKernelGGL; the reference reads its kernel's
+ * CL_PROFILING_COMMAND_START/END the same way, 1frameMeasure.cpp:77-85).  mi_ctx_profile_read() synchronises those events and accumulates. */
 enum { MI_K_HIST = 0, MI_K_EQ_LUT = 1, MI_K_LUT_APPLY = 2, MI_K_TILE_HIST = 3, MI_K_TILE_LUT = 4,
        MI_K_CLAHE_INTERP = 5, MI_K_FUSED = 6, MI_K_COLOR = 7, MI_K_FUSED_FINISH = 8, MI_K_COUNT = 9 };
 typedef struct mi_profile {
@@ -302,7 +302,9 @@ typedef struct mi_profile {
                                      /* distribution of the per-launch durations since the last reset (over at most the
                                       * 65 536 most recent launches of each kernel; 0 when there were none) */
 } mi_profile;
-mi_status   mi_ctx_set_profiling(mi_ctx* ctx, int enabled);
+mi_status   mi_ctx_set_profiling(mi_ctx* ctx, int enabled);   /* 0 off; 1 every kernel; 2 every kernel except the few-microsecond
+                                                                * housekeeping launch behind each fused kernel (two events fewer per
+                                                                * batch: what bench.py's timed region uses) */
 mi_status   mi_ctx_profile_read(mi_ctx* ctx, mi_profile* out, int reset);
 const char* mi_kernel_name(int k);
 

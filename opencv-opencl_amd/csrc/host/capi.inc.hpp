@@ -124,7 +124,7 @@ const char* mi_ctx_last_error_msg(const mi_ctx* c) { return c ? c->last_msg.c_st
 mi_status mi_ctx_set_profiling(mi_ctx* c, int enabled)
 {
     ENTER(c);
-    c->profiling = enabled != 0;
+    c->profiling = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled);
     return MI_OK;
 }
 

@@ -74,7 +74,7 @@ struct mi_ctx {
     uint8_t*  h_pin_out = nullptr; size_t pin_out_bytes = 0;
 
     // profiling
-    bool profiling = false;
+    int profiling = 0;                                           // 0 off, 1 every kernel, 2 every kernel but the housekeeping ones
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
     std::vector<hipEvent_t> chunk_events;                        // D2H chunk completion (host-pointer forms)
@@ -135,35 +135,33 @@ mi_status grow_pinned(mi_ctx* c, uint8_t** p, size_t* have, size_t need)
     return MI_OK;
 }
 
-// ---- kernel launch with optional event bracketing ---------------------------------------------
+// ---- kernel launch with optional timing ------------------------------------------------------------
+// With profiling on, the kernel is dispatched through hipExtLaunchKernelGGL, which stamps the start and the stop event from the
+// dispatch itself (the way CL_QUEUE_PROFILING_ENABLE stamps a kernel's own start / end, 1frameMeasure.cpp:81-85): no marker
+// packets on the stream.  Two hipEventRecord calls around every launch -- round 1 -- cost the timed region of the bench 4 %.
 struct Bracket {
-    mi_ctx* c; hipStream_t s; int kernel; hipEvent_t a = nullptr, b = nullptr; bool on;
-    Bracket(mi_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kernel(k), on(c_->profiling) {}
-    hipError_t begin()
+    mi_ctx* c; int kernel; hipEvent_t a = nullptr, b = nullptr; bool on;
+    Bracket(mi_ctx* c_, int k) : c(c_), kernel(k), on(!c_->capturing && (c_->profiling == 1 || (c_->profiling == 2 && k != MI_K_FUSED_FINISH))) {}
+    hipError_t acquire()
     {
         if (!on) return hipSuccess;
         for (hipEvent_t* e : {&a, &b}) {
             if (!c->free_events.empty()) { *e = c->free_events.back(); c->free_events.pop_back(); }
             else { hipError_t r = hipEventCreate(e); if (r != hipSuccess) return r; }
         }
-        return hipEventRecord(a, s);
+        return hipSuccess;
     }
-    hipError_t end()
-    {
-        if (!on) return hipSuccess;
-        hipError_t r = hipEventRecord(b, s);
-        c->pending.push_back({a, b, kernel});
-        return r;
-    }
+    void submitted() { if (on) c->pending.push_back({a, b, kernel}); }
 };
 
-#define LAUNCH(c, s, kid, kern, grid, block, shmem, ...)                          \
-    do {                                                                          \
-        Bracket br__((c), (s), (kid));                                            \
-        HIPCHK((c), br__.begin());                                                \
-        hipLaunchKernelGGL(kern, grid, block, shmem, (s), __VA_ARGS__);           \
-        HIPCHK((c), hipGetLastError());                                           \
-        HIPCHK((c), br__.end());                                                  \
+#define LAUNCH(c, s, kid, kern, grid, block, shmem, ...)                                              \
+    do {                                                                                              \
+        Bracket br__((c), (kid));                                                                     \
+        HIPCHK((c), br__.acquire());                                                                  \
+        if (br__.on) hipExtLaunchKernelGGL(kern, grid, block, shmem, (s), br__.a, br__.b, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, shmem, (s), __VA_ARGS__);                          \
+        HIPCHK((c), hipGetLastError());                                                               \
+        br__.submitted();                                                                             \
     } while (0)
 
 // ---- geometry / grid heuristics -----------------------------------------------------------------

@@ -8,6 +8,7 @@
 // There is NO CPU fallback in this file: without a HIP device every entry point fails loudly.
 #include "../../include/mi_lumaeq.h"
 #include "lumaeq_kernels.hip.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>

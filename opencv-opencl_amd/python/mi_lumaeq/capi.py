@@ -450,8 +450,9 @@ class Context:
         self._chk(lib().mi_ctx_set_option(self._h, name.encode(), int(value)), "mi_ctx_set_option")
 
     # ---- profiling ----
-    def set_profiling(self, on: bool):
-        self._chk(lib().mi_ctx_set_profiling(self._h, 1 if on else 0), "mi_ctx_set_profiling")
+    def set_profiling(self, on):
+        """False / 0: off.  True / 1: HIP events around every kernel.  2: every kernel but the housekeeping launch behind a fused kernel."""
+        self._chk(lib().mi_ctx_set_profiling(self._h, int(on)), "mi_ctx_set_profiling")
 
     def profile_read(self, reset: bool = True) -> dict:
         p = _Profile()
