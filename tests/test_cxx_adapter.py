@@ -56,7 +56,9 @@ def test_stream_demo_file_io_matches_oracle(tmp_path):
     frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 800 + k) for k in range(n)])
     src = tmp_path / "in.nv12"
     src.write_bytes(frames.tobytes())
-    for op, uv, args in (("equalize", "copy", []), ("clahe", "fill128", ["--clipLimit", "3.0", "--tile", "4"]), ("channels", "fill128", [])):
+    for op, uv, args in (("equalize", "copy", []), ("clahe", "fill128", ["--clipLimit", "3.0", "--tile", "4"]), ("channels", "fill128", []),
+                         ("equalize", "fill128", ["--depth", "2", "--uv-policy", "device", "--no-pin"]),          # pageable ring, UV written by the kernels
+                         ("clahe", "copy", ["--clipLimit", "3.0", "--tile", "4", "--depth", "8", "--uv-policy", "device"])):
         dst = tmp_path / f"out_{op}.nv12"
         r = subprocess.run([str(ROOT / "opencv-opencl_amd" / "lib" / "nv12_stream"), "--input", str(src), "--output", str(dst),
                             "--width", str(w), "--height", str(h), "--frames", str(n), "--workers", "3", "--op", op, "--uv", uv] + args,

@@ -1100,6 +1100,31 @@ def test_pipe_frames_in_flight_complete_in_order_and_match_oracle(case, pinned):
                 mi_lumaeq.host_unregister(a)
 
 
+@pytest.mark.parametrize("shape", [(322, 182), (2, 2), (4098, 6)], ids=str)
+def test_pipe_odd_geometries(shape):
+    """Frames whose Y plane is not a multiple of 16 bytes (the fused kernel does not apply: staged kernels inside the pipe), the
+    smallest NV12 frame, and a very wide one -- every op, host and device UV."""
+    w, h = shape
+    frames = [synth.nv12_frame(w, h, synth.DISTS[k % 5], 1700 + k) for k in range(5)]
+    c = mi_lumaeq.Context(0)
+    try:
+        for op in (mi_lumaeq.OP_EQUALIZE, mi_lumaeq.OP_CLAHE, mi_lumaeq.OP_CHANNELS):
+            for policy in (mi_lumaeq.PIPE_UV_HOST, mi_lumaeq.PIPE_UV_DEVICE):
+                outs = [np.zeros_like(f) for f in frames]
+                with mi_lumaeq.Pipe(c, w, h, op=op, uv_mode=1, clip_limit=2.0, tiles_x=2, tiles_y=2, depth=2, uv_policy=policy) as pipe:
+                    done = []
+                    for k, f in enumerate(frames):
+                        while not pipe.submit(f, outs[k], k):
+                            done.append(pipe.wait()[0])
+                    while pipe.pending:
+                        done.append(pipe.wait()[0])
+                assert done == list(range(len(frames)))
+                for k, f in enumerate(frames):
+                    assert np.array_equal(outs[k], _pipe_expected(f, w, h, op, 1, (2.0, 2, 2))), (shape, op, policy, k)
+    finally:
+        c.close()
+
+
 def test_pipe_argument_errors_and_fail_soft():
     c = mi_lumaeq.Context(0)
     try:
