@@ -518,7 +518,9 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     B = args.batch
     d_in = synth.nv12_batch_torch(w, h, B, args.dist, "cuda", seed=5)
     d_out = torch.empty_like(d_in)
-    ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 20)
+    for _ in range(10):                                           # steady state like the headline loop: clocks and caches settled
+        ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream)
+    ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 100)
     res["clahe8x8_batch_frames_per_s"] = round(B / (ms * 1e-3), 1)
     res["clahe8x8_batch_whole_path_frac_of_8TBs"] = round((3 * w * h + w * h // 2) * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     del d_in, d_out

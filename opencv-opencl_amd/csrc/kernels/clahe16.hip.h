@@ -16,9 +16,11 @@ namespace mi {
 //                 [frame lo, frame hi] only, starting from the closed-form prefix of the empty bins below it (they still
 //                 receive `batch` and their share of the residual increments, exactly as the sequential loops would give them).
 //   clahe_interp16  one workgroup per (tile pair, band, sub-band): stages {LUT[ty1][tx1][v], [ty1][tx2][v], [ty2][tx1][v],
-//                 [ty2][tx2][v]} for v in the frame range as ONE 8-byte LDS entry when the range fits (<= kInterp16Entries
-//                 values: every 12- and 13-bit source), so a pixel costs one ds_read_b64 instead of four L2 gathers; frames
-//                 with a wider range gather from the LUTs in L2 as before (same kernel, uniform branch per frame).
+//                 [ty2][tx2][v]} for v in the frame range as ONE 8-byte LDS entry, so a pixel costs one ds_read_b64 instead of
+//                 four L2 gathers.  kInterp16Entries values fit at a time (every 12- and 13-bit source in one go); a wider range
+//                 is walked in windows of that size, each pixel finished in the window its value falls into (the workgroup's
+//                 pixels are re-read once per window, from L2).  Only in-place calls on wide-range frames still gather from L2
+//                 (clahe_interp16_wide_kernel): re-reading pixels that earlier windows have overwritten is not an option.
 // =============================================================================================
 constexpr int kHist16 = 65536;
 constexpr int kHalf16 = 32768;
@@ -265,22 +267,11 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const uint16_t* ld = lf + ((size_t)ty2 * g.tiles_x + tx2) * kHist16;
     const Range16 fr = frame_ranges[f];
     const uint32_t start = fr.lo & ~3u;
-    if (fr.hi - start >= (uint32_t)kInterp16Entries) return;         // wide range: clahe_interp16_wide_kernel does this frame
-    {
-        const uint32_t n4 = (fr.hi - start) / 4 + 1;                 // groups of four consecutive values
-        for (uint32_t i = t; i < n4; i += kInterp16Threads) {
-            const uint32_t v = start + 4 * i;
-            const uint2 qa = *reinterpret_cast<const uint2*>(la + v), qb = *reinterpret_cast<const uint2*>(lb + v);
-            const uint2 qc = *reinterpret_cast<const uint2*>(lc + v), qd = *reinterpret_cast<const uint2*>(ld + v);
-            uint2 e0, e1, e2, e3;
-            e0.x = (qa.x & 0xffffu) | (qb.x << 16);        e0.y = (qc.x & 0xffffu) | (qd.x << 16);
-            e1.x = (qa.x >> 16) | (qb.x & 0xffff0000u);    e1.y = (qc.x >> 16) | (qd.x & 0xffff0000u);
-            e2.x = (qa.y & 0xffffu) | (qb.y << 16);        e2.y = (qc.y & 0xffffu) | (qd.y << 16);
-            e3.x = (qa.y >> 16) | (qb.y & 0xffff0000u);    e3.y = (qc.y >> 16) | (qd.y & 0xffff0000u);
-            tab[4 * i] = e0; tab[4 * i + 1] = e1; tab[4 * i + 2] = e2; tab[4 * i + 3] = e3;
-        }
-    }
-    __syncthreads();
+    // A range wider than the table is walked in WINDOWS of kInterp16Entries values: the table is staged once per window and a pixel is
+    // finished in the window its value falls into (2-byte stores).  That re-reads the workgroup's pixels once per window, so it
+    // cannot be done in place: in-place calls with a wide range are left to clahe_interp16_wide_kernel.
+    const bool multi = fr.hi - start >= (uint32_t)kInterp16Entries;
+    if (multi && src_base == dst_base) return;
 
     // rows of the band (as clahe_interp_kernel): ideal range widened, then trimmed with the float expression
     const int y_lo_band = (int)max(0LL, ((long long)(2 * band - 1) * g.tile_h) / 2 - kBandMargin);
@@ -294,81 +285,111 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     // columns of the pair, in 8-pixel groups
     const int x_lo = (int)max(0LL, ((long long)(2 * pr - 1) * g.tile_w) / 2 - kBandMargin);
     const int x_hi = (int)min((long long)g.width, ((long long)(2 * pr + 1) * g.tile_w + 1) / 2 + kBandMargin);
-    if (x_lo >= x_hi || y_lo >= y_hi) return;
+    if (x_lo >= x_hi || y_lo >= y_hi) return;                       // uniform over the workgroup
     const int g_lo = x_lo >> 3, ngroups = ((x_hi + 7) >> 3) - g_lo;
     const int phases = max(1, kInterp16Threads / ngroups);
     const int passes = (ngroups + kInterp16Threads - 1) / kInterp16Threads;          // > 1 only for tiles wider than 4096 pixels
     const uint8_t* src = src_base + (long long)f * src_frame;
     uint8_t* dst = dst_base + (long long)f * dst_frame;
-    for (int pass = 0; pass < passes; ++pass) {
-        const int gi = pass * kInterp16Threads + (passes > 1 ? t : t % ngroups);
-        const int phase = passes > 1 ? 0 : t / ngroups;
-        if (gi >= ngroups || phase >= phases) continue;
-        const int x0 = (g_lo + gi) << 3;
-        float xa[8], xa1[8];
-        uint32_t own = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float txf = tile_coord(x0 + j, g.inv_tw, g.contract);
-            const int txu = floor_f32_to_int(txf);
-            xa[j] = __fsub_rn(txf, (float)txu);
-            xa1[j] = __fsub_rn(1.0f, xa[j]);
-            int q = txu + 1; q = q < 0 ? 0 : (q > g.tiles_x ? g.tiles_x : q);
-            if (q == pr && x0 + j < g.width) own |= 1u << j;
+
+    for (uint32_t w0 = start; w0 <= fr.hi; w0 += (uint32_t)kInterp16Entries) {
+        __syncthreads();                                            // the previous window's table is no longer read
+        {
+            const uint32_t w1 = min(fr.hi, w0 + (uint32_t)kInterp16Entries - 1);
+            const uint32_t n4 = (w1 - w0) / 4 + 1;                   // groups of four consecutive values
+            for (uint32_t i = t; i < n4; i += kInterp16Threads) {
+                const uint32_t v = w0 + 4 * i;
+                const uint2 qa = *reinterpret_cast<const uint2*>(la + v), qb = *reinterpret_cast<const uint2*>(lb + v);
+                const uint2 qc = *reinterpret_cast<const uint2*>(lc + v), qd = *reinterpret_cast<const uint2*>(ld + v);
+                uint2 e0, e1, e2, e3;
+                e0.x = (qa.x & 0xffffu) | (qb.x << 16);        e0.y = (qc.x & 0xffffu) | (qd.x << 16);
+                e1.x = (qa.x >> 16) | (qb.x & 0xffff0000u);    e1.y = (qc.x >> 16) | (qd.x & 0xffff0000u);
+                e2.x = (qa.y & 0xffffu) | (qb.y << 16);        e2.y = (qc.y & 0xffffu) | (qd.y << 16);
+                e3.x = (qa.y >> 16) | (qb.y & 0xffff0000u);    e3.y = (qc.y >> 16) | (qd.y & 0xffff0000u);
+                tab[4 * i] = e0; tab[4 * i + 1] = e1; tab[4 * i + 2] = e2; tab[4 * i + 3] = e3;
+            }
         }
-        if (!own) continue;
-        const bool vec_ok = own == 0xffu && ((((uintptr_t)src | (uintptr_t)dst | (unsigned long long)src_step | (unsigned long long)dst_step) & 15) == 0);
-        auto blend_row = [&](int y, const uint32_t* px, uint32_t* res) {
-            const float tyf = tile_coord(y, g.inv_th, g.contract);
-            const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
+        __syncthreads();
+        for (int pass = 0; pass < passes; ++pass) {
+            const int gi = pass * kInterp16Threads + (passes > 1 ? t : t % ngroups);
+            const int phase = passes > 1 ? 0 : t / ngroups;
+            if (gi >= ngroups || phase >= phases) continue;
+            const int x0 = (g_lo + gi) << 3;
+            float xa[8], xa1[8];
+            uint32_t own = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                // values outside the frame range cannot occur for owned pixels; masked lanes may carry anything: clamp the index
-                const uint32_t idx = min(px[j] - start, (uint32_t)kInterp16Entries - 1);
-                const uint2 e = tab[idx];
-                const float a = (float)(e.x & 0xffffu), b = (float)(e.x >> 16), c = (float)(e.y & 0xffffu), d = (float)(e.y >> 16);
-                int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa[j], xa1[j], ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa[j], xa1[j], ya, ya1));
-                res[j] = (uint32_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+                const float txf = tile_coord(x0 + j, g.inv_tw, g.contract);
+                const int txu = floor_f32_to_int(txf);
+                xa[j] = __fsub_rn(txf, (float)txu);
+                xa1[j] = __fsub_rn(1.0f, xa[j]);
+                int q = txu + 1; q = q < 0 ? 0 : (q > g.tiles_x ? g.tiles_x : q);
+                if (q == pr && x0 + j < g.width) own |= 1u << j;
             }
-        };
-        int y = y_lo + phase;
-        if (vec_ok) {
-            // four rows are loaded before the first is blended: 64 B in flight per lane instead of 16 (the kernel runs at two
-            // workgroups per CU, too few waves to hide the HBM latency otherwise)
-            constexpr int kRows = 4;
-            auto do_vec_row = [&](int yy, const u32x4& q) {
-                const uint32_t px[8] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, q.z & 0xffffu, q.z >> 16, q.w & 0xffffu, q.w >> 16};
-                uint32_t res[8];
-                blend_row(yy, px, res);
-                u32x4 o;
-                o.x = res[0] | (res[1] << 16); o.y = res[2] | (res[3] << 16); o.z = res[4] | (res[5] << 16); o.w = res[6] | (res[7] << 16);
-                *reinterpret_cast<u32x4*>(dst + (long long)yy * dst_step + 2 * (long long)x0) = o;
+            if (!own) continue;
+            const bool aligned = ((((uintptr_t)src | (uintptr_t)dst | (unsigned long long)src_step | (unsigned long long)dst_step) & 15) == 0);
+            const bool vec_ok = own == 0xffu && aligned && !multi;
+            auto blend_row = [&](int y, const uint32_t* px, uint32_t* res) {
+                const float tyf = tile_coord(y, g.inv_th, g.contract);
+                const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // owned pixels of this window index the table directly; anything else is masked out later: clamp its index
+                    const uint32_t idx = min(px[j] - w0, (uint32_t)kInterp16Entries - 1);
+                    const uint2 e = tab[idx];
+                    const float a = (float)(e.x & 0xffffu), b = (float)(e.x >> 16), c = (float)(e.y & 0xffffu), d = (float)(e.y >> 16);
+                    int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa[j], xa1[j], ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa[j], xa1[j], ya, ya1));
+                    res[j] = (uint32_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+                }
             };
-            for (; y + (kRows - 1) * phases < y_hi; y += kRows * phases) {
-                u32x4 q[kRows];
+            int y = y_lo + phase;
+            if (vec_ok) {
+                // four rows are loaded before the first is blended: 64 B in flight per lane instead of 16 (the kernel runs at two
+                // workgroups per CU, too few waves to hide the HBM latency otherwise)
+                constexpr int kRows = 4;
+                auto do_vec_row = [&](int yy, const u32x4& q) {
+                    const uint32_t px[8] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, q.z & 0xffffu, q.z >> 16, q.w & 0xffffu, q.w >> 16};
+                    uint32_t res[8];
+                    blend_row(yy, px, res);
+                    u32x4 o;
+                    o.x = res[0] | (res[1] << 16); o.y = res[2] | (res[3] << 16); o.z = res[4] | (res[5] << 16); o.w = res[6] | (res[7] << 16);
+                    *reinterpret_cast<u32x4*>(dst + (long long)yy * dst_step + 2 * (long long)x0) = o;
+                };
+                for (; y + (kRows - 1) * phases < y_hi; y += kRows * phases) {
+                    u32x4 q[kRows];
 #pragma unroll
-                for (int k = 0; k < kRows; ++k) q[k] = *reinterpret_cast<const u32x4*>(src + (long long)(y + k * phases) * src_step + 2 * (long long)x0);
+                    for (int k = 0; k < kRows; ++k) q[k] = *reinterpret_cast<const u32x4*>(src + (long long)(y + k * phases) * src_step + 2 * (long long)x0);
 #pragma unroll
-                for (int k = 0; k < kRows; ++k) { do_vec_row(y + k * phases, q[k]); __builtin_amdgcn_sched_barrier(0); }
-            }
-            for (; y < y_hi; y += phases) do_vec_row(y, *reinterpret_cast<const u32x4*>(src + (long long)y * src_step + 2 * (long long)x0));
-        } else {
-            for (; y < y_hi; y += phases) {
-                const uint8_t* sp = src + (long long)y * src_step + 2 * (long long)x0;
-                uint8_t* dp = dst + (long long)y * dst_step + 2 * (long long)x0;
-                uint32_t px[8], res[8];
+                    for (int k = 0; k < kRows; ++k) { do_vec_row(y + k * phases, q[k]); __builtin_amdgcn_sched_barrier(0); }
+                }
+                for (; y < y_hi; y += phases) do_vec_row(y, *reinterpret_cast<const u32x4*>(src + (long long)y * src_step + 2 * (long long)x0));
+            } else {
+                for (; y < y_hi; y += phases) {
+                    const uint8_t* sp = src + (long long)y * src_step + 2 * (long long)x0;
+                    uint8_t* dp = dst + (long long)y * dst_step + 2 * (long long)x0;
+                    uint32_t px[8], res[8], todo = 0;
+                    if (own == 0xffu && aligned) {
+                        const u32x4 q = *reinterpret_cast<const u32x4*>(sp);
+                        px[0] = q.x & 0xffffu; px[1] = q.x >> 16; px[2] = q.y & 0xffffu; px[3] = q.y >> 16;
+                        px[4] = q.z & 0xffffu; px[5] = q.z >> 16; px[6] = q.w & 0xffffu; px[7] = q.w >> 16;
+                    } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) px[j] = (own >> j) & 1u ? *reinterpret_cast<const uint16_t*>(sp + 2 * j) : 0u;
-                blend_row(y, px, res);
+                        for (int j = 0; j < 8; ++j) px[j] = (own >> j) & 1u ? *reinterpret_cast<const uint16_t*>(sp + 2 * j) : 0xffffffffu;
+                    }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if ((own >> j) & 1u) *reinterpret_cast<uint16_t*>(dp + 2 * j) = (uint16_t)res[j];
+                    for (int j = 0; j < 8; ++j) if (((own >> j) & 1u) && px[j] - w0 < (uint32_t)kInterp16Entries) todo |= 1u << j;   // this window's pixels
+                    if (!todo) continue;
+                    blend_row(y, px, res);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if ((todo >> j) & 1u) *reinterpret_cast<uint16_t*>(dp + 2 * j) = (uint16_t)res[j];
+                }
             }
         }
     }
 }
 
-// Frames whose populated range does not fit the LDS table (full-range 16-bit sources, MSB-aligned video): one pixel per lane, four
-// ushort gathers from the per-tile LUTs in L2 -- bound by the divergent gathers themselves (up to 64 cache lines per wave
+// IN-PLACE calls on frames whose populated range does not fit the LDS table (full-range 16-bit sources, MSB-aligned video; out of place
+// such frames go through the table in several windows): one pixel per lane, four ushort gathers from the per-tile LUTs in L2 -- bound by the divergent gathers themselves (up to 64 cache lines per wave
 // instruction).  Launched after clahe_interp16_kernel on every call; a workgroup whose frame was handled there returns at once, so
 // the grid is kept small: grid = (min(items, 2048), 1, frames) workgroups walking (row, 256-pixel block) items in row-major order
 // with stride gridDim.x -- the rows in flight at any moment are neighbours, so the LUTs they gather from (two tile rows) stay in L2
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uin
 {
     const int f = blockIdx.z;
     const Range16 fr = frame_ranges[f];
-    if (fr.hi - (fr.lo & ~3u) < (uint32_t)kInterp16Entries) return;  // narrow range: done from LDS tables
+    if (fr.hi - (fr.lo & ~3u) < (uint32_t)kInterp16Entries || src_base != dst_base) return;   // done from LDS tables (one window, or several when not in place)
     const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
     const int bx = (g.width + kThreads - 1) / kThreads;
     const long long items = (long long)bx * g.height;
