@@ -486,13 +486,13 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
         lambda: ctx.equalize_hist_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, stream=stream), 200), 4)
     res["single_frame_dev_clahe8x8_ms"] = round(timeit(
         lambda: ctx.clahe_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 200), 4)
-    # the launch-bound case replayed from a captured HIP graph (the library switches its hand-off to replay-safe mode when it sees a
-    # capture): one graph launch instead of 1 (equalize) / 2-3 (CLAHE) kernel launches per frame
+    # the launch-bound case replayed from a captured HIP graph (all per-launch state of the fused path lives in device memory, so a
+    # captured call replays as it is): one graph launch instead of 2 (equalize + finish) / 2-3 (CLAHE) kernel launches per frame
     gctx = None
     try:
         if not args.graph_extras:
             raise StopIteration
-        gctx = mi_lumaeq.Context(torch.cuda.current_device())   # its own context: a capture switches a context's hand-off mode for good
+        gctx = mi_lumaeq.Context(torch.cuda.current_device())   # its own context: scratch seen by a capture is never freed again
         for name, fn in (("equalize", lambda st: gctx.equalize_hist_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, stream=st)),
                          ("clahe8x8", lambda st: gctx.clahe_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=st))):
             fn(stream)                                         # size the scratch eagerly: allocations are not capturable
