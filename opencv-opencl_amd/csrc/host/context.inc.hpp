@@ -7,12 +7,6 @@ struct PendingEvent { hipEvent_t a, b; int kernel; };
 
 }  // namespace
 
-// Concurrency guard for the fused kernel.  Its workgroups wait for each other, so every slice of a frame (T
-// workgroups) must be co-resident.  Several contexts may run fused launches on one GPU at the same time (the
-// worker pool does); each launch is then only guaranteed a share of the chip.  At most kMaxFusedCtxPerDevice live
-// contexts per device get the fused path (later ones use the three-kernel path), and a frame is only fused when
-// T <= (CUs * WGs/CU) / (2 * kMaxFusedCtxPerDevice), i.e. a launch that receives half of its fair share still
-// has all of a frame's slices resident.  (Other processes on the GPU are covered by the bounded waits.)
 // process-wide registry of caller-pinned host ranges (mi_host_register)
 struct PinnedRange { uintptr_t lo, hi; };
 static std::mutex g_pin_mu;
@@ -26,6 +20,12 @@ static bool host_range_pinned(const void* p, size_t bytes)
     return false;
 }
 
+// Concurrency guard for the fused kernel.  Its workgroups wait for each other, so every slice of a frame (T
+// workgroups) must be co-resident.  Several contexts may run fused launches on one GPU at the same time; each launch is then only
+// guaranteed a share of the chip.  At most kMaxFusedCtxPerDevice live contexts per device get the fused path (later ones use the
+// three-kernel path), and a frame is only fused when T <= (CUs * WGs/CU) / (2 * kMaxFusedCtxPerDevice), i.e. a launch that
+// receives half of its fair share still has all of a frame's slices resident.  What this cannot see -- other processes on the
+// GPU, a preempted queue -- is covered by the bounded waits and the finish kernel's repair (kernels/equalize_fused.hip.h).
 constexpr int kMaxDevices = 64;
 constexpr int kMaxFusedCtxPerDevice = 4;
 static std::atomic<int> g_fused_ctx_live[kMaxDevices];
