@@ -57,7 +57,7 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                    (const Range16*)franges, subs);
             // frames whose range does not fit the LDS table (their workgroups above returned at once); a no-op otherwise
             const long long wide_items = (long long)((width + kThreads - 1) / kThreads) * height;
-            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_wide_kernel, dim3((unsigned)std::min<long long>(wide_items, 2048), 1, nf), dim3(kThreads), 0,
+            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_wide_kernel, dim3((unsigned)std::min<long long>(wide_items, std::max(512, 2048 / nf)), 1, nf), dim3(kThreads), 0,
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
                    dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges);
         }

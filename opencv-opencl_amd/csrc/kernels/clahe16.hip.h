@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
 // IN-PLACE calls on frames whose populated range does not fit the LDS table (full-range 16-bit sources, MSB-aligned video; out of place
 // such frames go through the table in several windows): one pixel per lane, four ushort gathers from the per-tile LUTs in L2 -- bound by the divergent gathers themselves (up to 64 cache lines per wave
 // instruction).  Launched after clahe_interp16_kernel on every call; a workgroup whose frame was handled there returns at once, so
-// the grid is kept small: grid = (min(items, 2048), 1, frames) workgroups walking (row, 256-pixel block) items in row-major order
+// the grid is kept small: grid = (min(items, max(512, 2048 / frames)), 1, frames) workgroups walking (row, 256-pixel block) items in row-major order
 // with stride gridDim.x -- the rows in flight at any moment are neighbours, so the LUTs they gather from (two tile rows) stay in L2
 // (rows strided over the whole image measured 2x slower: all 64 tiles' LUTs in use at once).
 __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
