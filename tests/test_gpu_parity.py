@@ -1175,3 +1175,39 @@ def test_clahe_tuning_options_do_not_change_bytes(ctx):
     finally:
         ctx.set_option("clahe_xcd_map", 1)
         ctx.set_option("clahe_hist_threads", 512)
+
+
+def test_contexts_and_pipes_release_their_device_memory():
+    """Creating and destroying contexts, pipes and their scratch (fused hand-off block, ticket stamps, 16-bit CLAHE scratch, pipe
+    frames, retired buffers of a captured context) gives the device memory back: 25 cycles must not move the free-memory mark."""
+    w, h = 1280, 720
+    frame = synth.nv12_frame(w, h, "D2", 5)
+    y16 = np.random.default_rng(1).integers(0, 4096, (h, w), dtype=np.uint16)
+
+    def cycle():
+        c = mi_lumaeq.Context(0)
+        try:
+            out = np.zeros_like(frame)
+            with mi_lumaeq.Pipe(c, w, h, depth=3) as pipe:
+                assert pipe.submit(frame, out, 1)
+                pipe.wait()
+            d = dev(np.stack([frame] * 70))                          # > 64 frames: the hand-off block is laid out twice
+            o = torch.empty_like(d)
+            c.equalize_hist_nv12_batch_dev(d, o, w, h, 3, 0)
+            c.equalize_hist_nv12_batch_dev(d, o, w, h, 70, 0)
+            c.clahe_nv12_batch_dev(d, o, w, h, 4, 1, 2.0, 8, 8)
+            c.synchronize()
+            c.clahe16(y16, 2.0, 8, 8)
+            del d, o
+        finally:
+            c.close()
+
+    for _ in range(3):
+        cycle()                                                      # allocator pools of torch and of the runtime settle
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), (free0, free1)               # one cycle allocates several hundred MiB
