@@ -19,7 +19,8 @@ namespace mi {
 //                 [ty2][tx2][v]} for v in the frame range as ONE 8-byte LDS entry, so a pixel costs one ds_read_b64 instead of
 //                 four L2 gathers.  kInterp16Entries values fit at a time (every 12- and 13-bit source in one go); a wider range
 //                 is walked in windows of that size, each pixel finished in the window its value falls into (the workgroup's
-//                 pixels are re-read once per window, from L2).  Only in-place calls on wide-range frames still gather from L2
+//                 pixels are re-read once per window, from L2; windows none of them falls into are skipped -- a locally smooth
+//                 image needs one or two of the eight).  Only in-place calls on wide-range frames still gather from L2
 //                 (clahe_interp16_wide_kernel): re-reading pixels that earlier windows have overwritten is not an option.
 // =============================================================================================
 constexpr int kHist16 = 65536;
@@ -292,7 +293,39 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const uint8_t* src = src_base + (long long)f * src_frame;
     uint8_t* dst = dst_base + (long long)f * dst_frame;
 
-    for (uint32_t w0 = start; w0 <= fr.hi; w0 += (uint32_t)kInterp16Entries) {
+    // Which windows does this workgroup's rectangle populate at all?  (One extra read of its pixels: real images are locally much
+    // narrower than their frame.)  Bit w of s_windows: some owned pixel has (value - start) / kInterp16Entries == w; at most 8 windows.
+    __shared__ uint32_t s_windows;
+    if (multi) {
+        if (t == 0) s_windows = 0;
+        __syncthreads();
+        uint32_t seen = 0;
+        const bool al16 = ((((uintptr_t)src | (unsigned long long)src_step) & 15) == 0);
+        for (int pass = 0; pass < passes; ++pass) {
+            const int gi = pass * kInterp16Threads + (passes > 1 ? t : t % ngroups);
+            const int phase = passes > 1 ? 0 : t / ngroups;
+            if (gi >= ngroups || phase >= phases) continue;
+            const int x0 = (g_lo + gi) << 3;
+            auto note = [&](uint32_t v) { seen |= 1u << ((v - start) / (uint32_t)kInterp16Entries); };
+            if (al16 && x0 + 8 <= g.width) {                        // a superset of the owned pixels is fine here
+                for (int y = y_lo + phase; y < y_hi; y += phases) {
+                    const u32x4 q = *reinterpret_cast<const u32x4*>(src + (long long)y * src_step + 2 * (long long)x0);
+                    note(q.x & 0xffffu); note(q.x >> 16); note(q.y & 0xffffu); note(q.y >> 16);
+                    note(q.z & 0xffffu); note(q.z >> 16); note(q.w & 0xffffu); note(q.w >> 16);
+                }
+            } else {
+                for (int y = y_lo + phase; y < y_hi; y += phases)
+                    for (int jx = 0; jx < 8 && x0 + jx < g.width; ++jx)
+                        note(*reinterpret_cast<const uint16_t*>(src + (long long)y * src_step + 2 * (long long)(x0 + jx)));
+            }
+        }
+        if (seen) __hip_atomic_fetch_or(&s_windows, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+    }
+    const uint32_t windows = multi ? s_windows : 1u;
+
+    for (uint32_t w0 = start, wi = 0; w0 <= fr.hi; w0 += (uint32_t)kInterp16Entries, ++wi) {
+        if (!((windows >> wi) & 1u)) continue;                      // uniform: nothing of this rectangle lives in that window
         __syncthreads();                                            // the previous window's table is no longer read
         {
             const uint32_t w1 = min(fr.hi, w0 + (uint32_t)kInterp16Entries - 1);
