@@ -275,6 +275,8 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * thread keeps in registers, default 20; 0 restores the default), "fused_acquire" (1/0), "fused_timeout_ms" (bound of every
  * inter-workgroup wait, default 50), "fused_timeout_us" (test hook: the same bound in microseconds, so that ordinary waits expire),
  * "fused_fault_inject" (test hook, 0..3), "clahe_float_tables" (1/0),
+ * "clahe_xcd_map" (1/0, default 1: XCD-aware tile order of the CLAHE tile-histogram pass; speed only),
+ * "clahe_hist_threads" (256 / 512, default 512: threads per tile-histogram workgroup; speed only),
  * "bgr_fused" (1/0, default 1: mi_bgr_luma_op_u8c3 runs as two passes over the interleaved image instead of through
  * Y/U/V planes; CLAHE only for unpadded shapes with tile_w % 16 == 0),
  * "clahe_fp_contract" (1/0, default 0: CLAHE interpolation arithmetic.  0 = every multiply and add rounded separately, what an
