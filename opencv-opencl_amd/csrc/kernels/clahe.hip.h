@@ -105,13 +105,17 @@ __global__ __launch_bounds__(NT) void tile_hist_kernel(const uint8_t* __restrict
             if (slot >= slots) { slot -= slots; ++row; }
             return p;
         };
-        long long it = t;
-        for (; it + 3 * NT < items; it += 4 * NT) {          // 4 x 16 B in flight per lane
-            const u32x4_u* p0 = item_ptr(); const u32x4_u* p1 = item_ptr(); const u32x4_u* p2 = item_ptr(); const u32x4_u* p3 = item_ptr();
-            const u32x4 a = *p0, b = *p1, c = *p2, d = *p3;
-            hist_add_vec(h, a, copy); hist_add_vec(h, b, copy); hist_add_vec(h, c, copy); hist_add_vec(h, d, copy);
+        // groups of four 16-byte loads per lane, each predicated on its own bound: the ragged end of a tile (and all of a small tile:
+        // a 240 x 135 tile is four vectors per lane) still has four loads in flight instead of a serial tail -- tile histograms of
+        // 1080p 8x8 / 4K 16x16: -12 % / -16 %, 4K 8x8 unchanged (profiles/r02_n_clahe_ab_tail.txt)
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (long long it = t; it < items; it += 4 * NT) {
+            u32x4 cur[4]; bool cv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cv[k] = it + (long long)k * NT < items; const u32x4_u* q = item_ptr(); cur[k] = cv[k] ? *q : zero; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (cv[k]) hist_add_vec(h, cur[k], copy);
         }
-        for (; it < items; it += NT) hist_add_vec(h, *item_ptr(), copy);
     }
     if ((in_w & 15) != 0) {                                     // ragged right edge of the in-frame part: byte loads
         const int pw = in_w & 15, xs = x0 + (slots << 4);
