@@ -149,6 +149,26 @@ mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* ctx, const void* d_src, size_t sr
                                        double clip_limit, int tiles_x, int tiles_y,
                                        void* d_luts, void* stream);
 
+/* ---- the reference's own parity check as an operator (1frameMeasure.cpp:91-100) ------------------------
+ * The only test the reference holds compares its accelerator's plane with cv::equalizeHist's:
+ *     cv::absdiff(y_ocv, y_fpga, diff);  xf::cv::analyzeDiff(diff, 1, err_per);      pass iff err_per == 0
+ * (Vitis Vision's analyzeDiff walks the difference image, reports the smallest and the largest difference and the
+ * percentage of pixels whose difference EXCEEDS the threshold).  Both steps in one pass, on planes wherever they are:
+ * per frame f, stats[f] = { pixels with |a - b| > threshold, largest |a - b|, smallest |a - b|, pixels compared };
+ * err_per = 100.0 * above / total.  `b` may be NULL: `a` then already is a difference image (analyzeDiff on its own);
+ * `diff` may be NULL: no difference image is written (otherwise diff = |a - b|, cv::absdiff; it may alias a or b).
+ * This library's own tests demand bit-exactness (max_diff == 0); the operator exists so a caller can keep the
+ * reference's +-1 check, and so full-size device batches can be compared without a download. */
+typedef struct mi_diff_stats { uint32_t above, max_diff, min_diff, total; } mi_diff_stats;
+/* host planes (step >= width), blocking */
+mi_status mi_analyze_diff_u8(mi_ctx* ctx, const uint8_t* a, size_t a_step, const uint8_t* b, size_t b_step,
+                             uint8_t* diff, size_t diff_step, int width, int height, int threshold, mi_diff_stats* out);
+/* device planes, batched, stream-ordered; d_stats = n_frames mi_diff_stats in device memory */
+mi_status mi_analyze_diff_u8_batch_dev(mi_ctx* ctx, const void* d_a, size_t a_step, size_t a_frame_stride,
+                                       const void* d_b, size_t b_step, size_t b_frame_stride,
+                                       void* d_diff, size_t diff_step, size_t diff_frame_stride,
+                                       int width, int height, int n_frames, int threshold, mi_diff_stats* d_stats, void* stream);
+
 /* ---- CLAHE on CV_16UC1 (OpenCV surface beyond what the reference uses) ------------------------
  * cv::createCLAHE(clip, Size(tx,ty))->apply on 16-bit single-channel images: 65 536 bins, ushort LUTs.
  * Steps / frame strides in BYTES (>= 2*width).  In place allowed. */
@@ -296,7 +316,7 @@ mi_status mi_ctx_get_stat(mi_ctx* ctx, const char* name, uint64_t* out);
  * its own dispatch on the stream it is launched on (hipExtLaunchKernelGGL; the reference reads its kernel's
  * CL_PROFILING_COMMAND_START/END the same way, 1frameMeasure.cpp:77-85).  mi_ctx_profile_read() synchronises those events and accumulates. */
 enum { MI_K_HIST = 0, MI_K_EQ_LUT = 1, MI_K_LUT_APPLY = 2, MI_K_TILE_HIST = 3, MI_K_TILE_LUT = 4,
-       MI_K_CLAHE_INTERP = 5, MI_K_FUSED = 6, MI_K_COLOR = 7, MI_K_FUSED_FINISH = 8, MI_K_COUNT = 9 };
+       MI_K_CLAHE_INTERP = 5, MI_K_FUSED = 6, MI_K_COLOR = 7, MI_K_FUSED_FINISH = 8, MI_K_DIFF = 9, MI_K_COUNT = 10 };
 typedef struct mi_profile {
     double   total_ms[MI_K_COUNT];   /* summed kernel durations since the last reset */
     uint64_t launches[MI_K_COUNT];

@@ -26,7 +26,7 @@ const char* mi_kernel_name(int k)
 {
     static const char* names[MI_K_COUNT] = {"hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
                                             "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel",
-                                            "fused_finish_kernel"};
+                                            "fused_finish_kernel", "analyze_diff_kernel"};
     return (k >= 0 && k < MI_K_COUNT) ? names[k] : "?";
 }
 

@@ -28,6 +28,7 @@
 //   kernels/clahe16.hip.h         CLAHE on CV_16UC1 (N4)
 //   kernels/color.hip.h           cvtColor BGR2YUV / YUV2BGR + fused split/merge, 4:2:0 codes, NV12 per-channel equalize (N3)
 //   kernels/color_clahe.hip.h     CLAHE on the luma of interleaved BGR in two passes (N3)
+//   kernels/diff.hip.h            absdiff + analyzeDiff: the reference's own device-vs-CPU check (1frameMeasure.cpp:91-100)
 #pragma once
 #include "kernels/common.hip.h"
 #include "kernels/equalize.hip.h"
@@ -36,3 +37,4 @@
 #include "kernels/clahe16.hip.h"
 #include "kernels/color.hip.h"
 #include "kernels/color_clahe.hip.h"
+#include "kernels/diff.hip.h"

@@ -32,3 +32,4 @@ using namespace mi;
 #include "host/color.inc.hpp"
 #include "host/clahe16.inc.hpp"
 #include "host/pipe.inc.hpp"
+#include "host/diff.inc.hpp"

@@ -357,6 +357,34 @@ inline void claheLumaBGR(const Mat& bgr, Mat& dst, double clipLimit, Size tiles)
     detail::check(c, mi_bgr_luma_op_u8c3(c, s.data, s.step, dst.data, dst.step, s.cols, s.rows, MI_OP_CLAHE, clipLimit, tiles.width, tiles.height), "mi_bgr_luma_op_u8c3");
 }
 
+// ---- the reference's own device-vs-CPU check, 1frameMeasure.cpp:91-94, call for call:
+//          cv::absdiff(y_ocv, y_fpga, diff);   float err_per;   xf::cv::analyzeDiff(diff, 1, err_per);
+// absdiff: dst = |a - b| (CV_8UC1, same size).  analyzeDiff: err_per = percentage of pixels of `diff` that EXCEED err_thresh; the
+// smallest / largest difference are returned through the optional pointers (Vitis Vision prints them).
+inline void absdiff(const Mat& a, const Mat& b, Mat& dst)
+{
+    MI_CV_ASSERT(a.type() == CV_8UC1 && b.type() == CV_8UC1);
+    MI_CV_ASSERT(a.rows == b.rows && a.cols == b.cols);
+    if (a.empty()) return;
+    const Mat x = a, y = b;
+    dst.create(x.rows, x.cols, CV_8UC1);
+    mi_ctx* c = detail::thread_ctx();
+    mi_diff_stats st{};
+    detail::check(c, mi_analyze_diff_u8(c, x.data, x.step, y.data, y.step, dst.data, dst.step, x.cols, x.rows, 0, &st), "mi_analyze_diff_u8");
+}
+inline void analyzeDiff(const Mat& diff, int err_thresh, float& err_per, int* min_diff = nullptr, int* max_diff = nullptr)
+{
+    MI_CV_ASSERT(diff.type() == CV_8UC1);
+    err_per = 0.f;
+    if (diff.empty()) return;
+    mi_ctx* c = detail::thread_ctx();
+    mi_diff_stats st{};
+    detail::check(c, mi_analyze_diff_u8(c, diff.data, diff.step, nullptr, 0, nullptr, 0, diff.cols, diff.rows, err_thresh, &st), "mi_analyze_diff_u8");
+    err_per = 100.f * (float)st.above / (float)st.total;
+    if (min_diff) *min_diff = (int)st.min_diff;
+    if (max_diff) *max_diff = (int)st.max_diff;
+}
+
 // Pin a recycled frame-buffer pool once so the host forms DMA straight from / into it (mi_host_register).
 inline void registerHostBuffer(void* ptr, size_t bytes)
 {

@@ -17,7 +17,7 @@ UV_FILL128, UV_COPY = 0, 1
 STREAM_CTX = C.c_void_p(-1).value      # MI_STREAM_CTX: the context's private stream; 0/None = HIP null stream
 KERNEL_NAMES = ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel",
                 "tile_hist_kernel", "tile_lut_kernel", "clahe_interp_kernel", "equalize_fused_kernel", "color_kernel",
-                "fused_finish_kernel"]
+                "fused_finish_kernel", "analyze_diff_kernel"]
 COLOR_BGR2YUV, COLOR_YUV2BGR = 82, 84
 COLOR_YUV2BGR_NV12, COLOR_BGR2YUV_I420 = 93, 128
 OP_EQUALIZE, OP_CLAHE, OP_CHANNELS = 0, 1, 2
@@ -39,6 +39,7 @@ DECLARED_SYMBOLS = [
     "mi_host_register", "mi_host_unregister", "mi_clahe_u16", "mi_clahe_u16_batch_dev",
     "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
     "mi_nv12_bgr_equalize", "mi_nv12_bgr_equalize_batch_dev", "mi_cvt_color_420_u8", "mi_cvt_color_420_u8_batch_dev",
+    "mi_analyze_diff_u8", "mi_analyze_diff_u8_batch_dev",
 ]
 
 _K = len(KERNEL_NAMES)
@@ -117,6 +118,8 @@ def lib() -> C.CDLL:
     L.mi_nv12_bgr_equalize_batch_dev.argtypes = [vp, vp, sz, vp, sz, i, i, i, vp]
     L.mi_clahe_u16.argtypes = [vp, vp, sz, vp, sz, i, i, d, i, i]
     L.mi_clahe_u16_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i, i, d, i, i, vp]
+    L.mi_analyze_diff_u8.argtypes = [vp, vp, sz, vp, sz, vp, sz, i, i, i, vp]
+    L.mi_analyze_diff_u8_batch_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, vp, sz, sz, i, i, i, i, vp, vp]
     L.mi_host_register.argtypes = [vp, sz]
     L.mi_host_unregister.argtypes = [vp]
     L.mi_ctx_synchronize.argtypes = [vp, vp]
@@ -306,6 +309,40 @@ class Context:
         self._chk(lib().mi_clahe_nv12_batch_dev(self._h, _dptr(d_in), _dptr(d_out), width, height, n_frames,
                                                 uv_mode, float(clip_limit), tiles_x, tiles_y, stream),
                   "mi_clahe_nv12_batch_dev")
+
+    # ---- the reference's own check: cv::absdiff + xf::cv::analyzeDiff (1frameMeasure.cpp:91-100) ----
+    def analyze_diff(self, a: np.ndarray, b: np.ndarray | None = None, threshold: int = 1, want_diff: bool = False):
+        """Host planes.  Returns {"above", "max_diff", "min_diff", "total", "err_per"} (+ "diff" = |a - b| when asked);
+        b = None: `a` already is a difference image."""
+        a = _host2d(a, "analyze_diff")
+        h, w = a.shape
+        if b is not None:
+            b = _host2d(b, "analyze_diff")
+            if b.shape != a.shape:
+                raise ValueError("analyze_diff: planes differ in size")
+        diff = np.empty((h, w), np.uint8) if want_diff else None
+        out = (C.c_uint32 * 4)()
+        self._chk(lib().mi_analyze_diff_u8(self._h, a.ctypes.data, _step(a), b.ctypes.data if b is not None else None,
+                                           _step(b) if b is not None else 0, diff.ctypes.data if want_diff else None, w, w, h,
+                                           int(threshold), C.cast(out, C.c_void_p)), "mi_analyze_diff_u8")
+        r = {"above": int(out[0]), "max_diff": int(out[1]), "min_diff": int(out[2]), "total": int(out[3]),
+             "err_per": 100.0 * out[0] / out[3] if out[3] else 0.0}
+        if want_diff:
+            r["diff"] = diff
+        return r
+
+    def analyze_diff_batch_dev(self, a, b, width, height, n_frames, d_stats, threshold=1, diff=None, a_step=None, a_frame=None,
+                               b_step=None, b_frame=None, diff_step=None, diff_frame=None, stream=0):
+        """Device planes; d_stats = n_frames x 4 uint32 (above, max, min, total) in device memory."""
+        as_ = width if a_step is None else a_step
+        bs_ = width if b_step is None else b_step
+        ds_ = width if diff_step is None else diff_step
+        af = as_ * height if a_frame is None else a_frame
+        bf = bs_ * height if b_frame is None else b_frame
+        df = ds_ * height if diff_frame is None else diff_frame
+        self._chk(lib().mi_analyze_diff_u8_batch_dev(self._h, _dptr(a), as_, af, _dptr(b) if b is not None else None, bs_, bf,
+                                                     _dptr(diff) if diff is not None else None, ds_, df, width, height, n_frames,
+                                                     int(threshold), _dptr(d_stats), stream), "mi_analyze_diff_u8_batch_dev")
 
     # ---- stages ----
     def hist_batch_dev(self, src, width, height, n_frames, d_hist, src_step=None, src_frame=None, stream=0):

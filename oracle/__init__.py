@@ -276,4 +276,4 @@ def nv12_bgr_equalize(nv12: np.ndarray, width: int, height: int) -> np.ndarray:
     return dst
 
 
-from .np_oracle import np_equalize_hist, np_clahe, np_clahe_geometry, np_nv12_bgr_equalize  # noqa: E402,F401
+from .np_oracle import np_equalize_hist, np_clahe, np_clahe_geometry, np_nv12_bgr_equalize, np_analyze_diff  # noqa: E402,F401

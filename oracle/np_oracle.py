@@ -163,3 +163,15 @@ def np_nv12_bgr_equalize(nv12: np.ndarray, width: int, height: int) -> np.ndarra
     Uo = sat((-155188 * r0 - 305135 * g0 + 460324 * b0 + half + (128 << 20)) >> 20)
     Vo = sat((460324 * r0 - 385875 * g0 - 74448 * b0 + half + (128 << 20)) >> 20)
     return np.concatenate([Yo.reshape(-1), np.stack([Uo, Vo], axis=-1).reshape(-1)])
+
+
+def np_analyze_diff(a: np.ndarray, b: np.ndarray | None = None, threshold: int = 1) -> dict:
+    """The reference's own device-vs-CPU check (1frameMeasure.cpp:91-100): cv::absdiff(a, b, diff) followed by Vitis Vision's
+    xf::cv::analyzeDiff(diff, threshold, err_per) -- smallest and largest difference, pixels whose difference EXCEEDS the threshold,
+    err_per = 100 * count / (rows * cols).  b = None: `a` already is the difference image.  Vitis Vision is not in /root/reference
+    (an include, accel.cpp:8, unversioned): this restates its published behaviour."""
+    d = a.astype(np.int16) if b is None else np.abs(a.astype(np.int16) - b.astype(np.int16))
+    total = int(d.size)
+    above = int(np.count_nonzero(d > threshold))
+    return {"above": above, "max_diff": int(d.max()) if total else 0, "min_diff": int(d.min()) if total else 0, "total": total,
+            "err_per": 100.0 * above / total if total else 0.0, "diff": d.astype(np.uint8)}

@@ -82,6 +82,27 @@ int main()
         equalizeHist(empty, untouched);                              // empty src: no-op
         EXPECT(untouched.data[4] == 5);
     }
+    // --- 1frameMeasure.cpp:38-44, :91-100 written call for call: the CPU result against the device result through
+    //     absdiff + analyzeDiff(diff, 1, err_per); here the "CPU" plane is the oracle's, and the bar is 0 differences at all
+    {
+        Mat y_plane(H, W, CV_8UC1, nv12.data());
+        Mat y_ocv(H, W, CV_8UC1, ref.data());                        // orc_equalize_hist_u8 above
+        Mat y_dev(H, W, CV_8UC1);
+        Mat diff(H, W, CV_8UC1);
+        equalizeHist(y_plane, y_dev);
+        absdiff(y_ocv, y_dev, diff);
+        float err_per = -1.f; int dmin = -1, dmax = -1;
+        analyzeDiff(diff, 1, err_per, &dmin, &dmax);
+        EXPECT(err_per == 0.0f && dmin == 0 && dmax == 0);
+        y_dev.data[5 * y_dev.step + 7] ^= 1;                         // within the reference's tolerance
+        y_dev.data[9 * y_dev.step + 11] ^= 0x40;                     // far outside it
+        absdiff(y_ocv, y_dev, diff);
+        analyzeDiff(diff, 1, err_per, &dmin, &dmax);
+        EXPECT(diff.data[5 * diff.step + 7] == 1 && diff.data[9 * diff.step + 11] == 0x40);
+        EXPECT(dmin == 0 && dmax == 0x40 && err_per == 100.f * 1.f / (float)(W * H));
+        analyzeDiff(diff, 0, err_per);
+        EXPECT(err_per == 100.f * 2.f / (float)(W * H));
+    }
     // --- wrong type throws something derived from std::exception (OpenCVequalHist.cpp:189)
     {
         bool threw = false;

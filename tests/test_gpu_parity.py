@@ -68,6 +68,74 @@ def test_equalize_full_size_frames(ctx, wh, dist):
     assert np.array_equal(ctx.equalize_hist(src), oracle.equalize_hist(src))
 
 
+# ---- the reference's own check as an operator: cv::absdiff + xf::cv::analyzeDiff (1frameMeasure.cpp:91-100) -------------------
+
+@pytest.mark.parametrize("shape", SMALL + [(1080, 1920)], ids=str)
+@pytest.mark.parametrize("threshold", [0, 1, 7])
+def test_analyze_diff_host_form(ctx, shape, threshold):
+    h, w = shape
+    a = synth.y_plane(w, h, "D1", 61)
+    b = a.copy()
+    rng = np.random.default_rng(w * 131 + h)
+    k = max(1, a.size // 9)
+    idx = rng.choice(a.size, size=k, replace=False)
+    b.reshape(-1)[idx] = (b.reshape(-1)[idx].astype(np.int16) + rng.integers(-9, 10, size=k)).clip(0, 255).astype(np.uint8)
+    want = oracle.np_analyze_diff(a, b, threshold)
+    got = ctx.analyze_diff(a, b, threshold, want_diff=True)
+    assert np.array_equal(got.pop("diff"), want.pop("diff"))
+    assert got == want
+    # analyzeDiff on its own: the difference image in, same statistics out
+    alone = ctx.analyze_diff(oracle.np_analyze_diff(a, b)["diff"], None, threshold)
+    assert alone == {k_: v for k_, v in want.items()}
+    same = ctx.analyze_diff(a, a, threshold)
+    assert (same["above"], same["max_diff"], same["min_diff"], same["err_per"]) == (0, 0, 0, 0.0)
+
+
+def test_analyze_diff_strided_views_and_errors(ctx):
+    big_a, big_b = synth.y_plane(300, 200, "D2", 5), synth.y_plane(320, 210, "D1", 6)
+    va, vb = big_a[10:190, 37:291], big_b[7:187, 3:257]                 # different steps, unaligned starts
+    want = oracle.np_analyze_diff(va, vb, 3)
+    out = np.zeros((200, 400), np.uint8)
+    got = ctx.analyze_diff(va, vb, 3, want_diff=True)
+    assert np.array_equal(got.pop("diff"), want.pop("diff")) and got == want
+    assert ctx.analyze_diff(np.empty((0, 0), np.uint8), np.empty((0, 0), np.uint8))["total"] == 0
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.analyze_diff(va, vb, 256)
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.analyze_diff(va.astype(np.float32), vb)
+    assert out.sum() == 0
+
+
+def test_analyze_diff_batch_dev_is_how_full_size_batches_are_compared(ctx):
+    """The reference's check at BASELINE size, on the device: 16 x 4K frames through the fused path and through the three-kernel path
+    (two independent implementations) differ nowhere -- and a single planted +-1 and +-2 are found where they were put."""
+    w, h, n = 3840, 2160, 16
+    d_in = synth.nv12_batch_torch(w, h, n, "D2", "cuda:0", seed=77)
+    fused, staged = torch.empty_like(d_in), torch.empty_like(d_in)
+    ctx.equalize_hist_nv12_batch_dev(d_in, fused, w, h, n, mi_lumaeq.UV_FILL128)
+    other = mi_lumaeq.Context(0)
+    other.set_option("fused", 0)
+    other.equalize_hist_nv12_batch_dev(d_in, staged, w, h, n, mi_lumaeq.UV_FILL128)
+    other.synchronize(); ctx.synchronize()
+    fb = w * h * 3 // 2
+    stats = torch.full((n, 4), 0xFFFFFFFF, dtype=torch.int64, device="cuda:0").to(torch.int32)
+    ctx.analyze_diff_batch_dev(fused, staged, w, h * 3 // 2, n, stats, threshold=1, a_frame=fb, b_frame=fb)
+    torch.cuda.synchronize()
+    s = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert (s[:, 0] == 0).all() and (s[:, 1] == 0).all() and (s[:, 2] == 0).all() and (s[:, 3] == fb).all()
+    staged[3, 12345] = fused[3, 12345] ^ 1                                  # within the reference's tolerance: seen by max_diff, not by `above`
+    v = int(fused[9, 777])
+    staged[9, 777] = v + 2 if v < 254 else v - 2                            # outside it
+    diff = torch.empty_like(d_in)
+    ctx.analyze_diff_batch_dev(fused, staged, w, h * 3 // 2, n, stats, threshold=1, diff=diff, a_frame=fb, b_frame=fb, diff_frame=fb)
+    torch.cuda.synchronize()
+    s = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert s[3].tolist() == [0, 1, 0, fb] and s[9].tolist() == [1, 2, 0, fb]
+    assert s[[i for i in range(n) if i not in (3, 9)], :3].sum() == 0
+    assert int(diff[3, 12345]) == 1 and int(diff[9, 777]) == 2 and int(diff.sum()) == 3
+    other.close()
+
+
 def test_stage_apis(ctx):
     w, h, n = 640, 360, 3
     ys = np.stack([synth.y_plane(w, h, d, 30 + i) for i, d in enumerate(("D1", "D2", "D3"))])

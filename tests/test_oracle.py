@@ -389,3 +389,14 @@ def test_c_vs_numpy_clahe_fp_contract():
         assert np.array_equal(oracle.clahe16(s16, 2.0, 8, 8), oracle.np_clahe(s16, 2.0, 8, 8, fp_contract=True))
     finally:
         oracle.set_fp_contract(old)
+
+
+def test_np_analyze_diff_matches_the_reference_check():
+    """1frameMeasure.cpp:91-100: absdiff, then analyzeDiff(diff, 1, err_per) -- pixels whose difference EXCEEDS 1, as a percentage."""
+    a = np.array([[10, 20, 30, 40], [50, 60, 70, 80]], np.uint8)
+    b = np.array([[10, 21, 28, 40], [55, 60, 70, 0]], np.uint8)
+    r = oracle.np_analyze_diff(a, b, 1)
+    assert r["diff"].tolist() == [[0, 1, 2, 0], [5, 0, 0, 80]]
+    assert (r["above"], r["max_diff"], r["min_diff"], r["total"], r["err_per"]) == (3, 80, 0, 8, 37.5)
+    assert oracle.np_analyze_diff(a, a, 0)["err_per"] == 0.0
+    assert oracle.np_analyze_diff(r["diff"], None, 1)["above"] == 3
