@@ -11,7 +11,11 @@ fused_a, fused_b, ref = mi_lumaeq.Context(0), mi_lumaeq.Context(0), mi_lumaeq.Co
 ref.set_option("fused", 0)
 shapes = [(3840, 2160), (1920, 1080), (1280, 720), (640, 360), (256, 64), (3840, 1088), (2560, 1440)]
 t0 = time.time(); launches = frames = mismatches = errors = 0
+last_tick = t0
 while time.time() - t0 < budget:
+    if time.time() - last_tick > 30:                      # a line every half minute: gpurun takes 7 silent minutes for a hang
+        last_tick = time.time()
+        print(f"[{last_tick - t0:6.0f} s] {launches} fused launches, {frames} frames, mismatches={mismatches} errors={errors}", flush=True)
     w, h = random.choice(shapes)
     n = random.choice([1, 2, 3, 5, 8, 13, 32]) if w * h > 2_000_000 else random.choice([1, 7, 64, 200])
     uv = random.choice([0, 1])
@@ -67,6 +71,9 @@ repair_launches = 0
 fb0 = fused_a.get_stat("fused_fallbacks")
 t2 = time.time()
 while time.time() - t2 < budget / 3:
+    if time.time() - last_tick > 30:
+        last_tick = time.time()
+        print(f"[{last_tick - t0:6.0f} s] repair phase: {repair_launches} launches, mismatches={mismatches} errors={errors}", flush=True)
     w, h = random.choice(shapes[:6])
     n = random.choice([1, 2, 3, 5, 8, 13]) if w * h > 2_000_000 else random.choice([1, 7, 33])
     uv = random.choice([0, 1]); dist = random.choice(["D1", "D2", "D3", "D4", "D5"])
