@@ -545,6 +545,11 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     dst = np.empty_like(y)
     res["host_mat_equalize_ms_pcie_inclusive"] = round(timeit(lambda: ctx.equalize_hist(y, dst), 20), 3)
     res["host_mat_clahe8x8_ms_pcie_inclusive"] = round(timeit(lambda: ctx.clahe(y, 2.0, 8, 8, dst), 20), 3)
+    # the two figures above are for ordinary (unpinned) Mats, which the library packs through its own pinned staging; planes in
+    # memory the caller pinned (a registered frame pool) are DMA'd as they are
+    py, pd = torch.from_numpy(y.copy()).pin_memory(), torch.empty((h, w), dtype=torch.uint8).pin_memory()
+    res["host_mat_equalize_ms_pcie_inclusive_pinned_mats"] = round(timeit(lambda: ctx.equalize_hist(py.numpy(), pd.numpy()), 20), 3)
+    del py, pd
     B = args.batch
     d_in = synth.nv12_batch_torch(w, h, B, args.dist, "cuda", seed=5)
     d_out = torch.empty_like(d_in)

@@ -394,11 +394,13 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, ybytes))) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, ybytes))) return st;
     hipStream_t s = c->stream;
-    // Contiguous planes are handed to the copy engine as they are: caller-pinned memory (mi_host_register) is DMA'd
-    // asynchronously; plain pageable memory goes through the runtime's own pipelined staging, which on this platform
-    // runs at the full link rate (53 GB/s, measured by tools/pcie_probe.hip) -- 0.34 ms per 4K frame against 0.58 ms for
-    // copying through the context's pinned buffers.  Strided views (ROIs) are still staged row by row, in 2 MiB chunks
-    // whose host copies overlap the DMA of the previous chunk.  Option "host_direct" = 0 forces staging.
+    // Pinned memory (mi_host_register, or pinned by the caller) is DMA'd asynchronously as it is.  Everything else is packed through
+    // the context's own pinned staging buffers, in 2 MiB chunks whose host copies overlap the DMA of the previous chunk (0.58 ms per
+    // 4K plane).  Handing PAGEABLE memory to hipMemcpyAsync is faster in a single synchronous call (0.34 ms: the runtime pins the
+    // pages or stages them on helper threads of its own) and was the default in round 1 and most of round 2 -- but both silent
+    // process aborts on record happened in exactly that configuration, a pageable copy queued behind a kernel that stalls for its
+    // 50 ms bound, so the library no longer gives the runtime memory it did not pin itself.  Option "host_direct" = 1
+    // brings the old behaviour back.
     const bool in_pinned = src_step == (size_t)width && host_range_pinned(src, ybytes);
     const bool out_pinned = dst_step == (size_t)width && host_range_pinned(dst, ybytes);
     const bool in_direct = in_pinned || (c->host_direct && src_step == (size_t)width);

@@ -15,9 +15,18 @@ static bool host_range_pinned(const void* p, size_t bytes)
 {
     if (!p || bytes == 0) return false;
     const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    for (const auto& r : g_pinned) if (lo >= r.lo && hi <= r.hi) return true;
-    return false;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (const auto& r : g_pinned) if (lo >= r.lo && hi <= r.hi) return true;
+    }
+    // not registered through mi_host_register: memory the caller pinned itself (hipHostMalloc / hipHostRegister, a pinned torch
+    // tensor) is recognised by asking the runtime about both ends of the range
+    auto pinned_at = [](const void* q) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    };
+    return pinned_at(p) && pinned_at((const uint8_t*)p + bytes - 1);
 }
 
 // Concurrency guard for the fused kernel.  Its workgroups wait for each other, so every slice of a frame (T
@@ -60,7 +69,8 @@ struct mi_ctx {
     int fused_timeout_us = 0;                                    // test hook (option "fused_timeout_us"): > 0 overrides fused_timeout_ms
     int fused_timeout_ms = 50;                                   // option "fused_timeout_ms": bound of every inter-workgroup wait
     int bgr_fused = 1;                                           // option "bgr_fused": 9 B/px two-pass BGR luma equalization / CLAHE
-    int host_direct = 1;                                         // option "host_direct": contiguous host planes go to the copy engine unstaged
+    int host_direct = 0;                                         // option "host_direct": UNPINNED contiguous host planes are handed to the runtime's own
+                                                                 // pageable-copy path instead of the context's pinned staging (see host_op)
     int clahe_fp_contract = 0;                                   // option "clahe_fp_contract": CLAHE interpolation with GCC's FMA contraction (aarch64 OpenCV builds)
     int clahe16_transposed = 0;                                  // option "clahe16_transposed": value-major LUTs for 16-bit interpolation (tiles <= 64)
     int clahe_hist_threads = 512;                                // option "clahe_hist_threads": 256 or 512 threads per tile-histogram workgroup

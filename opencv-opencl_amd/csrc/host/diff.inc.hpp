@@ -74,14 +74,21 @@ mi_status mi_analyze_diff_u8(mi_ctx* c, const uint8_t* a, size_t a_step, const u
     uint8_t* d_a = c->d_stage_in;
     uint8_t* d_b = b ? c->d_stage_in + plane : nullptr;
     uint32_t* d_st = reinterpret_cast<uint32_t*>(c->d_stage_in + ((2 * plane + 15) & ~(size_t)15));
-    HIPCHK(c, hipMemcpy2DAsync(d_a, (size_t)width, a, a_step, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
-    if (b) HIPCHK(c, hipMemcpy2DAsync(d_b, (size_t)width, b, b_step, (size_t)width, (size_t)height, hipMemcpyHostToDevice, s));
+    // host planes are packed into the context's pinned staging (the library never hands the runtime memory it did not pin itself)
+    if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, 2 * plane))) return st;
+    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, plane + 64))) return st;
+    copy_rows(c->h_pin_in, (size_t)width, a, a_step, width, height);
+    if (b) copy_rows(c->h_pin_in + plane, (size_t)width, b, b_step, width, height);
+    HIPCHK(c, hipMemcpyAsync(d_a, c->h_pin_in, (b ? 2 : 1) * plane, hipMemcpyHostToDevice, s));
     st = analyze_diff_dev(c, s, d_a, (size_t)width, plane, d_b, (size_t)width, plane, diff ? c->d_stage_out : nullptr, (size_t)width, plane,
                           width, height, 1, threshold, d_st);
     if (st) return st;
-    if (diff) HIPCHK(c, hipMemcpy2DAsync(diff, diff_step, c->d_stage_out, (size_t)width, (size_t)width, (size_t)height, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(out, d_st, sizeof(mi_diff_stats), hipMemcpyDeviceToHost, s));
+    if (diff) HIPCHK(c, hipMemcpyAsync(c->h_pin_out, c->d_stage_out, plane, hipMemcpyDeviceToHost, s));
+    mi_diff_stats* h_st = reinterpret_cast<mi_diff_stats*>(c->h_pin_out + ((plane + 15) & ~(size_t)15));
+    HIPCHK(c, hipMemcpyAsync(h_st, d_st, sizeof(mi_diff_stats), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (diff) copy_rows(diff, diff_step, c->h_pin_out, (size_t)width, width, height);
+    *out = *h_st;
     return MI_OK;
 }
 

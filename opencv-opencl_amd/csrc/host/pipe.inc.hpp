@@ -12,8 +12,9 @@
 //
 // so PCIe runs in both directions at once while the kernels (tens of microseconds per 4K frame) hide behind it.
 // Frames complete in submission order (mi_pipe_wait).  Host memory that was registered with mi_host_register (a recycled
-// frame pool) is DMA'd asynchronously; unregistered (pageable) memory still works -- its copies block the caller, the
-// H2D at submit and the D2H at wait, as the runtime stages them -- with correspondingly less overlap.
+// frame pool) is DMA'd asynchronously as it is; unpinned (pageable) memory is copied through pinned staging buffers of the
+// slot by the calling thread (into them at submit, out of them at wait) -- the library never hands the runtime memory it did
+// not pin itself (host_op() in capi.inc.hpp says why); option "host_direct" = 1 restores the runtime's own pageable path.
 // All pipes of a process on one device share the SAME three streams: a second worker on a GPU then interleaves its frames
 // into the same queues instead of adding queues (8 streams on one device were measured 30 % SLOWER than 3: HIP multiplexes
 // streams onto 4 hardware queues, and unrelated copies end up ordered behind each other); as a side effect the fused
@@ -26,7 +27,9 @@ struct PipeSlot {
     hipEvent_t ev_h2d = nullptr, ev_k = nullptr, ev_done = nullptr;
     const uint8_t* in = nullptr; uint8_t* out = nullptr;
     uint64_t tag = 0;
-    bool out_async = false;                                       // D2H was queued at submit (registered memory)
+    bool out_async = false;                                       // D2H was queued at submit (pinned memory, or the slot's own staging)
+    bool out_staged = false;                                      // ... into h_out: mi_pipe_wait copies it to the caller's frame
+    uint8_t* h_in = nullptr; uint8_t* h_out = nullptr;            // pinned staging for frames the caller did not pin (allocated on first use)
     mi_status st = MI_OK;
 };
 
@@ -70,6 +73,8 @@ void pipe_free(mi_pipe* p)
     for (auto& sl : p->slots) {
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
         for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_done}) if (e) (void)hipEventDestroy(e);
     }
     if (p->h_hard) (void)hipHostFree(p->h_hard);
@@ -199,18 +204,36 @@ mi_status mi_pipe_submit(mi_pipe* p, const uint8_t* in, uint8_t* out, uint64_t t
     PipeSlot& sl = p->slots[(p->head + p->count) % p->slots.size()];
     sl.in = in; sl.out = out; sl.tag = tag; sl.st = MI_OK;
     const size_t fbytes = p->ybytes + p->uvbytes;
-    // registered (pinned) memory is DMA'd asynchronously; pageable memory makes this copy block the caller while the
-    // runtime stages it, which is still correct
-    HIPCHK(c, hipMemcpyAsync(sl.d_in, in, p->xfer_in, hipMemcpyHostToDevice, p->s_h2d));
+    auto staging = [&](uint8_t** h, size_t bytes) -> mi_status {
+        if (*h) return MI_OK;
+        void* q = nullptr;
+        hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocDefault);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(c, MI_ERR_OOM, "pipe: pinned staging allocation failed"); }
+        if (e != hipSuccess) return fail_hip(c, e, "hipHostMalloc");
+        *h = (uint8_t*)q;
+        return MI_OK;
+    };
+    // pinned memory is DMA'd as it is; anything else goes through the slot's pinned staging buffer (the calling thread's memcpy)
+    const uint8_t* h2d_src = in;
+    if (!c->host_direct && !host_range_pinned(in, p->xfer_in)) {
+        mi_status st = staging(&sl.h_in, fbytes);
+        if (st) return st;
+        memcpy(sl.h_in, in, p->xfer_in);
+        h2d_src = sl.h_in;
+    }
+    HIPCHK(c, hipMemcpyAsync(sl.d_in, h2d_src, p->xfer_in, hipMemcpyHostToDevice, p->s_h2d));
     HIPCHK(c, hipEventRecord(sl.ev_h2d, p->s_h2d));
     HIPCHK(c, hipStreamWaitEvent(p->s_k, sl.ev_h2d, 0));
     mi_status st = pipe_run_op(p, sl);
     if (st) return st;
     HIPCHK(c, hipEventRecord(sl.ev_k, p->s_k));
-    sl.out_async = host_range_pinned(out, p->uv_dev ? fbytes : p->ybytes);
+    const bool out_pinned = host_range_pinned(out, p->uv_dev ? fbytes : p->ybytes);
+    sl.out_staged = !out_pinned && !c->host_direct;
+    sl.out_async = out_pinned || sl.out_staged;
+    if (sl.out_staged && (st = staging(&sl.h_out, fbytes))) return st;
     if (sl.out_async) {
         HIPCHK(c, hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0));
-        HIPCHK(c, hipMemcpyAsync(out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
+        HIPCHK(c, hipMemcpyAsync(sl.out_staged ? sl.h_out : out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
         if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)
             HIPCHK(c, hipMemcpyAsync(p->h_hard + (&sl - p->slots.data()), c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_d2h));
         HIPCHK(c, hipEventRecord(sl.ev_done, p->s_d2h));
@@ -236,7 +259,8 @@ mi_status mi_pipe_wait(mi_pipe* p, uint64_t* tag, uint8_t** out_frame)
     }
     if (sl.out_async) {
         HIPCHK(c, hipEventSynchronize(sl.ev_done));
-    } else {
+        if (sl.out_staged) memcpy(sl.out, sl.h_out, p->xfer_out);
+    } else {                                                      // option "host_direct": the runtime's own (blocking) pageable copy
         HIPCHK(c, hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0));
         HIPCHK(c, hipMemcpyAsync(sl.out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
         if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)

@@ -151,9 +151,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     const uint32_t* h = hist + tile_id * kHist16;
     uint16_t* lut = luts + tile_id * kHist16;
     auto block_scan = [&](uint32_t v, uint32_t& total) -> uint32_t {     // inclusive prefix of v over the 1024 threads
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        const uint32_t incl = wave_incl_scan(v);
         __syncthreads();
         if (lane == 63) s_w[w] = incl;
         __syncthreads();

@@ -80,12 +80,14 @@ __device__ __forceinline__ void hist_flat(uint32_t* h, const uint8_t* p, long lo
     if (part == nparts - 1 && t < s.tail) lds_inc(h, ((uint32_t)p[s.head + (s.nvec << 4) + t] << kCopyShift) + copy);
     const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
     const u32x4* vp = reinterpret_cast<const u32x4*>(p + s.head);
-    long long i = v0 + t;
-    for (; i + 3 * NT < v1; i += 4 * NT) {      // 4 x 16 B in flight per lane
-        const u32x4 a = vp[i], b = vp[i + NT], c = vp[i + 2 * NT], d = vp[i + 3 * NT];
-        hist_add_vec(h, a, copy); hist_add_vec(h, b, copy); hist_add_vec(h, c, copy); hist_add_vec(h, d, copy);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (long long i = v0 + t; i < v1; i += 4 * NT) {      // 4 x 16 B in flight per lane, each load predicated on its own bound (no serial tail)
+        u32x4 q[4]; bool qv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { qv[k] = i + (long long)k * NT < v1; q[k] = qv[k] ? vp[i + (long long)k * NT] : zero; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (qv[k]) hist_add_vec(h, q[k], copy);
     }
-    for (; i < v1; i += NT) hist_add_vec(h, vp[i], copy);
 }
 
 __device__ __forceinline__ void lds_hist_zero(uint32_t* h)
@@ -104,15 +106,19 @@ __device__ __forceinline__ uint32_t lds_hist_bin(const uint32_t* h, int t)
 }
 
 // Block-wide helpers for 256 threads = 4 waves ------------------------------------------------
+// Inclusive scan over the 64 lanes of a wave with DPP moves (no LDS traffic, ~8 VALU instructions instead of six ds_bpermute round
+// trips): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of rows 0 / 2 added to rows 1 / 3 (row_bcast15) and lane 31
+// to rows 2 and 3 (row_bcast31).  Lanes without a source read 0 (old = 0, bound_ctrl off).
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     // row_bcast15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast31 -> rows 2, 3
+    return (uint32_t)x;
 }
 
 // inclusive scan over the 256 threads of the block; *block_total receives the grand total.

@@ -111,15 +111,14 @@ __device__ __forceinline__ void lut_flat(const uint32_t* lut, const uint8_t* src
     const long long v0 = s.nvec * part / nparts, v1 = s.nvec * (part + 1) / nparts;
     const u32x4_u* sp = reinterpret_cast<const u32x4_u*>(src + s.head);
     u32x4* dp = reinterpret_cast<u32x4*>(dst + s.head);
-    long long i = v0 + t;
-    for (; i + 3 * kThreads < v1; i += 4 * kThreads) {
-        const u32x4 a = sp[i], b = sp[i + kThreads], c = sp[i + 2 * kThreads], d = sp[i + 3 * kThreads];
-        dp[i] = lut_vec(lut, a, copy);
-        dp[i + kThreads] = lut_vec(lut, b, copy);
-        dp[i + 2 * kThreads] = lut_vec(lut, c, copy);
-        dp[i + 3 * kThreads] = lut_vec(lut, d, copy);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (long long i = v0 + t; i < v1; i += 4 * kThreads) {       // 4 x 16 B in flight per lane, each predicated on its own bound
+        u32x4 q[4]; bool qv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { qv[k] = i + (long long)k * kThreads < v1; q[k] = qv[k] ? sp[i + (long long)k * kThreads] : zero; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (qv[k]) dp[i + (long long)k * kThreads] = lut_vec(lut, q[k], copy);
     }
-    for (; i < v1; i += kThreads) dp[i] = lut_vec(lut, sp[i], copy);
 }
 
 // UV plane: fill with 128 or copy, dst aligned stores.

@@ -3,7 +3,8 @@ import os
 import sys
 from pathlib import Path
 
-faulthandler.enable()        # a native crash (HIP runtime, our library) prints the Python stack of every thread
+faulthandler.enable(file=sys.__stderr__)        # a native crash (HIP runtime, our library) prints the Python stack of every thread
+                                                # (sys.stderr itself is pytest's capture object under --capture=sys: no fileno)
 
 import pytest
 
@@ -11,7 +12,9 @@ ROOT = Path(__file__).resolve().parents[1]
 
 # In front of faulthandler: the native call chain of the thread that raised a fatal signal (tests/cxx/abrt_trace.c).  Round 1
 # saw three silent SIGABRTs raised by a runtime thread in ~30 GPU sessions; with this loaded for the whole session a recurrence
-# names the library that called abort() instead of leaving only "Fatal Python error: Aborted".
+# names the library that called abort() instead of leaving only "Fatal Python error: Aborted".  It recurred once in round 2 and
+# the trace was LOST: pytest's default capture had fd 2 pointing at a temporary file.  Hence pytest.ini (--capture=sys leaves the file
+# descriptors alone) and the copy the tracer appends to gpurun_out/abrt_trace.log.
 _tracer = ROOT / "tests" / "cxx" / "libabrt_trace.so"
 if _tracer.exists():
     try:

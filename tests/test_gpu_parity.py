@@ -1044,8 +1044,9 @@ def test_photo_like_scene(ctx):
 
 
 def test_host_forms_staged_and_direct_agree(ctx):
-    """Option "host_direct": contiguous host planes go to the copy engine as they are (default) or through the context's
-    pinned staging buffers (0) -- same bytes either way, for every host-pointer form."""
+    """Option "host_direct": unpinned contiguous host planes go through the context's pinned staging buffers (default, 0) or are handed
+    to the runtime's own pageable-copy path (1) -- same bytes either way, for every host-pointer form; memory the caller pinned
+    (here: a pinned torch tensor, which the library recognises through hipPointerGetAttributes) takes the direct path in both."""
     w, h = 640, 360
     y = synth.y_plane(w, h, "D2", 3)
     nv = _nv12_frames(w, h, 1, 4)[0]
@@ -1062,8 +1063,12 @@ def test_host_forms_staged_and_direct_agree(ctx):
         for a, b in zip(*outs):
             assert np.array_equal(a, b)
         assert np.array_equal(outs[0][0], oracle.equalize_hist(y)) and np.array_equal(outs[1][1], oracle.clahe(y, 2.0, 8, 8))
+        ctx.set_option("host_direct", 0)
+        pin_in, pin_out = torch.from_numpy(y.copy()).pin_memory(), torch.empty((h, w), dtype=torch.uint8).pin_memory()
+        got = ctx.equalize_hist(pin_in.numpy(), pin_out.numpy())
+        assert np.array_equal(got, outs[0][0]) and got.ctypes.data == pin_out.numpy().ctypes.data
     finally:
-        ctx.set_option("host_direct", 1)
+        ctx.set_option("host_direct", 0)
 
 
 def test_clahe_fp_contract_mode(ctx):

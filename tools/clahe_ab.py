@@ -1,5 +1,5 @@
 """A/B of a CLAHE option in one process (interleaved rounds), per-kernel HIP-event averages:
-    python tools/clahe_ab.py <option> [modes e.g. 0,1] [batch]"""
+    python tools/clahe_ab.py <option> [modes e.g. 0,1] [batch] [cases e.g. 1280x720x8x576,3840x2160x8]"""
 import sys, time, torch
 sys.path.insert(0, "opencv-opencl_amd/python"); sys.path.insert(0, ".")
 import mi_lumaeq
@@ -8,7 +8,13 @@ opt = sys.argv[1] if len(sys.argv) > 1 else "clahe_xcd_map"
 MODES = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 a = mi_lumaeq.Context(0)
-for (w, h, tiles) in ((3840, 2160, 8), (1920, 1080, 8), (3840, 2160, 16)):
+CASES = [(3840, 2160, 8, B), (1920, 1080, 8, B), (3840, 2160, 16, B)]
+if len(sys.argv) > 4:
+    CASES = []
+    for c in sys.argv[4].split(","):
+        f = [int(x) for x in c.split("x")]
+        CASES.append((f[0], f[1], f[2], f[3] if len(f) > 3 else B))
+for (w, h, tiles, B) in CASES:
     d_in = synth.nv12_batch_torch(w, h, B, "D2", "cuda", seed=1)
     d_out = torch.empty_like(d_in)
     wall = {m: [] for m in MODES}
