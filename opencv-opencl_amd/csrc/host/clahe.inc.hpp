@@ -28,6 +28,15 @@ mi_status clahe_geometry(mi_ctx* c, int width, int height, double clip_limit, in
     return MI_OK;
 }
 
+// tiles per workgroup of the batched tile-histogram pass, by tile size.  Measured (profiles/r02_p_clahe_ab_tiles_per_wg.txt, tile
+// histograms per launch with 1 / 2 / 4 tiles per workgroup): 640x360 8x8 261 / 202 / 201 us, 1280x720 8x8 185 / 169 / 173,
+// 1920x1080 8x8 135 / 138 / 144, 3840x2160 16x16 132 / 135 / 142, 3840x2160 8x8 125 / 134 / 134 -- two tiles per workgroup pay
+// below ~3 vectors per lane of a 512-thread workgroup (tiles of less than ~24 K pixels), never more than two, and not above.
+int clahe_auto_tiles_per_wg(const ClaheGeom& g)
+{
+    return (long long)g.tile_w * g.tile_h < 3LL * 16 * 512 ? 2 : 1;
+}
+
 mi_status launch_tile_luts(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const ClaheGeom& g, int f0, int nf, uint8_t* d_luts_out)
 {
     const int tiles = g.tiles_x * g.tiles_y;
@@ -45,6 +54,21 @@ mi_status launch_tile_luts(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const C
     const int xcd_map = (c->clahe_xcd_map && S == 1 && tiles % 8 == 0) ? 1 : 0;
     // 512 threads per workgroup (32 waves per CU sharing four 32 KiB histograms) measured 6-8 % faster than 256 (20 waves) and
     // than 1024 (32 waves, two histograms) at 4K and 1080p, 64-frame batches: profiles/r02_c_clahe_ab.txt
+    // small tiles in large batches are bound by the rate at which workgroups are dispatched (~4 ns apiece): K tiles per workgroup
+    int K = 1;
+    if (direct && c->clahe_hist_threads == 512) {
+        const int want_k = c->clahe_tiles_per_wg > 0 ? c->clahe_tiles_per_wg : clahe_auto_tiles_per_wg(g);
+        const int run = xcd_map ? tiles / 8 : tiles;             // tiles a workgroup may take consecutively
+        for (K = std::max(1, std::min(want_k, 8)); K > 1 && run % K != 0; --K) {}
+        // the batch must still fill the chip with workgroups
+        while (K > 1 && (long long)tiles / K * nf < (long long)c->cu_count * 8) K >>= 1;
+        if (K > 1 && run % K != 0) K = 1;
+    }
+    if (K > 1) {
+        LAUNCH(c, s, MI_K_TILE_HIST, tile_hist_multi_kernel, dim3(1, tiles / K, nf), dim3(kTileMultiThreads), 0,
+               src, (long long)a.src_step, (long long)a.src_frame, g, direct, tiles, K, xcd_map);
+        return MI_OK;
+    }
     if (c->clahe_hist_threads == 512)
         LAUNCH(c, s, MI_K_TILE_HIST, tile_hist_kernel<512>, dim3(S, tiles, nf), dim3(512), 0,
                src, (long long)a.src_step, (long long)a.src_frame, g, c->d_partial, direct, xcd_map);

@@ -72,6 +72,37 @@ __device__ __forceinline__ uint8_t tile_lut_value(uint32_t c, const ClaheGeom& g
 // (tile rows are 480 bytes at 4K 8x8) is then fetched from HBM twice.  With the map, dispatch slot i of a frame works on tile
 // (i % 8) * (tiles / 8) + i / 8: each XCD owns a contiguous row-major run of tiles and walks it in order, so both halves of a cut
 // line are requested through the same L2 within microseconds of each other.
+// columns of a tile that are not covered by whole 16-byte slots: the ragged right edge of the in-frame part and the reflected columns
+// of a right-border tile (byte loads; rows r0..r1 of the tile)
+template <int NT>
+__device__ __forceinline__ void tile_hist_edges(uint32_t* h, const uint8_t* src, long long step, const ClaheGeom& g, int tx, int ty,
+                                                int r0, int r1, uint32_t copy)
+{
+    const int t = threadIdx.x;
+    const int x0 = tx * g.tile_w;
+    const int in_w = max(0, min(g.tile_w, g.width - x0));
+    const int slots = in_w >> 4;
+    if ((in_w & 15) != 0) {                                     // ragged right edge of the in-frame part: byte loads
+        const int pw = in_w & 15, xs = x0 + (slots << 4);
+        const long long items = (long long)(r1 - r0) * pw;
+        for (long long it = t; it < items; it += NT) {
+            const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            lds_inc(h, ((uint32_t)src[(long long)y * step + xs + c] << kCopyShift) + copy);
+        }
+    }
+    if (in_w < g.tile_w) {                                      // reflected columns (right border tiles only)
+        const int pw = g.tile_w - in_w;
+        const long long items = (long long)(r1 - r0) * pw;
+        for (long long it = t; it < items; it += NT) {
+            const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
+            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
+            const int x = reflect101(x0 + in_w + c, g.width);
+            lds_inc(h, ((uint32_t)src[(long long)y * step + x] << kCopyShift) + copy);
+        }
+    }
+}
+
 // NT = 256 or 512 threads: the histogram is shared by the whole workgroup either way (32 KiB), so 512 threads put 32 waves on a CU
 // (4 workgroups) instead of 20 (5 workgroups of 4 waves); waves 4..7 leave before the 256-thread fold / LUT stage.
 template <int NT>
@@ -117,31 +148,88 @@ __global__ __launch_bounds__(NT) void tile_hist_kernel(const uint8_t* __restrict
             for (int k = 0; k < 4; ++k) if (cv[k]) hist_add_vec(h, cur[k], copy);
         }
     }
-    if ((in_w & 15) != 0) {                                     // ragged right edge of the in-frame part: byte loads
-        const int pw = in_w & 15, xs = x0 + (slots << 4);
-        const long long items = (long long)(r1 - r0) * pw;
-        for (long long it = t; it < items; it += NT) {
-            const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
-            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
-            lds_inc(h, ((uint32_t)src[(long long)y * step + xs + c] << kCopyShift) + copy);
-        }
-    }
-    if (in_w < g.tile_w) {                                      // reflected columns (right border tiles only)
-        const int pw = g.tile_w - in_w;
-        const long long items = (long long)(r1 - r0) * pw;
-        for (long long it = t; it < items; it += NT) {
-            const int row = (int)(it / pw), c = (int)(it - (long long)row * pw);
-            const int y = reflect101(ty * g.tile_h + r0 + row, g.height);
-            const int x = reflect101(x0 + in_w + c, g.width);
-            lds_inc(h, ((uint32_t)src[(long long)y * step + x] << kCopyShift) + copy);
-        }
-    }
+    tile_hist_edges<NT>(h, src, step, g, tx, ty, r0, r1, copy);
     __syncthreads();
     if (NT > kThreads && t >= kThreads) return;                 // the fold and the LUT are 256-thread stages (terminated waves leave the barriers)
     const uint32_t bin = lds_hist_bin(h, t);
     __syncthreads();                                            // everybody has folded its bin: h[0..3] becomes the scan scratch
     if (luts) luts[((size_t)f * gridDim.y + tile) * 256 + t] = tile_lut_value(bin, g, s_wave);     // host passes luts only when S == 1
     else partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = bin;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4m  K4 for batches of SMALL tiles: one workgroup walks K consecutive tiles of its XCD's run, LUT included.
+// Workgroups are dispatched at ~4 ns apiece (measured with the pixel loop switched off: 17 us per 4096, 61 us per 16384,
+// profiles/r02_n_clahe_ab_no_pixel_loop.txt), so a 720p 8x8 batch of 576 frames -- the same bytes as 64 4K frames, in 36 864 tiles
+// of 160 x 90 pixels -- spends 150 of its 188 us being dispatched.  K tiles per workgroup divide that by K; the price is that fold,
+// scans and LUT of a tile now sit between two pixel loops of the same workgroup (the other three workgroups of the CU cover it).
+// grid = (1, tiles / K, frames), 512 threads.  Waves 4..7 zero the histogram for the next tile while waves 0..3 scan; the two sides
+// of that branch execute different s_barrier instructions, hence the scalar condition.
+// Tile order: dispatch slot g of a frame (XCD g % 8) -> tiles (g % 8) * (tiles / 8) + (g / 8) * K + k, k = 0..K-1, which needs
+// (tiles / 8) % K == 0; without the XCD map: g * K + k.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileMultiThreads = 512;
+__global__ __launch_bounds__(kTileMultiThreads) void tile_hist_multi_kernel(const uint8_t* __restrict__ src_base, long long step,
+                                                                            long long frame_stride, ClaheGeom g,
+                                                                            uint8_t* __restrict__ luts, int ntiles, int K, int xcd_map)
+{
+    constexpr int NT = kTileMultiThreads;
+    __shared__ uint32_t h[256 * kCopies];
+    __shared__ uint32_t s_wave[4];
+    const int t = threadIdx.x;
+    const uint32_t copy = t & (kCopies - 1);
+    const bool lower = __builtin_amdgcn_readfirstlane(t >> 6) < kThreads / 64;      // waves 0..3: the 256 threads of the fold / LUT stage
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int i = t; i < 256 * kCopies / 4; i += NT) reinterpret_cast<u32x4*>(h)[i] = zero;
+    const int f = blockIdx.z, grp = blockIdx.y;
+    const uint8_t* src = src_base + (long long)f * frame_stride;
+    const int first = xcd_map ? ((grp & 7) * (ntiles >> 3) + (grp >> 3) * K) : grp * K;
+    for (int k = 0; k < K; ++k) {
+        __syncthreads();                                        // histogram zeroed (and the previous tile's scans done with s_wave)
+        const int tile = first + k;
+        const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+        const int x0 = tx * g.tile_w;
+        const int in_w = max(0, min(g.tile_w, g.width - x0));
+        const int slots = in_w >> 4;
+        if (slots > 0) {
+            const int items = g.tile_h * slots;
+            int row = t / slots, slot = t - row * slots;
+            const int drow = NT / slots, dslot = NT - drow * slots;
+            auto item_ptr = [&]() -> const u32x4_u* {
+                const int y = reflect101(ty * g.tile_h + row, g.height);
+                const u32x4_u* p = reinterpret_cast<const u32x4_u*>(src + (long long)y * step + x0 + (slot << 4));
+                row += drow; slot += dslot;
+                if (slot >= slots) { slot -= slots; ++row; }
+                return p;
+            };
+            for (int it = t; it < items; it += 4 * NT) {
+                u32x4 cur[4]; bool cv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { cv[q] = it + q * NT < items; const u32x4_u* p = item_ptr(); cur[q] = cv[q] ? *p : zero; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (cv[q]) hist_add_vec(h, cur[q], copy);
+            }
+        }
+        tile_hist_edges<NT>(h, src, step, g, tx, ty, 0, g.tile_h, copy);
+        __syncthreads();                                        // A: every pixel of the tile counted
+        uint32_t bin = 0;
+        if (lower) {
+#pragma unroll 1
+            for (int k0 = 0; k0 < kCopies; k0 += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bin += h[(t << kCopyShift) + ((k0 + q + t) & (kCopies - 1))];
+            }
+        }
+        __syncthreads();                                        // B: folded
+        if (lower) {
+            luts[((size_t)f * ntiles + tile) * 256 + t] = tile_lut_value(bin, g, s_wave);      // two barriers per scan inside
+        } else {
+            if (k + 1 < K)
+                for (int q = t - kThreads; q < 256 * kCopies / 4; q += NT - kThreads) reinterpret_cast<u32x4*>(h)[q] = zero;
+            if (g.clip > 0) { __syncthreads(); __syncthreads(); }
+            __syncthreads(); __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

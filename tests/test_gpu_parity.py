@@ -1250,6 +1250,36 @@ def test_clahe_tuning_options_do_not_change_bytes(ctx):
         ctx.set_option("clahe_hist_threads", 512)
 
 
+@pytest.mark.parametrize("case", [(640, 360, 96, (2.0, 8, 8), 0), (638, 358, 96, (3.0, 8, 8), 0), (320, 180, 200, (2.0, 6, 4), 0),
+                                  (640, 360, 140, (2.0, 8, 8), 4), (640, 360, 300, (2.0, 8, 8), 8), (1280, 720, 70, (2.0, 8, 8), 2),
+                                  (1920, 1080, 40, (2.0, 8, 8), 2)], ids=str)
+def test_clahe_small_tiles_in_large_batches(ctx, case):
+    """Batches of small tiles let one tile-histogram workgroup walk several tiles (tile_hist_multi_kernel: chosen by tile size, or forced
+    through option "clahe_tiles_per_wg"), with and without the XCD-aware order (a 6 x 4 grid has none), padded geometry included:
+    every frame of the batch against the oracle."""
+    w, h, n, cfg, k = case
+    base = [synth.nv12_frame(w + (w & 1), h + (h & 1), synth.DISTS[i % 5], 2100 + i) for i in range(7)]
+    ys = np.stack([base[i % 7][: (w + (w & 1)) * (h + (h & 1))].reshape(h + (h & 1), w + (w & 1))[:h, :w] for i in range(n)])
+    ys = np.ascontiguousarray((ys.astype(np.uint16) + (np.arange(n, dtype=np.uint16) % 11)[:, None, None]).clip(0, 255).astype(np.uint8))
+    want = {}
+    try:
+        ctx.set_option("clahe_tiles_per_wg", k)
+        d_in = dev(ys)
+        d_out = torch.zeros_like(d_in)
+        ctx.clahe_batch_dev(d_in, d_out, w, h, n, *cfg)
+        ctx.synchronize()
+        out = d_out.cpu().numpy()
+        for i in range(n):
+            key = (i % 7, i % 11)
+            if key not in want:
+                want[key] = oracle.clahe(ys[i], *cfg)
+            assert np.array_equal(out[i], want[key]), (case, i)
+    finally:
+        ctx.set_option("clahe_tiles_per_wg", 0)
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.set_option("clahe_tiles_per_wg", 9)
+
+
 def test_contexts_and_pipes_release_their_device_memory():
     """Creating and destroying contexts, pipes and their scratch (fused hand-off block, ticket stamps, 16-bit CLAHE scratch, pipe
     frames, retired buffers of a captured context) gives the device memory back: 25 cycles must not move the free-memory mark."""
