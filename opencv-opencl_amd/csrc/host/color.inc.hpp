@@ -101,7 +101,7 @@ mi_status bgr_luma_dev(mi_ctx* c, hipStream_t s, const Color3Args& a, int op, do
                 if ((st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * tiles * S * 256 * sizeof(uint32_t)))) return st;
                 if ((st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)nf * tiles * 256))) return st;
                 uint8_t* direct = S == 1 ? c->d_luts : nullptr;
-                LAUNCH(c, s, MI_K_TILE_HIST, bgr_tile_hist_kernel, dim3(S, tiles, nf), dim3(kThreads), 0,
+                LAUNCH(c, s, MI_K_TILE_HIST, bgr_tile_hist_kernel<512>, dim3(S, tiles, nf), dim3(512), 0,
                        q.src, q.src_step, q.src_frame, g, c->d_partial, direct);
                 if (!direct)
                     LAUNCH(c, s, MI_K_TILE_LUT, tile_lut_kernel, dim3(tiles, nf), dim3(kThreads), 0, (const uint32_t*)c->d_partial, S, g, c->d_luts);

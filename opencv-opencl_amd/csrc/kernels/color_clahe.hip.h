@@ -36,27 +36,48 @@ __device__ __forceinline__ u32x4 bgr16_to_y(const uint8_t* p, u32x4* up, u32x4* 
     return y;
 }
 
-// pass 1: per-tile luma histogram partials straight from BGR.  grid = (S, tiles, n_frames), as tile_hist_kernel.
-__global__ __launch_bounds__(kThreads) void bgr_tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                                ClaheGeom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ luts)
+// pass 1: per-tile luma histogram partials straight from BGR.  grid = (S, tiles, n_frames), as tile_hist_kernel: NT = 512 threads
+// share the tile's histogram (32 waves per CU instead of 16), (row, slot) items are walked incrementally (no division per item),
+// two 48-byte items in flight per lane; waves 4..7 leave before the 256-thread fold / LUT stage.
+template <int NT>
+__global__ __launch_bounds__(NT) void bgr_tile_hist_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                          ClaheGeom g, uint32_t* __restrict__ partial, uint8_t* __restrict__ luts)
 {
     __shared__ uint32_t h[256 * kCopies];
     __shared__ uint32_t s_wave[4];
-    lds_hist_zero(h);
     const int t = threadIdx.x;
+    for (int i = t; i < 256 * kCopies; i += NT) h[i] = 0;
+    __syncthreads();
     const uint32_t copy = t & (kCopies - 1);
     const int S = gridDim.x, s = blockIdx.x, tile = blockIdx.y, f = blockIdx.z;
     const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
-    const uint8_t* src = src_base + (long long)f * frame_stride + (long long)tx * g.tile_w * 3;
     const int r0 = (int)((long long)g.tile_h * s / S), r1 = (int)((long long)g.tile_h * (s + 1) / S);
+    const uint8_t* src = src_base + (long long)f * frame_stride + (long long)tx * g.tile_w * 3 + (long long)(ty * g.tile_h + r0) * step;
     const int slots = g.tile_w >> 4;                               // 16-pixel groups per tile row (tile_w % 16 == 0)
-    const long long items = (long long)(r1 - r0) * slots;
-    for (long long it = t; it < items; it += kThreads) {
-        const int row = (int)(it / slots), slot = (int)(it - (long long)row * slots);
-        const u32x4 y = bgr16_to_y<false>(src + (long long)(ty * g.tile_h + r0 + row) * step + slot * 48, nullptr, nullptr);
-        hist_add_vec(h, y, copy);
+    const int items = (r1 - r0) * slots;                           // < 2^27: the tile area is < 2^31
+    int row = t / slots, slot = t - row * slots;
+    const int drow = NT / slots, dslot = NT - drow * slots;
+    auto item_ptr = [&]() -> const uint8_t* {
+        const uint8_t* p = src + (long long)row * step + slot * 48;
+        row += drow; slot += dslot;
+        if (slot >= slots) { slot -= slots; ++row; }
+        return p;
+    };
+    for (int it = t; it < items; it += 2 * NT) {
+        const uint8_t* p0 = item_ptr();
+        const uint8_t* p1 = item_ptr();
+        const bool two = it + NT < items;
+        const u32x4 y0 = bgr16_to_y<false>(p0, nullptr, nullptr);
+        if (two) {
+            const u32x4 y1 = bgr16_to_y<false>(p1, nullptr, nullptr);
+            hist_add_vec(h, y0, copy);
+            hist_add_vec(h, y1, copy);
+        } else {
+            hist_add_vec(h, y0, copy);
+        }
     }
     __syncthreads();
+    if (NT > kThreads && t >= kThreads) return;
     const uint32_t bin = lds_hist_bin(h, t);
     if (luts) luts[((size_t)f * gridDim.y + tile) * 256 + t] = tile_lut_value(bin, g, s_wave);     // one workgroup per tile: LUT in place
     else partial[(((size_t)f * gridDim.y + tile) * S + s) * 256 + t] = bin;
