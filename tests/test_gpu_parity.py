@@ -359,6 +359,32 @@ def test_large_and_degenerate_shapes(ctx):
     ctx.synchronize()
 
 
+def test_maximum_size_frame(ctx):
+    """The largest frame the interface admits: W*H just below 2^31 (OpenCV's `int total`), 2 GiB of pixels.  Every index in the host
+    form and the three-kernel path has to survive it, the counts reach 2^23 per bin and the LUT scale is 255 / (2^31 - ...) -- bit-exact
+    against the oracle, checked by CRC and on both ends of the plane."""
+    import zlib
+    side = 46336                                                    # 46336^2 = 2 147 024 896 < 2^31, a multiple of 16
+    rng = np.random.default_rng(99)
+    row = rng.integers(0, 256, (1024, side), dtype=np.uint8)
+    src = np.empty((side, side), np.uint8)
+    for y0 in range(0, side, 1024):                                 # 2 GiB of varied content without 2 GiB of random numbers
+        n = min(1024, side - y0)
+        np.add(row[:n], np.uint8((y0 // 1024) * 5), out=src[y0:y0 + n])      # wraps modulo 256
+    src[: side // 3] //= 3                                          # a dark third: the histogram is far from flat
+    want = oracle.equalize_hist(src)
+    got = ctx.equalize_hist(src)
+    assert np.array_equal(got[:64], want[:64]) and np.array_equal(got[-64:], want[-64:])
+    assert zlib.crc32(got) == zlib.crc32(want)
+    del got, want
+    # CLAHE 8 x 8 on the same plane: tiles of 5792 x 5792 pixels (33.5 M each: counts and clip limit far above 2^16)
+    want = oracle.clahe(src, 2.0, 8, 8)
+    got = ctx.clahe(src, 2.0, 8, 8)
+    assert np.array_equal(got[:64], want[:64]) and np.array_equal(got[-64:], want[-64:])
+    assert zlib.crc32(got) == zlib.crc32(want)
+    del got, want, src                                              # (one pixel more per side is refused: test_argument_errors)
+
+
 def test_argument_errors(ctx):
     d = torch.zeros(1024, dtype=torch.uint8, device="cuda:0")
     with pytest.raises(mi_lumaeq.MiError) as e:
