@@ -50,16 +50,23 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
             long long want = ((long long)c->cu_count * 4 + (long long)npairs * bands * nf - 1) / ((long long)npairs * bands * nf);
             const int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 16), 16LL}));
             if ((long long)npairs * bands * subs > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "16-bit CLAHE: tile grid too large");
-            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel, dim3((unsigned)(npairs * bands * subs), nf), dim3(kInterp16Threads),
-                   (size_t)kInterp16Entries * sizeof(uint2),
-                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
-                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts,
-                   (const Range16*)franges, subs);
-            // frames whose range does not fit the LDS table (their workgroups above returned at once); a no-op otherwise
-            const long long wide_items = (long long)((width + kThreads - 1) / kThreads) * height;
-            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_wide_kernel, dim3((unsigned)std::min<long long>(wide_items, std::max(512, 2048 / nf)), 1, nf), dim3(kThreads), 0,
-                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
-                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges);
+            const uint8_t* sp = src + (size_t)f0 * src_frame;
+            uint8_t* dp = dst + (size_t)f0 * dst_frame;
+            if (g.contract)
+                LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<true>, dim3((unsigned)(npairs * bands * subs), nf), dim3(kInterp16Threads),
+                       (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs);
+            else
+                LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<false>, dim3((unsigned)(npairs * bands * subs), nf), dim3(kInterp16Threads),
+                       (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs);
+            // IN-PLACE frames whose range does not fit the LDS table (their workgroups above returned at once); the launch is a no-op for
+            // every other frame, and is left out altogether when the call is not in place (it cost 8 us per call)
+            if (sp == dp) {
+                const long long wide_items = (long long)((width + kThreads - 1) / kThreads) * height;
+                LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_wide_kernel, dim3((unsigned)std::min<long long>(wide_items, std::max(512, 2048 / nf)), 1, nf), dim3(kThreads), 0,
+                       sp, (long long)src_step, (long long)src_frame, dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges);
+            }
         }
     }
     return MI_OK;

@@ -25,6 +25,7 @@ namespace mi {
 // =============================================================================================
 constexpr int kHist16 = 65536;
 constexpr int kHalf16 = 32768;
+constexpr int kInterp16F32Entries = 4096;                  // ... or 4096 entries of four floats
 constexpr int kInterp16Entries = 8192;               // LDS pair-table entries (64 KiB): two workgroups of 512 threads per CU
 constexpr int kInterp16Threads = 512;
 
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
 // of fixed columns -- column weights and ownership are lane constants -- and walks down the band's rows.  Ownership is decided by
 // the reference's own float expressions on ranges widened by a few pixels, so a pair / band edge can never be mis-assigned;
 // an 8-pixel group cut by a pair edge is visited by both neighbours, each storing only its own pixels.
+template <bool FMA>
 __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                          uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                          ClaheGeom g, const uint16_t* __restrict__ luts,
@@ -271,6 +273,11 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     // cannot be done in place: in-place calls with a wide range are left to clahe_interp16_wide_kernel.
     const bool multi = fr.hi - start >= (uint32_t)kInterp16Entries;
     if (multi && src_base == dst_base) return;
+    // A range of at most kInterp16F32Entries values (every 12-bit source) gets the table as FLOATS, {a, c, b, d} in 16 bytes: one
+    // ds_read_b128 per pixel feeds v_pk_mul / v_pk_add directly and the four ushort -> float conversions per pixel are gone
+    // (the blend was VALU-bound: ~25 instructions per pixel, now ~12).  Same 64 KiB of LDS either way.
+    const bool f32tab = fr.hi - start < (uint32_t)kInterp16F32Entries;
+    f32x4* const tabf = reinterpret_cast<f32x4*>(tab);
 
     // rows of the band (as clahe_interp_kernel): ideal range widened, then trimmed with the float expression
     const int y_lo_band = (int)max(0LL, ((long long)(2 * band - 1) * g.tile_h) / 2 - kBandMargin);
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const int nrows = max(0, y_hi_band - y_lo_band);
     int y_lo = y_lo_band + (int)((long long)nrows * sub / subs);
     int y_hi = y_lo_band + (int)((long long)nrows * (sub + 1) / subs);
-    auto ty1_of = [&](int y) { return floor_f32_to_int(tile_coord(y, g.inv_th, g.contract)); };
+    auto ty1_of = [&](int y) { return floor_f32_to_int(tile_coord<FMA>(y, g.inv_th)); };
     while (y_lo < y_hi && ty1_of(y_lo) != ty1u) ++y_lo;
     while (y_hi > y_lo && ty1_of(y_hi - 1) != ty1u) --y_hi;
     // columns of the pair, in 8-pixel groups
@@ -332,6 +339,17 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                 const uint32_t v = w0 + 4 * i;
                 const uint2 qa = *reinterpret_cast<const uint2*>(la + v), qb = *reinterpret_cast<const uint2*>(lb + v);
                 const uint2 qc = *reinterpret_cast<const uint2*>(lc + v), qd = *reinterpret_cast<const uint2*>(ld + v);
+                if (f32tab) {
+                    const uint32_t wa[2] = {qa.x, qa.y}, wb[2] = {qb.x, qb.y}, wc[2] = {qc.x, qc.y}, wd[2] = {qd.x, qd.y};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int sh = 16 * (k & 1);
+                        const f32x4 e = {(float)((wa[k >> 1] >> sh) & 0xffffu), (float)((wc[k >> 1] >> sh) & 0xffffu),
+                                         (float)((wb[k >> 1] >> sh) & 0xffffu), (float)((wd[k >> 1] >> sh) & 0xffffu)};      // {a, c, b, d}
+                        tabf[4 * i + k] = e;
+                    }
+                    continue;
+                }
                 uint2 e0, e1, e2, e3;
                 e0.x = (qa.x & 0xffffu) | (qb.x << 16);        e0.y = (qc.x & 0xffffu) | (qd.x << 16);
                 e1.x = (qa.x >> 16) | (qb.x & 0xffff0000u);    e1.y = (qc.x >> 16) | (qd.x & 0xffff0000u);
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
             uint32_t own = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float txf = tile_coord(x0 + j, g.inv_tw, g.contract);
+                const float txf = tile_coord<FMA>(x0 + j, g.inv_tw);
                 const int txu = floor_f32_to_int(txf);
                 xa[j] = __fsub_rn(txf, (float)txu);
                 xa1[j] = __fsub_rn(1.0f, xa[j]);
@@ -361,15 +379,35 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
             const bool aligned = ((((uintptr_t)src | (uintptr_t)dst | (unsigned long long)src_step | (unsigned long long)dst_step) & 15) == 0);
             const bool vec_ok = own == 0xffu && aligned && !multi;
             auto blend_row = [&](int y, const uint32_t* px, uint32_t* res) {
-                const float tyf = tile_coord(y, g.inv_th, g.contract);
+                const float tyf = tile_coord<FMA>(y, g.inv_th);
                 const float ya = __fsub_rn(tyf, (float)ty1u), ya1 = __fsub_rn(1.0f, ya);
+                if (f32tab) {
+                    const f32x2 yv = {ya1, ya};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t idx = min(px[j] - w0, (uint32_t)kInterp16F32Entries - 1);
+                        const f32x4 e = tabf[idx];
+                        const f32x2 ac = {e.x, e.y}, bd = {e.z, e.w}, xw = {xa1[j], xa[j]};
+                        float r;
+                        if (FMA) {
+                            const f32x2 tb = pk_fma_bcast_lo(ac, xw, pk_mul_bcast_hi(bd, xw));       // {fma(a,xa1,b*xa), fma(c,xa1,d*xa)}
+                            r = __fmaf_rn(tb.x, ya1, __fmul_rn(tb.y, ya));
+                        } else {
+                            const f32x2 tb = (pk_mul_bcast_lo(ac, xw) + pk_mul_bcast_hi(bd, xw)) * yv; // nine individually rounded operations
+                            r = __fadd_rn(tb.x, tb.y);
+                        }
+                        const int ri = __float2int_rn(r);
+                        res[j] = (uint32_t)(ri < 0 ? 0 : (ri > 65535 ? 65535 : ri));
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     // owned pixels of this window index the table directly; anything else is masked out later: clamp its index
                     const uint32_t idx = min(px[j] - w0, (uint32_t)kInterp16Entries - 1);
                     const uint2 e = tab[idx];
                     const float a = (float)(e.x & 0xffffu), b = (float)(e.x >> 16), c = (float)(e.y & 0xffffu), d = (float)(e.y >> 16);
-                    int r = __float2int_rn(g.contract ? clahe_blend_f<true>(a, b, c, d, xa[j], xa1[j], ya, ya1) : clahe_blend_f<false>(a, b, c, d, xa[j], xa1[j], ya, ya1));
+                    int r = __float2int_rn(clahe_blend_f<FMA>(a, b, c, d, xa[j], xa1[j], ya, ya1));
                     res[j] = (uint32_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
                 }
             };
