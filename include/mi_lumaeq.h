@@ -300,6 +300,8 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * "fused_fault_inject" (test hook, 0..3), "clahe_float_tables" (1/0),
  * "clahe_xcd_map" (1/0, default 1: XCD-aware tile order of the CLAHE tile-histogram pass; speed only),
  * "clahe_hist_threads" (256 / 512, default 512: threads per tile-histogram workgroup; speed only),
+ * "clahe_seg_pairs" (4..15, default 9: pairs per LDS float table when a grid of more than 14 tiles across is cut into column
+ * segments; speed only),
  * "clahe_tiles_per_wg" (0..8, default 0 = by tile size: tiles one tile-histogram workgroup walks in large batches of small
  * tiles -- two below ~24 K pixels per tile, e.g. 720p 8x8; speed only),
  * "bgr_fused" (1/0, default 1: mi_bgr_luma_op_u8c3 runs as two passes over the interleaved image instead of through

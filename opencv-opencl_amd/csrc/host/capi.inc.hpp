@@ -200,6 +200,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "bgr_fused")) { c->bgr_fused = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_hist_threads")) { if (value != 256 && value != 512) return fail(c, MI_ERR_BAD_ARG, "clahe_hist_threads must be 256 or 512"); c->clahe_hist_threads = value; return MI_OK; }
     if (!strcmp(name, "clahe_tiles_per_wg")) { if (value < 0 || value > 8) return fail(c, MI_ERR_BAD_ARG, "clahe_tiles_per_wg must be 0..8"); c->clahe_tiles_per_wg = value; return MI_OK; }
+    if (!strcmp(name, "clahe_seg_pairs")) { if (value < 4 || value > 15) return fail(c, MI_ERR_BAD_ARG, "clahe_seg_pairs must be 4..15"); c->clahe_seg_pairs = value; return MI_OK; }
     if (!strcmp(name, "clahe_xcd_map")) { c->clahe_xcd_map = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
     if (!strcmp(name, "host_direct")) { c->host_direct = value != 0; return MI_OK; }

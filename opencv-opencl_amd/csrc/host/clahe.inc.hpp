@@ -98,7 +98,23 @@ mi_status launch_interp(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const Clah
     const int npairs = g.tiles_x + 1;
     if (npairs <= kMaxPairsLds) {
         const int ngroups = (a.width + kInterpPx - 1) / kInterpPx;
-        const int groups = std::min(ngroups, kThreads);
+        int groups = std::min(ngroups, kThreads);
+        // float tables hold kMaxPairsLdsF32 pairs.  A wider grid still gets them when the frame is cut into column segments narrow
+        // enough to touch few pairs: a span of G groups touches at most floor(16 G / tile_w) + 2 pairs (+ 1 of slack for the float
+        // expression that decides them).  Segment tables of 9 pairs (36 KiB, four workgroups per CU like the 8 x 8 case) measured best
+        // (profiles/r02_s_clahe_ab_seg_pairs.txt: interpolation of 4K 16x16 327 -> 284 us, 1080p 16x16 317 -> 294, 4K 32x32 338 -> 299
+        // against the uchar-quad tables; 15 pairs = 60 KiB = two workgroups per CU is SLOWER than the quads); below ~40 groups per
+        // segment (tiles narrower than ~110 pixels: 720p 16x16 365 -> 386) the quads stay.
+        bool seg_tables = false;
+        const int seg_cap = std::max(4, std::min(c->clahe_seg_pairs, kMaxPairsLdsF32));      // pairs per segment table (4 KiB of LDS each)
+        if (npairs > kMaxPairsLdsF32 && c->clahe_float_tables) {
+            const int gmax = (int)(((long long)(seg_cap - 3) * g.tile_w) / kInterpPx);
+            if (gmax >= 40) {                                 // equal segments: a short last one would leave most of its workgroups idle
+                const int nseg = (ngroups + std::min(groups, gmax) - 1) / std::min(groups, gmax);
+                groups = (ngroups + nseg - 1) / nseg;
+                seg_tables = true;
+            }
+        }
         const int segs = (ngroups + groups - 1) / groups;
         const int bands = g.tiles_y + 1;
         long long want = ((long long)c->cu_count * 8 + (long long)bands * nf * segs - 1) / ((long long)bands * nf * segs);
@@ -106,14 +122,15 @@ mi_status launch_interp(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const Clah
         int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, rows_per_band / 8), 64LL}));
         if ((long long)bands * subs > 0x7fffffffLL || segs > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "image too wide");
         const dim3 grid(bands * subs, nf, segs);
-        if (npairs <= kMaxPairsLdsF32 && c->clahe_float_tables) {
-            const size_t lds = (size_t)npairs * 256 * 4 * sizeof(float);
-            if (g.contract) LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<true, true>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv);
-            else            LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<true, false>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv);
+        if ((npairs <= kMaxPairsLdsF32 || seg_tables) && c->clahe_float_tables) {
+            const int cap = seg_tables ? seg_cap : kMaxPairsLdsF32;
+            const size_t lds = (size_t)std::min(npairs, cap) * 256 * 4 * sizeof(float);
+            if (g.contract) LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<true, true>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv, cap);
+            else            LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<true, false>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv, cap);
         } else {
             const size_t lds = (size_t)npairs * 256 * sizeof(uint32_t);
-            if (g.contract) LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<false, true>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv);
-            else            LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<false, false>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv);
+            if (g.contract) LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<false, true>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv, kMaxPairsLds + 1);
+            else            LAUNCH(c, s, MI_K_CLAHE_INTERP, (clahe_interp_kernel<false, false>), grid, dim3(kThreads), lds, p, g, d_luts, subs, groups, uv, kMaxPairsLds + 1);
         }
     } else {
         if (a.height > kMaxGridY) return fail(c, MI_ERR_UNSUPPORTED, "height > 65535 with tiles_x > 62");

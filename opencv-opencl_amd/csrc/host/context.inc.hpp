@@ -75,6 +75,7 @@ struct mi_ctx {
     int clahe16_transposed = 0;                                  // option "clahe16_transposed": value-major LUTs for 16-bit interpolation (tiles <= 64)
     int clahe_hist_threads = 512;                                // option "clahe_hist_threads": 256 or 512 threads per tile-histogram workgroup
     int clahe_tiles_per_wg = 0;                                  // option "clahe_tiles_per_wg": tiles a tile-histogram workgroup walks in batches (0 = by tile size, 1, 2, 4, 8)
+    int clahe_seg_pairs = 9;                                     // option "clahe_seg_pairs": pairs per float table when a wide grid is cut into column segments (4..15)
     int clahe_xcd_map = 1;                                       // option "clahe_xcd_map": XCD-aware tile order of the tile histogram pass
     int clahe_float_tables = 1;                                  // option "clahe_float_tables": f32 pair tables in LDS (tiles_x <= 14)
     uint8_t*  d_stage_in = nullptr;  size_t stage_in_bytes = 0;  // device frame for the host-pointer forms

@@ -373,9 +373,13 @@ __device__ __forceinline__ u32x4 clahe_vec16_f32(const f32x4* quadf, u32x4 q, co
     return o;
 }
 
+// pair_cap: pairs the LDS table holds.  With tiles_x + 1 <= pair_cap the table covers every pair of the frame; otherwise each column
+// segment (blockIdx.z, `groups` 16-pixel groups wide -- the host sizes it so that a segment touches at most pair_cap pairs) stages only
+// the pairs ITS columns use, first pair = p0 below, and the float tables serve grids of up to 63 tiles across (16 x 16 on 4K: the
+// interpolation 322 -> see DESIGN.md).
 template <bool FT, bool FMA>
 __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, ClaheGeom g, const uint8_t* __restrict__ luts,
-                                                               int subs, int groups, UVJob uv)
+                                                               int subs, int groups, UVJob uv, int pair_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t quad[];   // [(tiles_x + 1)][256] u32 quads, or f32x4 when FT
     f32x4* quadf = reinterpret_cast<f32x4*>(quad);
@@ -388,9 +392,16 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
     const uint8_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * 256;
     const uint8_t* l1 = lf + (size_t)ty1 * g.tiles_x * 256;
     const uint8_t* l2 = lf + (size_t)ty2 * g.tiles_x * 256;
-    const int npairs = g.tiles_x + 1;
+    int p0 = 0, npairs = g.tiles_x + 1;
+    if (npairs > pair_cap) {                                  // the pairs of this column segment only
+        const int xs = (int)blockIdx.z * groups * kInterpPx;
+        const int xe = min(g.width, xs + groups * kInterpPx) - 1;
+        auto pair_of = [&](int x) { const int q = floor_f32_to_int(tile_coord<FMA>(x, g.inv_tw)) + 1; return q < 0 ? 0 : (q > g.tiles_x ? g.tiles_x : q); };
+        p0 = pair_of(xs);
+        npairs = min(pair_of(max(xe, xs)) - p0 + 1, pair_cap);
+    }
     for (int i = t; i < npairs * 256; i += kThreads) {
-        const int pr = i >> 8, v = i & 255;
+        const int pr = p0 + (i >> 8), v = i & 255;
         const int ta = max(pr - 1, 0), tb = min(pr, g.tiles_x - 1);
         if (FT) {
             const f32x4 e = {(float)l1[ta * 256 + v], (float)l2[ta * 256 + v], (float)l1[tb * 256 + v], (float)l2[tb * 256 + v]};   // {a, c, b, d}
@@ -426,6 +437,8 @@ __global__ __launch_bounds__(kThreads) void clahe_interp_kernel(PlaneBatch p, Cl
             xw[j].x = xa1[j]; xw[j].y = xa[j];
             int pr = tx1 + 1;                                  // pair index; columns beyond the frame are never used
             pr = pr < 0 ? 0 : (pr > g.tiles_x ? g.tiles_x : pr);
+            pr -= p0;                                          // position in this workgroup's table
+            pr = pr < 0 ? 0 : (pr >= npairs ? npairs - 1 : pr);
             poff[j] = pr << 8;
         }
         const uint8_t* src = p.src + (long long)f * p.src_frame;

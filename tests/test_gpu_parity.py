@@ -195,6 +195,38 @@ def test_clahe_host_form(ctx, shape, cfg):
         assert np.array_equal(ctx.clahe(src, clip, tx, ty), oracle.clahe(src, clip, tx, ty)), dist
 
 
+@pytest.mark.parametrize("case", [(3840, 2160, 16, 16), (3840, 2160, 32, 8), (3840, 2160, 60, 4), (1920, 1080, 24, 5), (1919, 1079, 20, 7),
+                                  (1919, 1079, 16, 7), (4097, 64, 48, 2), (4097, 64, 20, 2), (1280, 720, 63, 3)], ids=str)
+def test_clahe_wide_tile_grids(ctx, case):
+    """Grids of more than 14 tiles across: the float pair tables are staged per COLUMN SEGMENT (each segment only the pairs its
+    columns use), down to tiles of ~20 pixels; narrower tiles take the uchar-quad tables.  Host form and batch form, both table
+    kinds, against the oracle."""
+    w, h, tx, ty = case
+    src = synth.y_plane(w, h, "D2", 41)
+    want = oracle.clahe(src, 2.0, tx, ty)
+    try:
+        for ft, pairs in ((1, 9), (1, 4), (1, 15), (0, 9)):
+            ctx.set_option("clahe_float_tables", ft)
+            ctx.set_option("clahe_seg_pairs", pairs)               # pairs per segment table (speed only)
+            assert np.array_equal(ctx.clahe(src, 2.0, tx, ty), want), (case, ft, pairs)
+        ctx.set_option("clahe_float_tables", 1)
+        ctx.set_option("clahe_seg_pairs", 9)
+        if w % 2 == 0 and h % 2 == 0:
+            frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k], 300 + k) for k in range(3)])
+            d_in = dev(frames)
+            d_out = torch.zeros_like(d_in)
+            ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, 3, mi_lumaeq.UV_COPY, 3.0, tx, ty)
+            ctx.synchronize()
+            out = d_out.cpu().numpy()
+            for k in range(3):
+                assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=1, op=1, clip_limit=3.0, tiles_x=tx, tiles_y=ty)), (case, k)
+    finally:
+        ctx.set_option("clahe_float_tables", 1)
+        ctx.set_option("clahe_seg_pairs", 9)
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.set_option("clahe_seg_pairs", 16)
+
+
 def test_clahe_kats(ctx):
     assert (ctx.clahe(np.full((4, 4), 7, np.uint8), 2.0, 1, 1) == 32).all()             # CL-1
     rng = np.random.default_rng(5)
