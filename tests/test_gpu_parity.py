@@ -59,6 +59,43 @@ def test_equalize_strided_roi_and_inplace(ctx):
     assert np.array_equal(buf, want)
 
 
+@pytest.mark.parametrize("pitch", [320, 336, 300, 4096], ids=str)
+def test_equalize_roi_views_by_pitch(ctx, pitch):
+    """ROI views by row pitch: a pitch that is a multiple of 16 takes the band walk of the three-kernel path (all rows share one alignment
+    phase: vectors over (row, slot) items, head / tail bytes apart), any other pitch the row-by-row walk; origins at every alignment,
+    widths shorter than a vector, in place, and a device batch with separate source / destination pitches."""
+    rng = np.random.default_rng(pitch)
+    rows = 97
+    big = rng.integers(0, 256, (rows, pitch), dtype=np.uint8)
+    big[:, : pitch // 2] //= 2
+    for x0, wv in ((0, min(pitch, 256)), (1, 254), (15, 33), (16, 17), (21, min(pitch - 21, 277)), (5, 9), (pitch - 20, 20)):
+        view = big[3:rows - 2, x0:x0 + wv]
+        want = oracle.equalize_hist(view)
+        assert np.array_equal(ctx.equalize_hist(view), want), (pitch, x0, wv)
+        buf = big.copy()
+        bview = buf[3:rows - 2, x0:x0 + wv]
+        ctx.equalize_hist(bview, bview)                                  # in place, strided
+        assert np.array_equal(bview, want), (pitch, x0, wv)
+        untouched = np.ones_like(buf, dtype=bool)
+        untouched[3:rows - 2, x0:x0 + wv] = False
+        assert np.array_equal(buf[untouched], big[untouched]), (pitch, x0, wv)
+    # device batch: source pitch `pitch`, destination pitch pitch + 16 (same phase class) and pitch + 5 (not)
+    n, w, h = 5, min(pitch - 29, 501), 61
+    src = rng.integers(0, 200, (n, h + 6, pitch), dtype=np.uint8)
+    d_src = dev(src)
+    for dpitch in (pitch + 16, pitch + 5):
+        d_dst = torch.zeros((n, h + 6, dpitch), dtype=torch.uint8, device="cuda:0")
+        so, do = 2 * pitch + 29, 3 * dpitch + 7
+        ctx.equalize_hist_batch_dev(d_src.data_ptr() + so, d_dst.data_ptr() + do, w, h, n, src_step=pitch, src_frame=(h + 6) * pitch,
+                                    dst_step=dpitch, dst_frame=(h + 6) * dpitch)
+        ctx.synchronize()
+        out = d_dst.cpu().numpy()
+        for k in range(n):
+            want = oracle.equalize_hist(src[k, 2:2 + h, 29:29 + w])
+            assert np.array_equal(out[k, 3:3 + h, 7:7 + w], want), (pitch, dpitch, k)
+            assert out[k, :3].sum() == 0 and out[k, 3:3 + h, :7].sum() == 0 and out[k, 3:3 + h, 7 + w:].sum() == 0
+
+
 @pytest.mark.parametrize("wh", [(1920, 1080), (3840, 2160)], ids=str)
 @pytest.mark.parametrize("dist", synth.DISTS)
 def test_equalize_full_size_frames(ctx, wh, dist):
