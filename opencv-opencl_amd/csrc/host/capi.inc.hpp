@@ -44,12 +44,16 @@ static int contract_probe()
     int v = g_contract_ok.load();
     if (v != 0) return v;
     float* d = nullptr;
-    float h = 1.0f;
+    float* hp = nullptr;                                          // pinned, like every host buffer this library gives the runtime
     if (hipMalloc((void**)&d, sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipHostMalloc((void**)&hp, sizeof(float), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return 0; }
+    *hp = 1.0f;
     const float a = 1.0f + 1.0f / 4096.0f;
     hipLaunchKernelGGL(contract_probe_kernel, dim3(1), dim3(1), 0, nullptr, a, a, -(1.0f + 1.0f / 2048.0f), d);
-    const bool ran = hipGetLastError() == hipSuccess && hipMemcpy(&h, d, sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    const bool ran = hipGetLastError() == hipSuccess && hipMemcpy(hp, d, sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    const float h = *hp;
     (void)hipFree(d);
+    (void)hipHostFree(hp);
     if (!ran) { (void)hipGetLastError(); return 0; }
     v = h == 0.0f ? 1 : -1;
     g_contract_ok.store(v);
