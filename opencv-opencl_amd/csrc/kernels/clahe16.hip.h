@@ -68,6 +68,38 @@ __device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, in
     hist16_add_dword(h16, q.z, half, lmin, lmax); hist16_add_dword(h16, q.w, half, lmin, lmax);
 }
 
+// OPTIMISTIC sweep (vector path): count every pixel at (value & 32767) without asking which half it belongs to, and track the range
+// with packed 16-bit min / max (one v_pk_min_u16 / v_pk_max_u16 per TWO pixels).  If the tile turns out to hold a value >= 32768 the
+// counters have aliased and the careful two-sweep code below starts over; for everything up to 15 bits -- all video -- this sweep is
+// the whole job at ~4 VALU instructions per pixel instead of ~14 (no per-pixel half test, no divergent branch around the ds_add).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hist16_fast_dword(uint32_t* h16, uint32_t w, u16x2& pmin, u16x2& pmax)
+{
+    const u16x2 v = __builtin_bit_cast(u16x2, w);
+    pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
+    lds_inc(h16, w & (kHalf16 - 1));
+    lds_inc(h16, (w >> 16) & (kHalf16 - 1));
+}
+__device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u16x2& pmin, u16x2& pmax)
+{
+    const uint32_t v0 = q.x & 0xffffu;
+    const bool flat = q.x == q.y && q.y == q.z && q.z == q.w && v0 == (q.x >> 16);
+    if (__builtin_expect(flat, 0)) {                                // as hist16_add_vec: flat regions never reach the LDS pixel by pixel
+        const u16x2 v = __builtin_bit_cast(u16x2, q.x);
+        pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
+        const unsigned long long active = __ballot(1);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
+        if (__ballot(v0 == first) == active) {
+            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(active)) lds_add(h16, v0 & (kHalf16 - 1), 8u * (uint32_t)__builtin_popcountll(active));
+        } else {
+            lds_add(h16, v0 & (kHalf16 - 1), 8u);
+        }
+        return;
+    }
+    hist16_fast_dword(h16, q.x, pmin, pmax); hist16_fast_dword(h16, q.y, pmin, pmax);
+    hist16_fast_dword(h16, q.z, pmin, pmax); hist16_fast_dword(h16, q.w, pmin, pmax);
+}
+
 // grid = (tiles, frames), 1024 threads, 128 KiB dynamic LDS.  steps in BYTES.
 // `vec` (host: no REFLECT_101 padding, tile_w % 8 == 0, 16-B aligned rows): a lane takes 8 pixels per 16-byte load with
 // four loads in flight; otherwise one pixel per lane per step with index reflection.
@@ -95,6 +127,44 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
     auto vadd = [&](const u32x4& q, int half) { hist16_add_vec(h16, q, half, lmin, lmax); };
     if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
     uint32_t lo = 0, hi = 0;
+    bool range_known = false;
+    if (vec) {                                                    // optimistic sweep, see hist16_fast_vec
+        for (int i = t; i < kHalf16 / 4; i += 1024) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        u16x2 pmin = {0xffff, 0xffff}, pmax = {0, 0};
+        int row = t / slots, slot = t - row * slots;
+        const int vdrow = 1024 / slots, vdslot = 1024 - vdrow * slots;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (int it = t; it < vitems; it += 4 * 1024) {           // (row, slot) items walked incrementally, four predicated loads in flight
+            u32x4 q[4]; bool qv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                qv[k] = it + k * 1024 < vitems;
+                const u32x4* ptr = reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
+                q[k] = qv[k] ? *ptr : zero;
+                row += vdrow; slot += vdslot;
+                if (slot >= slots) { slot -= slots; ++row; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (qv[k]) hist16_fast_vec(h16, q[k], pmin, pmax);
+        }
+        lmin = min((uint32_t)pmin.x, (uint32_t)pmin.y); lmax = max((uint32_t)pmax.x, (uint32_t)pmax.y);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64)); }
+        if ((t & 63) == 0) {
+            __hip_atomic_fetch_min(&s_lo, lmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&s_hi, lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        lo = s_lo; hi = s_hi;
+        if (hi < kHalf16) {                                       // nothing aliased: the counters are the histogram
+            for (uint32_t i = (lo & ~3u) + (uint32_t)t; i <= hi; i += 1024) out[i] = h16[i];
+            if (t == 0) { Range16 r; r.lo = lo; r.hi = hi; ranges[tile_id] = r; }
+            return;
+        }
+        range_known = true;                                       // a value >= 32768: start over, one half of the value range per sweep
+        __syncthreads();
+    }
     for (int half = 0; half < 2; ++half) {
         for (int i = t; i < kHalf16; i += 1024) h16[i] = 0;
         __syncthreads();
@@ -117,7 +187,7 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
                 if (col >= g.tile_w) { col -= g.tile_w; ++row; }
             }
         }
-        if (half == 0) {                                          // the tile's range is known after the first sweep
+        if (half == 0 && !range_known) {                          // the tile's range is known after the first sweep
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64)); }
             if ((t & 63) == 0) {
