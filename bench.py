@@ -583,9 +583,9 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     # a photo-like scene instead of noise (mi_lumaeq.synth.photo_like: piecewise-smooth gradients, flat and saturated regions, tiled
     # to 4K with a different window per frame): hot histogram bins, smooth neighbourhoods (LDS broadcasts in the CLAHE gather)
     yp = synth.photo_like(1919, 1079, 20261004)
-    reps = (-(-(h + 13 * 32) // yp.shape[0]), -(-(w + 29 * 32) // yp.shape[1]))
+    Bp = args.batch                                           # the headline's batch size, so that only the content differs
+    reps = (-(-(h + 13 * Bp) // yp.shape[0]), -(-(w + 29 * Bp) // yp.shape[1]))
     big = np.tile(yp, reps)
-    Bp = 32
     fr = np.empty((Bp, w * h * 3 // 2), np.uint8)
     for k in range(Bp):                                        # every frame a different window of the tiling
         fr[k, : w * h] = big[13 * k: 13 * k + h, 29 * k: 29 * k + w].reshape(-1)
