@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../opencv-opencl_amd/cxx/mi_cv.hpp"
@@ -261,6 +262,33 @@ int main()
         EXPECT(oks.size() == (size_t)N && oks[2] == 0 && oks[0] == 1 && oks[5] == 1);
         orc_nv12_frame(in[5].data(), ref.data(), W, H, 0, 0, 0.0, 0, 0);
         EXPECT(memcmp(out[5].data(), ref.data(), ysz + uvsz) == 0);
+    }
+    // --- the reference's worker pattern without the pool (OpenCVequalHist.cpp:397-402: 1..8 threads, each calling cv::equalizeHist on
+    //     its own Mats; clahevideo.cpp: one CLAHE object per thread): equalizeHist is re-entrant across threads, distinct CLAHE objects
+    //     are independent.  Eight threads -> eight per-thread contexts on one device (four get the fused kernel, four the three-kernel
+    //     path, kMaxFusedCtxPerDevice): every result against the oracle.
+    {
+        const int T = 8, ITER = 12;
+        std::vector<int> bad(T, 0);
+        std::vector<std::thread> th;
+        for (int w = 0; w < T; ++w)
+            th.emplace_back([&, w] {
+                try {
+                    std::vector<uint8_t> src(ysz), want(ysz), want_c(ysz);
+                    Ptr<CLAHE> clahe = createCLAHE(2.0 + w, Size(8, 8));
+                    for (int it = 0; it < ITER; ++it) {
+                        fill(src, 9000 + 100 * w + it);
+                        Mat y_in(H, W, CV_8UC1, src.data()), y_out, y_cl;
+                        equalizeHist(y_in, y_out);
+                        clahe->apply(y_in, y_cl);
+                        orc_equalize_hist_u8(src.data(), W, want.data(), W, W, H);
+                        orc_clahe_u8(src.data(), W, want_c.data(), W, W, H, 2.0 + w, 8, 8);
+                        if (memcmp(y_out.data, want.data(), ysz) != 0 || memcmp(y_cl.data, want_c.data(), ysz) != 0) ++bad[w];
+                    }
+                } catch (const std::exception& e) { printf("thread %d: %s\n", w, e.what()); bad[w] = 1000; }
+            });
+        for (auto& t : th) t.join();
+        for (int w = 0; w < T; ++w) EXPECT(bad[w] == 0);
     }
     printf(failures ? "test_adapter: %d FAILURES\n" : "test_adapter: all checks passed\n", failures);
     return failures ? 1 : 0;
