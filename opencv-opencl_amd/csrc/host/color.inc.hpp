@@ -193,8 +193,11 @@ mi_status cvt420_dev(mi_ctx* c, hipStream_t s, int code, const uint8_t* src, uin
         j.width = width; j.height = height;
         long long bx = ((long long)c->cu_count * 8 + nf - 1) / nf;
         bx = std::max<long long>(1, std::min<long long>(bx, (blocks + kThreads - 1) / kThreads));
-        if (enc) LAUNCH(c, s, MI_K_COLOR, cvt420_kernel<0>, dim3((unsigned)bx, nf), dim3(kThreads), 0, j);
-        else     LAUNCH(c, s, MI_K_COLOR, cvt420_kernel<1>, dim3((unsigned)bx, nf), dim3(kThreads), 0, j);
+        // 16 x 2 pixel groups per lane with 16-byte accesses when everything is 16-byte aligned, else 2 x 2 blocks with byte accesses
+        const int vec = width % 16 == 0 && (((uintptr_t)j.src | (uintptr_t)j.dst | c3_step | c3_frame | planar_frame) & 15) == 0;
+        if (vec) bx = std::max<long long>(1, std::min<long long>(bx, (blocks / 8 + kThreads - 1) / kThreads));
+        if (enc) LAUNCH(c, s, MI_K_COLOR, cvt420_kernel<0>, dim3((unsigned)bx, nf), dim3(kThreads), 0, j, vec);
+        else     LAUNCH(c, s, MI_K_COLOR, cvt420_kernel<1>, dim3((unsigned)bx, nf), dim3(kThreads), 0, j, vec);
     }
     return MI_OK;
 }

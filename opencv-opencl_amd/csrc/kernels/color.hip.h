@@ -420,11 +420,84 @@ struct Cvt420Job {
     int width, height;
 };
 
+// 16 BGR pixels packed into 48 bytes (three 16-byte stores; p 16-byte aligned)
+__device__ __forceinline__ void store_bgr16(uint8_t* p, const uint32_t* b, const uint32_t* g, const uint32_t* r)
+{
+    uint32_t w[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) w[k] = 0;
+#pragma unroll
+    for (int px = 0; px < 16; ++px) {
+        w[(3 * px) >> 2] |= b[px] << (8 * ((3 * px) & 3));
+        w[(3 * px + 1) >> 2] |= g[px] << (8 * ((3 * px + 1) & 3));
+        w[(3 * px + 2) >> 2] |= r[px] << (8 * ((3 * px + 2) & 3));
+    }
+    u32x4* dp = reinterpret_cast<u32x4*>(p);
+    const u32x4 r0 = {w[0], w[1], w[2], w[3]}, r1 = {w[4], w[5], w[6], w[7]}, r2 = {w[8], w[9], w[10], w[11]};
+    dp[0] = r0; dp[1] = r1; dp[2] = r2;
+}
+
+// `vec` (host: width % 16 == 0, every base / pitch / frame stride a multiple of 16): a lane owns a 16 x 2 pixel group -- six 16-byte
+// loads of BGR (or two of luma and one of chroma) and 16- / 8-byte stores -- instead of one 2 x 2 block with byte accesses
+// (4K, 16 frames: 2.2 -> 5.5 TB/s of the 4.5 B/px for BGR2YUV_I420, 2.4 -> 4.1 for YUV2BGR_NV12).
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void cvt420_kernel(Cvt420Job j)
+__global__ __launch_bounds__(kThreads) void cvt420_kernel(Cvt420Job j, int vec)
 {
     const int f = blockIdx.y, bx_n = j.width >> 1;
     const long long blocks = (long long)bx_n * (j.height >> 1), ysz = (long long)j.width * j.height;
+    if (vec) {
+        const int gx_n = j.width >> 4;
+        const int groups = gx_n * (j.height >> 1);
+        const int stride = (int)gridDim.x * kThreads, dby = stride / gx_n, dgx = stride - dby * gx_n;
+        int gi = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+        int by = gi / gx_n, gx = gi - by * gx_n;
+        for (; gi < groups; gi += stride, by += dby, gx += dgx) {
+            if (gx >= gx_n) { gx -= gx_n; ++by; }
+            if (MODE == 0) {
+                const uint8_t* r0 = j.src + (long long)f * j.c3_frame + (long long)(2 * by) * j.c3_step + 48 * gx;
+                uint8_t* pl = j.dst + (long long)f * j.planar_frame;
+                uint32_t b0[16], g0[16], q0[16], b1[16], g1[16], q1[16];
+                load_bgr16(r0, b0, g0, q0);
+                load_bgr16(r0 + j.c3_step, b1, g1, q1);
+                uint32_t y0[4] = {0, 0, 0, 0}, y1[4] = {0, 0, 0, 0}, uu[2] = {0, 0}, vv[2] = {0, 0};
+#pragma unroll
+                for (int px = 0; px < 16; ++px) {
+                    y0[px >> 2] |= bt601_y(b0[px], g0[px], q0[px]) << (8 * (px & 3));
+                    y1[px >> 2] |= bt601_y(b1[px], g1[px], q1[px]) << (8 * (px & 3));
+                    if ((px & 1) == 0) {                           // chroma from the top-left pixel of each 2 x 2 block
+                        uint32_t U, V;
+                        bt601_uv(b0[px], g0[px], q0[px], U, V);
+                        uu[px >> 3] |= U << (8 * ((px >> 1) & 3)); vv[px >> 3] |= V << (8 * ((px >> 1) & 3));
+                    }
+                }
+                const u32x4 o0 = {y0[0], y0[1], y0[2], y0[3]}, o1 = {y1[0], y1[1], y1[2], y1[3]};
+                *reinterpret_cast<u32x4*>(pl + (long long)(2 * by) * j.width + (gx << 4)) = o0;
+                *reinterpret_cast<u32x4*>(pl + (long long)(2 * by + 1) * j.width + (gx << 4)) = o1;
+                uint8_t* uo = pl + ysz + (long long)by * bx_n + (gx << 3);
+                *reinterpret_cast<uint2*>(uo) = make_uint2(uu[0], uu[1]);
+                *reinterpret_cast<uint2*>(uo + (ysz >> 2)) = make_uint2(vv[0], vv[1]);
+            } else {
+                const uint8_t* pl = j.src + (long long)f * j.planar_frame;
+                const u32x4 y0 = *reinterpret_cast<const u32x4*>(pl + (long long)(2 * by) * j.width + (gx << 4));
+                const u32x4 y1 = *reinterpret_cast<const u32x4*>(pl + (long long)(2 * by + 1) * j.width + (gx << 4));
+                const u32x4 uv = *reinterpret_cast<const u32x4*>(pl + ysz + (long long)by * j.width + (gx << 4));
+                uint32_t b0[16], g0[16], q0[16], b1[16], g1[16], q1[16];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int ruv, guv, buv;
+                    bt601_uv_terms(byte_of(uv, 2 * k), byte_of(uv, 2 * k + 1), ruv, guv, buv);
+                    bt601_px_bgr(byte_of(y0, 2 * k), ruv, guv, buv, b0[2 * k], g0[2 * k], q0[2 * k]);
+                    bt601_px_bgr(byte_of(y0, 2 * k + 1), ruv, guv, buv, b0[2 * k + 1], g0[2 * k + 1], q0[2 * k + 1]);
+                    bt601_px_bgr(byte_of(y1, 2 * k), ruv, guv, buv, b1[2 * k], g1[2 * k], q1[2 * k]);
+                    bt601_px_bgr(byte_of(y1, 2 * k + 1), ruv, guv, buv, b1[2 * k + 1], g1[2 * k + 1], q1[2 * k + 1]);
+                }
+                uint8_t* d0 = j.dst + (long long)f * j.c3_frame + (long long)(2 * by) * j.c3_step + 48 * gx;
+                store_bgr16(d0, b0, g0, q0);
+                store_bgr16(d0 + j.c3_step, b1, g1, q1);
+            }
+        }
+        return;
+    }
     for (long long bi = (long long)blockIdx.x * kThreads + threadIdx.x; bi < blocks; bi += (long long)gridDim.x * kThreads) {
         const int by = (int)(bi / bx_n), bx = (int)(bi - (long long)by * bx_n);
         if (MODE == 0) {

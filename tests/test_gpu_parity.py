@@ -1059,7 +1059,7 @@ def test_nv12_bgr_channel_equalize_batch_and_errors(ctx):
     assert ctx.nv12_bgr_equalize(np.zeros(0, np.uint8), 0, 0).size == 0
 
 
-@pytest.mark.parametrize("size", [(2, 2), (6, 4), (62, 34), (640, 360), (1920, 1080)], ids=str)
+@pytest.mark.parametrize("size", [(2, 2), (6, 4), (16, 2), (48, 18), (62, 34), (640, 360), (1920, 1080), (3840, 2160)], ids=str)
 def test_cvt_color_420_codes(ctx, size):
     """cv::cvtColor COLOR_BGR2YUV_I420 (1frameMeasure.cpp:32) and COLOR_YUV2BGR_NV12 vs the oracle, host and device forms."""
     import torch
