@@ -417,11 +417,14 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         HIPCHK(c, hipMemcpyAsync(c->d_stage_in, src, ybytes, hipMemcpyHostToDevice, s));
     } else {
         if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, ybytes))) return st;
-        for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
-            const int nr = std::min(rows_per_chunk, height - y0);
+        // chunks grow from 256 KiB to 2 MiB: the copy engine starts after a short first host copy instead of a 2 MiB one
+        int y0 = 0;
+        for (int ramp = 8; y0 < height; ramp = std::max(1, ramp / 2)) {
+            const int nr = std::min(std::max(1, rows_per_chunk / ramp), height - y0);
             const size_t off = (size_t)y0 * width;
             copy_rows(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
             HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, s));
+            y0 += nr;
         }
     }
     PlaneArgs a{c->d_stage_in, (size_t)width, ybytes, c->d_stage_out, (size_t)width, ybytes, width, height, 1};
@@ -460,9 +463,12 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, ybytes))) return st;
     struct Chunk { size_t off, bytes; int y0, nr; };
     std::vector<Chunk> chunks;
-    for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
-        const int nr = std::min(rows_per_chunk, height - y0);
-        chunks.push_back({(size_t)y0 * width, (size_t)nr * width, y0, nr});
+    {   // ... and shrink from 2 MiB to 256 KiB at the end: the last host copy, which nothing overlaps, is a short one
+        std::vector<int> sizes;
+        int left = height;
+        for (int ramp = 8; left > 0; ramp = std::max(1, ramp / 2)) { const int nr = std::min(std::max(1, rows_per_chunk / ramp), left); sizes.push_back(nr); left -= nr; }
+        int y0 = 0;
+        for (size_t i = sizes.size(); i-- > 0;) { chunks.push_back({(size_t)y0 * width, (size_t)sizes[i] * width, y0, sizes[i]}); y0 += sizes[i]; }
     }
     while (c->chunk_events.size() < chunks.size()) {
         hipEvent_t e;
