@@ -9,12 +9,12 @@ import mi_lumaeq, oracle
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = mi_lumaeq.Context(0)
-t0 = last = time.time(); n = {"roi": 0, "grid": 0, "small": 0, "c16": 0, "420": 0}
+t0 = last = time.time(); n = {"roi": 0, "grid": 0, "small": 0, "c16": 0, "420": 0, "nv12": 0}
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 def fail(what, *info):
     print("MISMATCH", what, info, flush=True); sys.exit(1)
 while time.time() - t0 < budget:
-    k = int(rng.integers(0, 5))
+    k = int(rng.integers(0, 6))
     if k == 0:      # ROI batch on the device: random pitches, origins, sizes
         w, h, nf = int(rng.integers(1, 700)), int(rng.integers(1, 90)), int(rng.integers(1, 6))
         sp = w + int(rng.integers(0, 40)); sp += (16 - sp % 16) % 16 if rng.integers(0, 2) else 0
@@ -54,6 +54,17 @@ while time.time() - t0 < budget:
         if rng.integers(0, 3) == 0: y[: h // 2] = lo
         if not np.array_equal(ctx.clahe16(y, 2.0, 4, 4), oracle.clahe16(y, 2.0, 4, 4)): fail("c16", w, h, lo, hi)
         n["c16"] += 1
+    elif k == 5:    # NV12 batches of random even sizes through the fused kernel (or the three-kernel path where it does not apply), both ops
+        w, h, nf = int(rng.integers(1, 400)) * 2, int(rng.integers(1, 200)) * 2, int(rng.integers(1, 9))
+        uv = int(rng.integers(0, 2)); op = int(rng.integers(0, 2))
+        fr = rng.integers(0, int(rng.integers(2, 257)), (nf, w * h * 3 // 2), dtype=np.uint8)
+        d_in = dev(fr); inplace = bool(rng.integers(0, 2)); d_out = d_in if inplace else torch.zeros_like(d_in)
+        if op == 0: ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, nf, uv)
+        else: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, nf, uv, 2.0, 4, 4)
+        ctx.synchronize(); out = d_out.cpu().numpy()
+        for f in range(nf):
+            if not np.array_equal(out[f], oracle.nv12_frame(fr[f], w, h, uv_mode=uv, op=op, clip_limit=2.0, tiles_x=4, tiles_y=4)): fail("nv12", w, h, nf, uv, op, inplace, f)
+        n["nv12"] += 1
     else:           # 4:2:0 codes
         w, h = int(rng.integers(1, 60)) * (16 if rng.integers(0, 2) else 2), int(rng.integers(1, 40)) * 2
         bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
