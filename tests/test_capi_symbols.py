@@ -54,3 +54,17 @@ def test_product_never_imports_oracle():
             txt = p.read_text(errors="ignore")
             assert "import oracle" not in txt and "from oracle" not in txt, p
             assert "liblumaeq_oracle" not in txt and not re.search(r"\borc_\w+\s*\(", txt), p
+
+
+def test_header_is_plain_c():
+    """The drop-in boundary is a C ABI: include/mi_lumaeq.h must compile as C99 (no C++-isms, no torch / HIP types) and as C++11."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    hdr = Path(__file__).resolve().parents[1] / "include" / "mi_lumaeq.h"
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", str(hdr)],
+                ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", str(hdr)]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
