@@ -4,7 +4,7 @@
 // in frame order to a sink (optional raw file) instead of `appsrc ... omxh264enc`.
 //
 // Mirrors, flag for flag where they still apply:
-//   --workers N (1..8)  --width W  --height H  --fps F           OpenCVequalHist.cpp:262-284
+//   --workers N (reference: 1..8; here 1..64)  --width W  --height H  --fps F           OpenCVequalHist.cpp:262-284
 //   --clipLimit C  --tile T                                      clahevideo.cpp:374-452
 //   2 s status tick: in/out fps, queue depth, errors, backlog    OpenCVequalHist.cpp:200-234,
 //                                                                OpenCLequalHist.cpp:439-508
