@@ -281,6 +281,24 @@ def main():
                   "whole_path_frac_of_8TBs": round((3 * hw * hh + (hw * hh // 2) * (2 if args.uv == "copy" else 1)) * hb * steps2 / el2 / 1e9 / HBM_PEAK_GBS, 4)}        # per GPU
         del e_in, e_out
 
+    # BASELINE.json configs[3] as written -- 512 4K frames at 60 fps, frame-per-GPU across the node: with N > 1 every rank streams through
+    # ONE pool worker on its own GPU, all ranks at the same time (they share the host's memory bandwidth and PCIe root complexes, which is
+    # what this figure is about); reduced over the ranks below.  Every rank takes part in the reductions whatever happened to its child.
+    stream_all = None
+    if world > 1 and not args.no_extras and (w, h) == (3840, 2160):
+        barrier()
+        try:
+            mine = stream_config4(w, h, device=local_rank)
+        except Exception as e:                   # a failed child must not leave the other ranks in a collective
+            mine = {"error": repr(e)}
+        ok = 1.0 if ("p99_ms" in mine and mine.get("returncode") == 0) else 0.0
+        red = lambda v, op: shard.reduce_over_ranks(float(v), dist, op)
+        stream_all = {"what": "every rank: 512 4K NV12 frames paced at 60 fps through one pool worker on its own GPU, all ranks at once (host -> host, PCIe inclusive)",
+                      "ranks_ok": int(red(ok, "sum")),
+                      "p50_ms_max": red(mine.get("p50_ms", -1.0), "max"), "p99_ms_max": red(mine.get("p99_ms", -1.0), "max"),
+                      "max_ms_max": red(mine.get("max_ms", -1.0), "max"), "late_total": int(red(mine.get("late", 0), "sum")),
+                      "errors_total": int(red(mine.get("errors", 0), "sum")),
+                      "unpaced_frames_per_s_total": round(red(mine.get("unpaced_frames_per_s", 0.0), "sum"), 1)}
     if rank != 0:
         if world > 1:
             dist.barrier()                       # leave together with rank 0 (it is still printing the result line)
@@ -370,6 +388,8 @@ def main():
         except Exception as e:
             print(f"[bench] {fn.__name__} failed: {e!r}", file=sys.stderr, flush=True)
             return {"error": repr(e)}
+    if stream_all is not None:
+        out["stream_4k60_512_all_gpus"] = stream_all
     if world == 1:
         out["opencv_cross_check"] = guarded(opencv_cross_check, ctx, w, h, args.dist)
     if world == 1 and not args.no_extras:
@@ -382,17 +402,24 @@ def main():
         dist.destroy_process_group()
 
 
-def stream_config4(w, h):
+def stream_config4(w, h, device=None):
     """BASELINE.json configs[3] on this GPU: 512 WxH NV12 frames released at 60 fps through ONE worker of the C++ frame pool
     (host frame in -> host frame out, PCIe inclusive; opencv-opencl_amd/cxx/examples/nv12_stream.cpp, the reference's worker
-    pipeline OpenCVequalHist.cpp:102-196 minus the codecs), plus the same pipeline unpaced.  Never the headline value."""
+    pipeline OpenCVequalHist.cpp:102-196 minus the codecs), plus the same pipeline unpaced.  Never the headline value.
+    `device`: the child process is shown only that GPU (HIP_VISIBLE_DEVICES), so its one worker lands on it -- how each rank of an
+    N-GPU run streams on its own GPU."""
     import re
     import subprocess
     exe = ROOT / "opencv-opencl_amd" / "lib" / "nv12_stream"
     if not exe.exists():
         return {"error": "nv12_stream not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    env = None
+    if device is not None:
+        env = dict(os.environ)
+        seen = [x for x in env.get("HIP_VISIBLE_DEVICES", "").split(",") if x.strip() != ""]
+        env["HIP_VISIBLE_DEVICES"] = seen[device] if device < len(seen) else str(device)
     base = [str(exe), "--width", str(w), "--height", str(h), "--workers", "1", "--op", "equalize", "--uv", "fill128"]
-    r = subprocess.run(base + ["--frames", "512", "--paced", "--fps", "60"], capture_output=True, text=True, timeout=180)
+    r = subprocess.run(base + ["--frames", "512", "--paced", "--fps", "60"], capture_output=True, text=True, timeout=180, env=env)
     res = {"frames": 512, "fps": 60, "workers": 1, "returncode": r.returncode,
            "what": "host NV12 frame in -> host NV12 frame out (PCIe inclusive), one pool worker driving an mi_pipe, registered frame ring"}
     m = re.search(r"p50=([0-9.]+) p90=([0-9.]+) p99=([0-9.]+) max=([0-9.]+); frames over the [0-9.]+ ms frame budget: (\d+)", r.stdout)
@@ -401,7 +428,7 @@ def stream_config4(w, h):
     m = re.search(r"errors=(\d+)", r.stdout)
     if m:
         res["errors"] = int(m.group(1))
-    u = subprocess.run(base + ["--frames", "2000"], capture_output=True, text=True, timeout=180)
+    u = subprocess.run(base + ["--frames", "2000"], capture_output=True, text=True, timeout=180, env=env)
     m = re.search(r"= ([0-9.]+) frames/s", u.stdout)
     if m:
         res["unpaced_frames_per_s"] = float(m.group(1))

@@ -34,6 +34,17 @@ def merge_in_order(per_rank: Sequence[Sequence], n_frames: int) -> list:
     return out
 
 
+def reduce_over_ranks(value: float, dist=None, op: str = "max") -> float:
+    """One scalar reduced over the ranks ("max" or "sum") through the job's own backend; the value itself without a process group."""
+    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def max_over_ranks(seconds: float, dist=None) -> float:
     """Whole-job time of a sharded step = the slowest rank's time (no collective on the data path;
     this single scalar all-reduce only aggregates the measurement)."""

@@ -32,6 +32,9 @@ def _worker(rank, world, port, n_frames, q):
         gathered = [None] * world
         dist.all_gather_object(gathered, sums)          # test-side collection only; the data path has none
         t = shard.max_over_ranks(0.25 * (rank + 1), dist)
+        tot = shard.reduce_over_ranks(10.0 + rank, dist, "sum")          # what the bench sums over the ranks (late frames, frames/s)
+        mx = shard.reduce_over_ranks(-1.0 if rank else 3.5, dist, "max")
+        assert tot == sum(10.0 + r for r in range(world)) and mx == 3.5
         if rank == 0:
             q.put((shard.merge_in_order(gathered, n_frames), t))
     finally:
@@ -74,3 +77,4 @@ def test_shard_helpers():
     with pytest.raises(ValueError):
         shard.frames_for_rank(4, 2, 2)
     assert shard.max_over_ranks(1.5) == 1.5
+    assert shard.reduce_over_ranks(2.5, None, "sum") == 2.5
