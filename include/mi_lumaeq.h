@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define MI_LUMAEQ_VERSION_MAJOR 0
-#define MI_LUMAEQ_VERSION_MINOR 1
+#define MI_LUMAEQ_VERSION_MINOR 2
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -47,7 +47,8 @@ typedef enum mi_status {
     MI_ERR_HIP = 3,              /* a HIP call failed; see mi_ctx_last_hip_error()                   */
     MI_ERR_OOM = 4,              /* host or device allocation failed                                 */
     MI_ERR_NO_DEVICE = 5,        /* no usable HIP device / device index out of range                 */
-    MI_ERR_BUSY = 6              /* mi_pipe_submit: `depth` frames are in flight, call mi_pipe_wait   */
+    MI_ERR_BUSY = 6              /* mi_pipe_submit: `depth` frames are in flight, call mi_pipe_wait; any compute entry point
+                                  * while frames are pending in the context's pipe; a second mi_pipe_create on a context  */
 } mi_status;
 
 /* UV handling of whole-NV12-frame entry points:
@@ -81,8 +82,9 @@ int         mi_device_count(void);                         /* 0 when no HIP devi
  * Replaces  cv::equalizeHist(y_in, y_out)  (OpenCVequalHist.cpp:145) and the whole blocking
  * write/write/task/read sequence of OpenCLequalHist.cpp:356-365.
  * Host memory: planes in PINNED memory (mi_host_register below, or hipHostMalloc / hipHostRegister by the caller) are DMA'd
- * as they are; anything else is packed through the context's own pinned staging buffers (0.58 ms instead of 0.34 ms per 4K
- * plane) -- the library never hands the HIP runtime memory it did not pin itself (option "host_direct"). */
+ * as they are; anything else is packed through the context's own pinned staging buffers by the calling thread and one helper
+ * thread of the context -- the library never hands the HIP runtime memory it did not pin itself.
+ * Errors: whatever a host-pointer form returns, no copy on src / dst is in flight any more when it returns. */
 mi_status mi_equalize_hist_u8(mi_ctx* ctx, const uint8_t* src, size_t src_step,
                               uint8_t* dst, size_t dst_step, int width, int height);
 
@@ -208,8 +210,12 @@ mi_status mi_host_unregister(void* ptr);
  *              MI_PIPE_UV_DEVICE: whole frames cross the bus and the kernels write the UV half (no host CPU work)
  *   depth      frames in flight, 2..16 (0 = default 4)
  * mi_pipe_submit returns MI_ERR_BUSY when `depth` frames are pending.  mi_pipe_wait blocks for the OLDEST pending
- * frame and returns its tag and output pointer.  A pipe uses its context's scratch and lock: one pipe per context,
- * destroy it before the context; the context's other entry points may be used while no frame is pending. */
+ * frame and returns its tag and output pointer.  A pipe uses its context's scratch and lock: ONE pipe per context (a
+ * second mi_pipe_create answers MI_ERR_BUSY), destroy it before the context; the context's other compute entry points may
+ * be used while no frame is pending and answer MI_ERR_BUSY otherwise.
+ * Errors keep caller and pipe in step: a failed mi_pipe_submit occupies no slot and leaves no copy in flight on in / out;
+ * a failed mi_pipe_wait has still retired the oldest frame (its tag is returned, its buffers are idle) -- one mi_pipe_wait
+ * call, one frame gone, whatever the status. */
 typedef struct mi_pipe mi_pipe;
 enum { MI_OP_EQUALIZE = 0, MI_OP_CLAHE = 1, MI_OP_CHANNELS = 2 };
 enum { MI_PIPE_UV_AUTO = 0, MI_PIPE_UV_HOST = 1, MI_PIPE_UV_DEVICE = 2 };
@@ -293,28 +299,22 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * the fused path lives in device memory -- and the graph can be replayed.  Size the scratch with one
  * eager call of the same shape first: scratch growth inside a capture returns MI_ERR_UNSUPPORTED, and
  * once a context has seen a capture it never frees scratch a graph node may reference.
- * Options (mi_ctx_set_option): "fused" (1/0: single-read fused kernel vs the three-kernel path),
- * "fused_wgs_per_cu" (persistent workgroups per CU, default 4), "fused_vpt" (8/16/20/24 16-byte vectors a
- * thread keeps in registers, default 20; 0 restores the default), "fused_acquire" (1/0), "fused_timeout_ms" (bound of every
- * inter-workgroup wait, default 50), "fused_timeout_us" (test hook: the same bound in microseconds, so that ordinary waits expire),
- * "fused_fault_inject" (test hook, 0..3), "clahe_float_tables" (1/0),
- * "clahe_xcd_map" (1/0, default 1: XCD-aware tile order of the CLAHE tile-histogram pass; speed only),
- * "clahe_hist_threads" (256 / 512, default 512: threads per tile-histogram workgroup; speed only),
- * "clahe_seg_pairs" (4..15, default 9: pairs per LDS float table when a grid of more than 14 tiles across is cut into column
- * segments; speed only),
- * "clahe_tiles_per_wg" (0..8, default 0 = by tile size: tiles one tile-histogram workgroup walks in large batches of small
- * tiles -- two below ~24 K pixels per tile, e.g. 720p 8x8; speed only),
- * "bgr_fused" (1/0, default 1: mi_bgr_luma_op_u8c3 runs as two passes over the interleaved image instead of through
- * Y/U/V planes; CLAHE only for unpadded shapes with tile_w % 16 == 0),
- * "clahe_fp_contract" (1/0, default 0: CLAHE interpolation arithmetic.  0 = every multiply and add rounded separately, what an
- * x86-64 baseline build of OpenCV computes; 1 = the fused multiply-adds GCC forms from clahe.cpp's expressions on FMA targets
- * under its default -ffp-contract=fast, i.e. a distribution OpenCV on aarch64 -- the reference's own board: txf = fma(x, 1/tw, -0.5),
- * res = fma(fma(l11, xa1, l12*xa), ya1, fma(l21, xa1, l22*xa) * ya).  The two differ by 1 in about 0.03 % of the pixels),
- * "clahe16_transposed" (1/0, default 0: value-major LUT layout for the 16-bit interpolation, faster on full-range content and
- * slower on narrow-range content),
- * "host_direct" (1/0, default 0: unpinned host memory goes through pinned staging buffers the library owns, as strided views
- * always do; 1 hands contiguous unpinned planes to hipMemcpyAsync as they are -- faster for a single synchronous call, but it
- * relies on the runtime's own pageable-copy path, under which both process aborts on record happened). */
+ * A context that keeps being repaired gives the fused path up for a while ("demotion"): `fused_demote_after` repaired launches
+ * within 32 fused launches route the following calls through the three-kernel path (no inter-workgroup dependency, nothing to
+ * stall) for `fused_reprobe_ms`; then one fused launch probes again, and a repair during the probe doubles the period (up to
+ * 64x).  mi_ctx_get_stat("fused_demotions" | "fused_demoted").  The bytes are the same on either path.
+ * Options that change BEHAVIOUR (mi_ctx_set_option; the speed-only ones are in mi_lumaeq_tuning.h):
+ *   "fused"              1/0, default 1: single-read fused kernel vs the three-kernel path for the batched equalizeHist forms
+ *   "fused_timeout_ms"   bound of every inter-workgroup wait of the fused kernel, default 50
+ *   "fused_demote_after" 0..32, default 3: repaired launches per window that demote the fused path (0 = never demote)
+ *   "fused_reprobe_ms"   first demotion period in milliseconds, default 1000
+ *   "clahe_fp_contract"  1/0, default 0: CLAHE interpolation arithmetic.  0 = every multiply and add rounded separately, what an
+ *                        x86-64 baseline build of OpenCV computes; 1 = the fused multiply-adds GCC forms from clahe.cpp's
+ *                        expressions on FMA targets under its default -ffp-contract=fast, i.e. OpenCV on aarch64 -- the
+ *                        reference's own board: txf = fma(x, 1/tw, -0.5), res = fma(fma(l11, xa1, l12*xa), ya1,
+ *                        fma(l21, xa1, l22*xa) * ya).  The two differ by 1 in about 0.03 % of the pixels.
+ * Other statistics (mi_ctx_get_stat): "error_drains" (error returns that had to wait for a stream first),
+ * "host_copies_shared" (staging copies of the host forms the context's helper thread took half of). */
 mi_status mi_ctx_synchronize(mi_ctx* ctx, void* stream);
 mi_status mi_ctx_set_option(mi_ctx* ctx, const char* name, int value);
 mi_status mi_ctx_get_stat(mi_ctx* ctx, const char* name, uint64_t* out);

@@ -1,0 +1,42 @@
+/*
+ * mi_lumaeq_tuning.h -- speed-only knobs of libmi_lumaeq (mi_ctx_set_option).
+ *
+ * Nothing in this file changes a single output byte: every option below only moves work between equivalent kernels or
+ * changes a launch geometry.  They exist for the measurements under profiles/ and tools/; a caller of the drop-in boundary
+ * (include/mi_lumaeq.h: the replacement of cv::equalizeHist / cv::CLAHE::apply at OpenCVequalHist.cpp:145,
+ * clahevideo.cpp:195) never needs them.  Options that change behaviour are documented in mi_lumaeq.h.
+ * This header declares no functions.
+ */
+#ifndef MI_LUMAEQ_TUNING_H_
+#define MI_LUMAEQ_TUNING_H_
+
+#include "mi_lumaeq.h"        /* mi_ctx_set_option */
+
+/* fused single-read equalizeHist kernel */
+#define MI_OPT_FUSED_WGS_PER_CU    "fused_wgs_per_cu"    /* 1..8, default 4: persistent workgroups per compute unit                   */
+#define MI_OPT_FUSED_VPT           "fused_vpt"           /* 8 / 16 / 20 / 24 (0 = default 20): 16-byte vectors a thread keeps in
+                                                           * registers between the histogram and the apply pass (slice = 256 x VPT x 16 B) */
+#define MI_OPT_FUSED_ACQUIRE       "fused_acquire"       /* 1/0, default 1: agent-scope acquire before a consumer reads the LUT       */
+
+/* CLAHE (8-bit) */
+#define MI_OPT_CLAHE_XCD_MAP       "clahe_xcd_map"       /* 1/0, default 1: XCD-aware tile order of the tile-histogram pass           */
+#define MI_OPT_CLAHE_HIST_THREADS  "clahe_hist_threads"  /* 256 / 512, default 512: threads per tile-histogram workgroup              */
+#define MI_OPT_CLAHE_SEG_PAIRS     "clahe_seg_pairs"     /* 4..15, default 9: LUT pairs per LDS float table when a grid wider than 14
+                                                           * tiles is cut into column segments                                      */
+#define MI_OPT_CLAHE_TILES_PER_WG  "clahe_tiles_per_wg"  /* 0..8, default 0 = by tile size: tiles one tile-histogram workgroup walks
+                                                           * in large batches of small tiles                                         */
+#define MI_OPT_CLAHE_FLOAT_TABLES  "clahe_float_tables"  /* 1/0, default 1: f32 pair tables in LDS for the interpolation (<= 14 tiles
+                                                           * across)                                                                 */
+
+/* CLAHE (16-bit) */
+#define MI_OPT_CLAHE16_TRANSPOSED  "clahe16_transposed"  /* 1/0, default 0: value-major LUT layout for the 16-bit interpolation       */
+
+/* colour neighbours */
+#define MI_OPT_BGR_FUSED           "bgr_fused"           /* 1/0, default 1: mi_bgr_luma_op_u8c3 as two passes over the interleaved
+                                                           * image instead of through Y/U/V planes                                   */
+
+/* host-pointer forms */
+#define MI_OPT_HOST_COPY_THREADS   "host_copy_threads"   /* 1 / 2, default 2: threads that pack unpinned planes through the pinned
+                                                           * staging buffers (the caller alone, or the caller and the context's helper) */
+
+#endif /* MI_LUMAEQ_TUNING_H_ */

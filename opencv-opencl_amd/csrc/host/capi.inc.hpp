@@ -6,7 +6,11 @@
 // =====================================================================================================
 extern "C" {
 
-const char* mi_version(void) { return "mi_lumaeq 0.1 (gfx950)"; }
+#ifdef MI_TEST_HOOKS
+const char* mi_version(void) { return "mi_lumaeq 0.2 (gfx950) +test-hooks"; }
+#else
+const char* mi_version(void) { return "mi_lumaeq 0.2 (gfx950)"; }
+#endif
 
 const char* mi_status_str(mi_status s)
 {
@@ -79,6 +83,19 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
         delete c;
         return MI_ERR_HIP;
     }
+    {   // one line of pinned, device-writable host memory: the finish kernel of the fused path reports repaired launches into it
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+            || hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (q) (void)hipHostFree(q);
+            (void)hipStreamDestroy(c->stream);
+            delete c;
+            return MI_ERR_HIP;
+        }
+        c->h_mirror = (uint32_t*)q;
+        memset(c->h_mirror, 0, 64);
+    }
     // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16Entries * (int)sizeof(uint2));
@@ -109,11 +126,13 @@ void mi_ctx_destroy(mi_ctx* c)
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_luts) (void)hipFree(c->d_luts);
     if (c->d_fused) (void)hipFree(c->d_fused);
-    if (c->d_fused_flags) (void)hipFree(c->d_fused_flags);
     for (void* q : c->retired) (void)hipFree(q);
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_c16) (void)hipFree(c->d_c16);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_mirror) (void)hipHostFree(c->h_mirror);
+    if (c->ev_scratch) (void)hipEventDestroy(c->ev_scratch);
+    delete c->crew;
     if (c->d_stage_in) (void)hipFree(c->d_stage_in);
     if (c->d_stage_out) (void)hipFree(c->d_stage_out);
     if (c->h_pin_in) (void)hipHostFree(c->h_pin_in);
@@ -173,6 +192,7 @@ mi_status mi_host_register(void* ptr, size_t bytes)
     if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP; }
     std::lock_guard<std::mutex> lk(g_pin_mu);
     g_pinned.push_back({(uintptr_t)ptr, (uintptr_t)ptr + bytes});
+    g_pin_generation.fetch_add(1, std::memory_order_relaxed);
     return MI_OK;
 }
 
@@ -184,32 +204,49 @@ mi_status mi_host_unregister(void* ptr)
         auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [&](const PinnedRange& r) { return r.lo == (uintptr_t)ptr; });
         if (it == g_pinned.end()) return MI_ERR_BAD_ARG;
         g_pinned.erase(it);
+        g_pin_generation.fetch_add(1, std::memory_order_relaxed);
     }
     if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return MI_ERR_HIP; }
     return MI_OK;
 }
 
+// Options: include/mi_lumaeq.h documents the ones that change behaviour, include/mi_lumaeq_tuning.h the speed-only ones; the
+// test hooks exist in libmi_lumaeq_test.so only (csrc/Makefile builds it with -DMI_TEST_HOOKS).
 mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
 {
     ENTER(c);
     if (!name) return fail(c, MI_ERR_BAD_ARG, "null option name");
+    // ---- behaviour (mi_lumaeq.h)
     if (!strcmp(name, "fused")) { c->fused_mode = value; return MI_OK; }
+    if (!strcmp(name, "fused_timeout_ms")) {
+        c->fused_timeout_ms = std::max(1, value);
+#ifdef MI_TEST_HOOKS
+        c->fused_timeout_us = 0;
+#endif
+        return MI_OK;
+    }
+    if (!strcmp(name, "fused_demote_after")) { if (value < 0 || value > 32) return fail(c, MI_ERR_BAD_ARG, "fused_demote_after must be 0..32"); c->fused_demote_after = value; return MI_OK; }
+    if (!strcmp(name, "fused_reprobe_ms")) { c->fused_reprobe_ms = c->fused_reprobe_ms_now = std::max(1, value); return MI_OK; }
+    if (!strcmp(name, "clahe_fp_contract")) { c->clahe_fp_contract = value != 0; return MI_OK; }
+    // ---- speed only (mi_lumaeq_tuning.h)
     if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }
     if (!strcmp(name, "fused_vpt") && value == 0) { c->fused_vpt = kVPT; return MI_OK; }
     if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 0 (default), 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }
     if (!strcmp(name, "fused_acquire")) { c->fused_acquire = value != 0; return MI_OK; }
-    if (!strcmp(name, "fused_fault_inject")) { if (value < 0 || value > 3) return fail(c, MI_ERR_BAD_ARG, "fused_fault_inject must be 0..3"); c->fused_fault_inject = value; return MI_OK; }
-    if (!strcmp(name, "fused_timeout_ms")) { c->fused_timeout_ms = std::max(1, value); c->fused_timeout_us = 0; return MI_OK; }
-    if (!strcmp(name, "fused_timeout_us")) { c->fused_timeout_us = std::max(0, value); return MI_OK; }
     if (!strcmp(name, "bgr_fused")) { c->bgr_fused = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_hist_threads")) { if (value != 256 && value != 512) return fail(c, MI_ERR_BAD_ARG, "clahe_hist_threads must be 256 or 512"); c->clahe_hist_threads = value; return MI_OK; }
     if (!strcmp(name, "clahe_tiles_per_wg")) { if (value < 0 || value > 8) return fail(c, MI_ERR_BAD_ARG, "clahe_tiles_per_wg must be 0..8"); c->clahe_tiles_per_wg = value; return MI_OK; }
     if (!strcmp(name, "clahe_seg_pairs")) { if (value < 4 || value > 15) return fail(c, MI_ERR_BAD_ARG, "clahe_seg_pairs must be 4..15"); c->clahe_seg_pairs = value; return MI_OK; }
     if (!strcmp(name, "clahe_xcd_map")) { c->clahe_xcd_map = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
-    if (!strcmp(name, "host_direct")) { c->host_direct = value != 0; return MI_OK; }
-    if (!strcmp(name, "clahe_fp_contract")) { c->clahe_fp_contract = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe16_transposed")) { c->clahe16_transposed = value != 0; return MI_OK; }
+    if (!strcmp(name, "host_copy_threads")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "host_copy_threads must be 1 or 2"); c->host_copy_threads = value; return MI_OK; }
+#ifdef MI_TEST_HOOKS
+    // ---- test hooks (this is libmi_lumaeq_test.so)
+    if (!strcmp(name, "fused_fault_inject")) { if (value < 0 || value > 3) return fail(c, MI_ERR_BAD_ARG, "fused_fault_inject must be 0..3"); c->fused_fault_inject = value; return MI_OK; }
+    if (!strcmp(name, "fused_timeout_us")) { c->fused_timeout_us = std::max(0, value); return MI_OK; }
+    if (!strcmp(name, "hip_fail_after")) { c->hip_fail_after = std::max(0, value); return MI_OK; }
+#endif
     return fail(c, MI_ERR_BAD_ARG, "unknown option");
 }
 
@@ -235,12 +272,18 @@ mi_status mi_ctx_synchronize(mi_ctx* c, void* stream)
 
 // Statistics: "fused_fallbacks" (fused launches in which a bounded wait expired and the finish kernel redid the missing tickets),
 // "fused_frames_repaired", "fused_hard_errors" (frames the repair refused), "fused_last_status" (1 = wait on a frame's LUT
-// flag / histogram total, 2 = LUT checksum).  Reads device words with a blocking copy on the context's stream: call it after the
-// stream the work ran on has been synchronised.
+// flag / histogram total, 2 = LUT checksum) -- these read device words with a blocking copy on the context's stream: call after the
+// stream the work ran on has been synchronised.  Host-side counters: "fused_demotions" (times the context gave the fused path up
+// for a while after repeated repairs), "fused_demoted" (1 while it is given up), "error_drains" (error exits that had to wait for
+// a stream before returning), "host_copies_shared" (staging copies the helper thread took half of).
 mi_status mi_ctx_get_stat(mi_ctx* c, const char* name, uint64_t* out)
 {
     ENTER(c);
     if (!name || !out) return fail(c, MI_ERR_BAD_ARG, "null stat name / out");
+    if (!strcmp(name, "fused_demotions")) { *out = c->fused_demotions; return MI_OK; }
+    if (!strcmp(name, "fused_demoted")) { *out = c->fused_demoted ? 1 : 0; return MI_OK; }
+    if (!strcmp(name, "error_drains")) { *out = c->error_drains; return MI_OK; }
+    if (!strcmp(name, "host_copies_shared")) { *out = c->crew ? c->crew->shared_jobs() : 0; return MI_OK; }
     static const char* names[4] = {"fused_fallbacks", "fused_frames_repaired", "fused_hard_errors", "fused_last_status"};
     for (int k = 0; k < 4; ++k)
         if (!strcmp(name, names[k])) {
@@ -258,7 +301,7 @@ mi_status mi_equalize_hist_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src
                                         void* d_dst, size_t dst_step, size_t dst_frame_stride,
                                         int width, int height, int n_frames, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
     mi_status st = check_plane(c, a, true);
     if (st || width == 0 || height == 0 || n_frames == 0) return st;
@@ -268,7 +311,7 @@ mi_status mi_equalize_hist_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src
 mi_status mi_equalize_hist_nv12_batch_dev(mi_ctx* c, const void* d_in, void* d_out, int width, int height, int n_frames,
                                           mi_uv_mode uv_mode, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
     const size_t frame = (size_t)width * height + ((size_t)width * height) / 2;
     PlaneArgs a{(const uint8_t*)d_in, (size_t)width, frame, (uint8_t*)d_out, (size_t)width, frame, width, height, n_frames};
@@ -282,7 +325,7 @@ mi_status mi_clahe_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, s
                                 void* d_dst, size_t dst_step, size_t dst_frame_stride,
                                 int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
     mi_status st = check_plane(c, a, true);
     if (st) return st;
@@ -294,7 +337,7 @@ mi_status mi_clahe_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, s
 mi_status mi_clahe_nv12_batch_dev(mi_ctx* c, const void* d_in, void* d_out, int width, int height, int n_frames,
                                   mi_uv_mode uv_mode, double clip_limit, int tiles_x, int tiles_y, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
     const size_t frame = (size_t)width * height + ((size_t)width * height) / 2;
     PlaneArgs a{(const uint8_t*)d_in, (size_t)width, frame, (uint8_t*)d_out, (size_t)width, frame, width, height, n_frames};
@@ -310,7 +353,7 @@ mi_status mi_clahe_nv12_batch_dev(mi_ctx* c, const void* d_in, void* d_out, int 
 mi_status mi_hist_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
                                int width, int height, int n_frames, void* d_hist, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, nullptr, 0, 0, width, height, n_frames};
     mi_status st = check_plane(c, a, false);
     if (st) return st;
@@ -331,7 +374,7 @@ mi_status mi_hist_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, si
 
 mi_status mi_equalize_lut_batch_dev(mi_ctx* c, const void* d_hist, int64_t total, int n_frames, void* d_lut, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     if (!d_hist || !d_lut || n_frames < 0) return fail(c, MI_ERR_BAD_ARG, "null pointer / negative count");
     if (total <= 0 || total > 0x7fffffffLL) return fail(c, MI_ERR_BAD_ARG, "total must be in [1, 2^31)");
     hipStream_t s = pick_stream(c, stream);
@@ -347,7 +390,7 @@ mi_status mi_lut_apply_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_ste
                                     void* d_dst, size_t dst_step, size_t dst_frame_stride,
                                     int width, int height, int n_frames, const void* d_lut, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
     mi_status st = check_plane(c, a, true);
     if (st || width == 0 || height == 0 || n_frames == 0) return st;
@@ -365,7 +408,7 @@ mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* c, const void* d_src, size_t src_
                                        int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y,
                                        void* d_luts, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     PlaneArgs a{(const uint8_t*)d_src, src_step, src_frame_stride, nullptr, 0, 0, width, height, n_frames};
     mi_status st = check_plane(c, a, false);
     if (st) return st;
@@ -386,8 +429,34 @@ mi_status mi_clahe_tile_luts_batch_dev(mi_ctx* c, const void* d_src, size_t src_
 }
 
 // ---- host-pointer forms (the cv::Mat boundary) -----------------------------------------------------------
-// Host plane -> (pinned staging for strided views ->) H2D -> kernels -> D2H (-> pinned -> host rows), all on the
+// Host plane -> (pinned staging unless the plane is pinned ->) H2D -> kernels -> D2H (-> pinned -> host rows), all on the
 // context's stream, synchronous on return.  `nv12_mode` < 0: plain Y plane; otherwise whole NV12 frame.
+//
+// Host memory.  Pinned planes (mi_host_register, or pinned by the caller) are DMA'd as they are.  Everything else is packed
+// through the context's own pinned staging buffers in chunks whose host copies overlap the DMA of the chunk before; the copies
+// are shared with the context's helper thread (copy_crew.hpp), because one core copies slower than the link transfers.  The
+// library never hands PAGEABLE memory to hipMemcpyAsync: the runtime pins such pages on the fly and keeps them pinned in a cache
+// of its own after the call has returned (profiles/r02_v_pageable_path_log.txt), and both process aborts on record happened on
+// that path (docs/experiments.md, "the silent abort").  The option that used to bring that path back (host_direct) is gone.
+//
+// Error exits.  From the first copy that touches caller memory on, every return that has not itself waited for the stream
+// drains it first (StreamDrain): the caller may free or reuse src / dst as soon as the call returns, whatever it returns.
+struct CrewCall {
+    mi_host::CopyCrew* crew;
+    CrewCall(mi_ctx* c, bool want) : crew(nullptr)
+    {
+        if (!want || c->host_copy_threads < 2) return;
+        if (!c->crew) c->crew = new (std::nothrow) mi_host::CopyCrew();
+        if (c->crew) { crew = c->crew; crew->begin(); }
+    }
+    ~CrewCall() { if (crew) crew->end(); }
+    void copy(uint8_t* dst, size_t dstep, const uint8_t* src, size_t sstep, int width, int rows)
+    {
+        if (crew) crew->copy_rows(dst, dstep, src, sstep, (size_t)width, (size_t)rows);
+        else copy_rows(dst, dstep, src, sstep, width, rows);
+    }
+};
+
 static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step,
                          int width, int height, int nv12_mode, bool is_clahe, double clip_limit, int tiles_x, int tiles_y)
 {
@@ -401,28 +470,23 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, ybytes))) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, ybytes))) return st;
     hipStream_t s = c->stream;
-    // Pinned memory (mi_host_register, or pinned by the caller) is DMA'd asynchronously as it is.  Everything else is packed through
-    // the context's own pinned staging buffers, in 2 MiB chunks whose host copies overlap the DMA of the previous chunk (0.58 ms per
-    // 4K plane).  Handing PAGEABLE memory to hipMemcpyAsync is faster in a single synchronous call (0.34 ms: the runtime pins the
-    // pages or stages them on helper threads of its own) and was the default in round 1 and most of round 2 -- but both silent
-    // process aborts on record happened in exactly that configuration, a pageable copy queued behind a kernel that stalls for its
-    // 50 ms bound, so the library no longer gives the runtime memory it did not pin itself.  Option "host_direct" = 1
-    // brings the old behaviour back.
-    const bool in_pinned = src_step == (size_t)width && host_range_pinned(src, ybytes);
-    const bool out_pinned = dst_step == (size_t)width && host_range_pinned(dst, ybytes);
-    const bool in_direct = in_pinned || (c->host_direct && src_step == (size_t)width);
-    const bool out_direct = out_pinned || (c->host_direct && dst_step == (size_t)width);
+    const bool in_pinned = src_step == (size_t)width && host_range_pinned(src, ybytes, &c->pin_neg);
+    const bool out_pinned = dst_step == (size_t)width && host_range_pinned(dst, ybytes, &c->pin_neg);
+    if (!in_pinned && (st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, ybytes))) return st;
+    if (!out_pinned && (st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, ybytes))) return st;
+    CrewCall crew(c, !(in_pinned && out_pinned) && ybytes >= 4 * mi_host::CopyCrew::kMinBytes);
+    StreamDrain drain(HipStreamSync{}, drain_counter(c));
+    drain.watch(s);
     const int rows_per_chunk = std::max(1, (int)((size_t)(2u << 20) / (size_t)width));
-    if (in_direct) {
+    if (in_pinned) {
         HIPCHK(c, hipMemcpyAsync(c->d_stage_in, src, ybytes, hipMemcpyHostToDevice, s));
     } else {
-        if ((st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, ybytes))) return st;
         // chunks grow from 256 KiB to 2 MiB: the copy engine starts after a short first host copy instead of a 2 MiB one
         int y0 = 0;
         for (int ramp = 8; y0 < height; ramp = std::max(1, ramp / 2)) {
             const int nr = std::min(std::max(1, rows_per_chunk / ramp), height - y0);
             const size_t off = (size_t)y0 * width;
-            copy_rows(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
+            crew.copy(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
             HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, s));
             y0 += nr;
         }
@@ -449,18 +513,16 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         if (nv12_mode == MI_UV_FILL128) memset(dst + ybytes, 128, uvbytes);
         else if (dst != src) memmove(dst + ybytes, src + ybytes, uvbytes);
     };
-    if (out_direct) {
-        // a copy into pageable memory blocks the caller, so the UV half goes first there (it overlaps the kernels);
-        // into pinned memory the copy is asynchronous and the UV work overlaps the DMA itself
-        if (!out_pinned) host_uv();
+    static const char* kHardMsg = "fused equalize kernel: a frame could not be repaired after an expired inter-workgroup wait; output invalid";
+    if (out_pinned) {
         HIPCHK(c, hipMemcpyAsync(dst, c->d_stage_out, ybytes, hipMemcpyDeviceToHost, s));
-        if (out_pinned) host_uv();
+        host_uv();                                              // the copy is asynchronous: the UV work overlaps the DMA itself
         HIPCHK(c, hipStreamSynchronize(s));
-        if (hard_error()) return fail(c, MI_ERR_HIP, "fused equalize kernel: a frame could not be repaired after an expired inter-workgroup wait; output invalid");
+        drain.done();
+        if (hard_error()) return fail(c, MI_ERR_HIP, kHardMsg);
         return MI_OK;
     }
     // device -> pinned in chunks, each followed by an event; then drain chunk by chunk into the caller's rows
-    if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, ybytes))) return st;
     struct Chunk { size_t off, bytes; int y0, nr; };
     std::vector<Chunk> chunks;
     {   // ... and shrink from 2 MiB to 256 KiB at the end: the last host copy, which nothing overlaps, is a short one
@@ -482,18 +544,16 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     host_uv();
     for (size_t i = 0; i < chunks.size(); ++i) {
         HIPCHK(c, hipEventSynchronize(c->chunk_events[i]));
-        if (i == 0 && hard_error()) {
-            (void)hipStreamSynchronize(s);
-            return fail(c, MI_ERR_HIP, "fused equalize kernel: a frame could not be repaired after an expired inter-workgroup wait; output invalid");
-        }
-        copy_rows(dst + (size_t)chunks[i].y0 * dst_step, dst_step, c->h_pin_out + chunks[i].off, (size_t)width, width, chunks[i].nr);
+        if (i == 0 && hard_error()) return fail(c, MI_ERR_HIP, kHardMsg);     // (the guard drains the remaining chunks)
+        crew.copy(dst + (size_t)chunks[i].y0 * dst_step, dst_step, c->h_pin_out + chunks[i].off, (size_t)width, width, chunks[i].nr);
     }
+    drain.done();                                               // the last chunk's event has been waited for: the stream is idle
     return MI_OK;
 }
 
 mi_status mi_equalize_hist_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     PlaneArgs a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
     mi_status st = check_plane(c, a, true);
     if (st || width == 0 || height == 0) return st;
@@ -503,7 +563,7 @@ mi_status mi_equalize_hist_u8(mi_ctx* c, const uint8_t* src, size_t src_step, ui
 mi_status mi_clahe_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height,
                       double clip_limit, int tiles_x, int tiles_y)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     PlaneArgs a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
     mi_status st = check_plane(c, a, true);
     if (st) return st;
@@ -514,7 +574,7 @@ mi_status mi_clahe_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* d
 
 mi_status mi_equalize_hist_nv12(mi_ctx* c, const uint8_t* in, uint8_t* out, int width, int height, mi_uv_mode uv_mode)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
     PlaneArgs a{in, (size_t)std::max(width, 0), 0, out, (size_t)std::max(width, 0), 0, width, height, 1};
     mi_status st = check_plane(c, a, true);
@@ -525,7 +585,7 @@ mi_status mi_equalize_hist_nv12(mi_ctx* c, const uint8_t* in, uint8_t* out, int 
 mi_status mi_clahe_nv12(mi_ctx* c, const uint8_t* in, uint8_t* out, int width, int height, mi_uv_mode uv_mode,
                         double clip_limit, int tiles_x, int tiles_y)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     if (uv_mode != MI_UV_FILL128 && uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
     PlaneArgs a{in, (size_t)std::max(width, 0), 0, out, (size_t)std::max(width, 0), 0, width, height, 1};
     mi_status st = check_plane(c, a, true);

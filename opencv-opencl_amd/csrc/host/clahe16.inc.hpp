@@ -94,7 +94,7 @@ mi_status mi_clahe_u16_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, 
                                  void* d_dst, size_t dst_step, size_t dst_frame_stride,
                                  int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     mi_status st = check_u16(c, d_src, src_step, d_dst, dst_step, width, height, n_frames, tiles_x, tiles_y);
     if (st || width == 0 || height == 0 || n_frames == 0) return st;
     return clahe16_dev(c, pick_stream(c, stream), (const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride,
@@ -104,16 +104,17 @@ mi_status mi_clahe_u16_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, 
 mi_status mi_clahe_u16(mi_ctx* c, const uint16_t* src, size_t src_step, uint16_t* dst, size_t dst_step, int width, int height,
                        double clip_limit, int tiles_x, int tiles_y)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     mi_status st = check_u16(c, src, src_step, dst, dst_step, width, height, 1, tiles_x, tiles_y);
     if (st || width == 0 || height == 0) return st;
     const size_t row = (size_t)width * 2, bytes = row * height;
     hipStream_t s = c->stream;
-    if ((st = stage_in(c, s, (const uint8_t*)src, src_step, row, (size_t)height))) return st;
+    StreamDrain drain(HipStreamSync{}, drain_counter(c));
+    if ((st = stage_in(c, s, (const uint8_t*)src, src_step, row, (size_t)height, drain))) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     st = clahe16_dev(c, s, c->d_stage_in, row, bytes, c->d_stage_out, row, bytes, width, height, 1, clip_limit, tiles_x, tiles_y);
     if (st) return st;
-    return stage_out(c, s, (uint8_t*)dst, dst_step, row, (size_t)height);
+    return stage_out(c, s, (uint8_t*)dst, dst_step, row, (size_t)height, drain);
 }
 
 }  // extern "C"

@@ -223,13 +223,14 @@ mi_status color_host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t*
 {
     const size_t row = (size_t)width * 3, bytes = row * height;
     hipStream_t s = c->stream;
-    mi_status st = stage_in(c, s, src, src_step, row, (size_t)height);
+    StreamDrain drain(HipStreamSync{}, drain_counter(c));
+    mi_status st = stage_in(c, s, src, src_step, row, (size_t)height, drain);
     if (st) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     Color3Args a{c->d_stage_in, row, bytes, c->d_stage_out, row, bytes, width, height, 1};
     st = luma ? bgr_luma_dev(c, s, a, code_or_op, clip, tx, ty) : cvt_color_dev(c, s, a, code_or_op);
     if (st) return st;
-    return stage_out(c, s, dst, dst_step, row, (size_t)height);
+    return stage_out(c, s, dst, dst_step, row, (size_t)height, drain);
 }
 
 }  // namespace
@@ -240,7 +241,7 @@ mi_status mi_cvt_color_u8c3_batch_dev(mi_ctx* c, const void* d_src, size_t src_s
                                       void* d_dst, size_t dst_step, size_t dst_frame_stride,
                                       int width, int height, int n_frames, int code, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     Color3Args a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
     mi_status st = check_color3(c, a);
     if (st) return st;
@@ -253,7 +254,7 @@ mi_status mi_bgr_luma_op_u8c3_batch_dev(mi_ctx* c, const void* d_src, size_t src
                                         void* d_dst, size_t dst_step, size_t dst_frame_stride,
                                         int width, int height, int n_frames, int op, double clip_limit, int tiles_x, int tiles_y, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     Color3Args a{(const uint8_t*)d_src, src_step, src_frame_stride, (uint8_t*)d_dst, dst_step, dst_frame_stride, width, height, n_frames};
     mi_status st = check_color3(c, a);
     if (st) return st;
@@ -265,7 +266,7 @@ mi_status mi_bgr_luma_op_u8c3_batch_dev(mi_ctx* c, const void* d_src, size_t src
 
 mi_status mi_cvt_color_u8c3(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height, int code)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     Color3Args a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
     mi_status st = check_color3(c, a);
     if (st) return st;
@@ -277,7 +278,7 @@ mi_status mi_cvt_color_u8c3(mi_ctx* c, const uint8_t* src, size_t src_step, uint
 mi_status mi_bgr_luma_op_u8c3(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height,
                               int op, double clip_limit, int tiles_x, int tiles_y)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     Color3Args a{src, src_step, 0, dst, dst_step, 0, width, height, 1};
     mi_status st = check_color3(c, a);
     if (st) return st;
@@ -290,7 +291,7 @@ mi_status mi_bgr_luma_op_u8c3(mi_ctx* c, const uint8_t* src, size_t src_step, ui
 mi_status mi_nv12_bgr_equalize_batch_dev(mi_ctx* c, const void* d_in, size_t in_frame_stride, void* d_out, size_t out_frame_stride,
                                          int width, int height, int n_frames, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     mi_status st = check_nv12_420(c, d_in, d_out, width, height, n_frames);
     if (st || width == 0 || height == 0 || n_frames == 0) return st;
     const size_t frame = (size_t)width * height * 3 / 2;
@@ -301,23 +302,24 @@ mi_status mi_nv12_bgr_equalize_batch_dev(mi_ctx* c, const void* d_in, size_t in_
 
 mi_status mi_nv12_bgr_equalize(mi_ctx* c, const uint8_t* nv12_in, uint8_t* nv12_out, int width, int height)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     mi_status st = check_nv12_420(c, nv12_in, nv12_out, width, height, 1);
     if (st || width == 0 || height == 0) return st;
     const size_t bytes = (size_t)width * height * 3 / 2;
     hipStream_t s = c->stream;
-    if ((st = stage_in(c, s, nv12_in, bytes, bytes, 1))) return st;
+    StreamDrain drain(HipStreamSync{}, drain_counter(c));
+    if ((st = stage_in(c, s, nv12_in, bytes, bytes, 1, drain))) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, bytes))) return st;
     st = nv12_bgr_equalize_dev(c, s, c->d_stage_in, bytes, c->d_stage_out, bytes, width, height, 1);
     if (st) return st;
-    return stage_out(c, s, nv12_out, bytes, bytes, 1);
+    return stage_out(c, s, nv12_out, bytes, bytes, 1, drain);
 }
 
 mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src_step, size_t src_frame_stride,
                                         void* d_dst, size_t dst_step, size_t dst_frame_stride,
                                         int width, int height, int n_frames, int code, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     mi_status st = check_cvt420(c, d_src, src_step, d_dst, dst_step, width, height, n_frames, code);
     if (st || width == 0 || height == 0 || n_frames == 0) return st;
     const bool enc = code == MI_COLOR_BGR2YUV_I420;
@@ -328,7 +330,7 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* c, const void* d_src, size_t src
 
 mi_status mi_cvt_color_420_u8(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int width, int height, int code)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     mi_status st = check_cvt420(c, src, src_step, dst, dst_step, width, height, 1, code);
     if (st || width == 0 || height == 0) return st;
     const bool enc = code == MI_COLOR_BGR2YUV_I420;
@@ -336,11 +338,12 @@ mi_status mi_cvt_color_420_u8(mi_ctx* c, const uint8_t* src, size_t src_step, ui
     const size_t in_row = enc ? c3_row : (size_t)width, in_rows = enc ? (size_t)height : (size_t)height * 3 / 2;
     const size_t out_row = enc ? (size_t)width : c3_row, out_rows = enc ? (size_t)height * 3 / 2 : (size_t)height, out_bytes = enc ? pl_bytes : c3_bytes;
     hipStream_t s = c->stream;
-    if ((st = stage_in(c, s, src, src_step, in_row, in_rows))) return st;
+    StreamDrain drain(HipStreamSync{}, drain_counter(c));
+    if ((st = stage_in(c, s, src, src_step, in_row, in_rows, drain))) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, out_bytes))) return st;
     st = cvt420_dev(c, s, code, c->d_stage_in, c->d_stage_out, c3_row, c3_bytes, pl_bytes, width, height, 1);
     if (st) return st;
-    return stage_out(c, s, dst, dst_step, out_row, out_rows);
+    return stage_out(c, s, dst, dst_step, out_row, out_rows, drain);
 }
 
 }  // extern "C"

@@ -11,7 +11,29 @@ struct PendingEvent { hipEvent_t a, b; int kernel; };
 struct PinnedRange { uintptr_t lo, hi; };
 static std::mutex g_pin_mu;
 static std::vector<PinnedRange> g_pinned;
-static bool host_range_pinned(const void* p, size_t bytes)
+static std::atomic<uint64_t> g_pin_generation{1};                // bumped by mi_host_register / mi_host_unregister
+
+// Per-context memory of ranges the runtime was asked about and did NOT know as pinned.  Only the negative verdict is remembered:
+// "not pinned" is always safe (the plane is packed through the library's own staging), while a remembered "pinned" could outlive
+// the caller's hipHostUnregister and hand the runtime pageable memory.  Entries expire with every (un)registration and after
+// kNegLife look-ups, so memory the caller pins later on is noticed again.
+struct PinnedNegCache {
+    static constexpr int kSlots = 8;
+    static constexpr uint32_t kNegLife = 4096;
+    struct Entry { uintptr_t lo = 0; size_t bytes = 0; uint32_t left = 0; } e[kSlots];
+    uint64_t generation = 0;
+    int next = 0;
+    bool hit(uintptr_t lo, size_t bytes)
+    {
+        const uint64_t g = g_pin_generation.load(std::memory_order_relaxed);
+        if (g != generation) { for (auto& x : e) x.left = 0; generation = g; return false; }
+        for (auto& x : e) if (x.left && x.lo == lo && x.bytes == bytes) { --x.left; return true; }
+        return false;
+    }
+    void remember(uintptr_t lo, size_t bytes) { e[next] = Entry{lo, bytes, kNegLife}; next = (next + 1) % kSlots; }
+};
+
+static bool host_range_pinned(const void* p, size_t bytes, PinnedNegCache* neg = nullptr)
 {
     if (!p || bytes == 0) return false;
     const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
@@ -19,14 +41,19 @@ static bool host_range_pinned(const void* p, size_t bytes)
         std::lock_guard<std::mutex> lk(g_pin_mu);
         for (const auto& r : g_pinned) if (lo >= r.lo && hi <= r.hi) return true;
     }
+    if (neg && neg->hit(lo, bytes)) return false;
     // not registered through mi_host_register: memory the caller pinned itself (hipHostMalloc / hipHostRegister, a pinned torch
-    // tensor) is recognised by asking the runtime about both ends of the range
+    // tensor) is recognised by asking the runtime about both ends of the range.  An unknown pointer is not an error worth keeping:
+    // only the error THIS query raised is cleared (a pending error of an earlier asynchronous call is left for its own check).
     auto pinned_at = [](const void* q) {
         hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        const hipError_t before = hipPeekAtLastError();
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) { if (before == hipSuccess) (void)hipGetLastError(); return false; }
         return at.type == hipMemoryTypeHost;
     };
-    return pinned_at(p) && pinned_at((const uint8_t*)p + bytes - 1);
+    const bool pinned = pinned_at(p) && pinned_at((const uint8_t*)p + bytes - 1);
+    if (!pinned && neg) neg->remember(lo, bytes);
+    return pinned;
 }
 
 // Concurrency guard for the fused kernel.  Its workgroups wait for each other, so every slice of a frame (T
@@ -52,12 +79,40 @@ struct mi_ctx {
     uint32_t* d_partial = nullptr; size_t partial_bytes = 0;     // histogram partials
     uint8_t*  d_luts = nullptr;    size_t luts_bytes = 0;        // per-frame / per-tile LUTs
     uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (self-cleaning; all per-launch
-                                                                 // state lives in it, so captured launches replay unchanged)
+                                                                 // state lives in it, so captured launches replay unchanged).  The
+                                                                 // ticket stamps are PART of the block: stamps, epochs and checksums
+                                                                 // share one lifetime (a retired block keeps its own stamps for the
+                                                                 // graphs that still replay into it)
     size_t fused_cap = 0;                                        // frames the block is laid out for
-    uint32_t* d_fused_flags = nullptr; size_t fused_flags_bytes = 0;   // ticket stamps of the fused kernel
+    size_t fused_ticket_cap = 0;                                 // ticket stamps the block holds
+    uint32_t fused_generation = 0;                               // blocks this context has allocated so far (selects the host mirror word)
     uint64_t fused_stat_base[4] = {};                            // statistics of hand-off blocks this context has since replaced
     uint64_t fused_seen_hard = 0;                                // unrecoverable frames already reported to the caller
-    uint32_t* h_status = nullptr;                                // pinned mirror of the device statistics words
+    uint32_t* h_status = nullptr;                                // pinned mirror of the device statistics words (blocking reads)
+    // Demotion of the fused path (equalize_fused.inc.hpp): the finish kernel also writes its "launches repaired" counter into a
+    // word of pinned host memory, so the host learns about repaired launches without a copy or a synchronisation.
+    uint32_t* h_mirror = nullptr;                                // pinned, device-written: [0] repaired launches of the current block
+    uint64_t fused_repaired_base = 0;                            // ... of blocks since replaced
+    uint64_t fused_window_start_repaired = 0;                    // repaired launches seen when the current observation window began
+    uint32_t fused_window_launches = 0;                          // fused launches issued in the window
+    uint64_t fused_demotions = 0;                                // statistic "fused_demotions"
+    bool fused_demoted = false;                                  // launches take the three-kernel path until fused_reprobe_at
+    bool fused_probing = false;                                  // the launch after a demotion period: one repair demotes again
+    std::chrono::steady_clock::time_point fused_reprobe_at{};
+    int fused_reprobe_ms = 1000, fused_reprobe_ms_now = 1000;    // option "fused_reprobe_ms": first demotion period (doubles, up to 64x)
+    int fused_demote_after = 3;                                  // option "fused_demote_after": repaired launches per window that demote (0 = never)
+    // pipes on this context (pipe.inc.hpp): one at a time; while frames are pending the other compute entry points answer MI_ERR_BUSY
+    int pipes_open = 0, pipe_pending = 0;
+    hipEvent_t ev_scratch = nullptr;                             // end of the last device-form call on a caller stream, while a pipe is open
+    bool scratch_foreign = false;                                // ... recorded and not yet waited for by the pipe's compute stream
+    hipStream_t cur_stream = nullptr;                            // stream of the device-form call in progress (pick_stream) ...
+    bool cur_stream_set = false;                                 // ... valid (the null stream is a legitimate value)
+    bool fused_pair_open = false;                                // a fused kernel was launched and its finish kernel was not (a failed launch in between):
+                                                                 // the hand-off block's counters are in an unknown state and are reset before the next launch
+    unsigned long long error_drains = 0;                                // statistic "error_drains": error exits that had to drain a stream first
+    PinnedNegCache pin_neg;
+    mi_host::CopyCrew* crew = nullptr;                           // helper thread for staging copies of the host forms (created on first use)
+    int host_copy_threads = 2;                                   // option "host_copy_threads": 1 = the calling thread copies alone
     bool capturing = false;                                      // the stream of the call in progress is being captured (hipGraph)
     bool graph_captured = false;                                 // a capture has been seen: scratch referenced by graph nodes is never freed
     std::vector<void*> retired;                                  // ... it is parked here until the context is destroyed
@@ -65,12 +120,14 @@ struct mi_ctx {
     int fused_wgs_per_cu = 4;                                    // MI_LUMAEQ_FUSED_WGS_PER_CU
     int fused_vpt = kVPT;                                        // MI_LUMAEQ_FUSED_VPT (8, 16, 20, 24)
     int fused_acquire = 1;                                       // MI_LUMAEQ_FUSED_ACQUIRE
-    int fused_fault_inject = 0;                                  // test hook (option "fused_fault_inject": 0 off, 1..3 see kernels/equalize_fused.hip.h)
-    int fused_timeout_us = 0;                                    // test hook (option "fused_timeout_us"): > 0 overrides fused_timeout_ms
+#ifdef MI_TEST_HOOKS                                             // libmi_lumaeq_test.so only (csrc/Makefile): the product library has neither
+    int fused_fault_inject = 0;                                  // option "fused_fault_inject": 0 off, 1..3 see kernels/equalize_fused.hip.h
+    int fused_timeout_us = 0;                                    // option "fused_timeout_us": > 0 overrides fused_timeout_ms
+    int hip_fail_after = 0;                                      // option "hip_fail_after": the n-th checked HIP call from now on reports a failure
+                                                                 // (after it has been issued), 0 = off
+#endif
     int fused_timeout_ms = 50;                                   // option "fused_timeout_ms": bound of every inter-workgroup wait
     int bgr_fused = 1;                                           // option "bgr_fused": 9 B/px two-pass BGR luma equalization / CLAHE
-    int host_direct = 0;                                         // option "host_direct": UNPINNED contiguous host planes are handed to the runtime's own
-                                                                 // pageable-copy path instead of the context's pinned staging (see host_op)
     int clahe_fp_contract = 0;                                   // option "clahe_fp_contract": CLAHE interpolation with GCC's FMA contraction (aarch64 OpenCV builds)
     int clahe16_transposed = 0;                                  // option "clahe16_transposed": value-major LUTs for 16-bit interpolation (tiles <= 64)
     int clahe_hist_threads = 512;                                // option "clahe_hist_threads": 256 or 512 threads per tile-histogram workgroup
@@ -109,11 +166,31 @@ mi_status fail(mi_ctx* c, mi_status s, const char* msg)
     return s;
 }
 
+// Test hook (libmi_lumaeq_test.so only): option "hip_fail_after" = n makes the n-th checked HIP call from now on REPORT a failure
+// after it has been issued -- the copy or launch is really in flight, which is exactly the state the error paths must clean up.
+#ifdef MI_TEST_HOOKS
+inline hipError_t test_hook_result(mi_ctx* c, hipError_t e)
+{
+    if (c && c->hip_fail_after > 0 && --c->hip_fail_after == 0 && e == hipSuccess) return hipErrorUnknown;
+    return e;
+}
+#define MI_HOOKED(c, e) test_hook_result((c), (e))
+#else
+#define MI_HOOKED(c, e) (e)
+#endif
+
 #define HIPCHK(c, expr)                                         \
     do {                                                        \
-        hipError_t e__ = (expr);                                \
+        hipError_t e__ = MI_HOOKED((c), (expr));                \
         if (e__ != hipSuccess) return fail_hip((c), e__, #expr); \
     } while (0)
+
+// "Never return while a DMA on caller memory is in flight" (drain_guard.hpp): error exits synchronise the watched streams.
+struct HipStreamSync {
+    void operator()(void* s) const { if (s) (void)hipStreamSynchronize((hipStream_t)s); else (void)hipDeviceSynchronize(); }
+};
+using StreamDrain = mi_host::DrainOnExit<HipStreamSync>;
+inline unsigned long long* drain_counter(mi_ctx* c) { return &c->error_drains; }
 
 template <class T>
 mi_status grow_dev(mi_ctx* c, T** p, size_t* have, size_t need)
@@ -154,6 +231,8 @@ mi_status grow_pinned(mi_ctx* c, uint8_t** p, size_t* have, size_t need)
 struct Bracket {
     mi_ctx* c; int kernel; hipEvent_t a = nullptr, b = nullptr; bool on;
     Bracket(mi_ctx* c_, int k) : c(c_), kernel(k), on(!c_->capturing && (c_->profiling == 1 || (c_->profiling == 2 && k != MI_K_FUSED_FINISH))) {}
+    Bracket(const Bracket&) = delete;
+    Bracket& operator=(const Bracket&) = delete;
     hipError_t acquire()
     {
         if (!on) return hipSuccess;
@@ -163,7 +242,9 @@ struct Bracket {
         }
         return hipSuccess;
     }
-    void submitted() { if (on) c->pending.push_back({a, b, kernel}); }
+    void submitted() { if (on) { c->pending.push_back({a, b, kernel}); a = b = nullptr; } }
+    // a launch that failed after acquire(): the events go back to the pool instead of leaking
+    ~Bracket() { for (hipEvent_t e : {a, b}) if (e) c->free_events.push_back(e); }
 };
 
 #define LAUNCH(c, s, kid, kern, grid, block, shmem, ...)                                              \

@@ -47,7 +47,7 @@ mi_status mi_analyze_diff_u8_batch_dev(mi_ctx* c, const void* d_a, size_t a_step
                                        void* d_diff, size_t diff_step, size_t diff_frame_stride,
                                        int width, int height, int n_frames, int threshold, mi_diff_stats* d_stats, void* stream)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     mi_status st = check_diff_args(c, d_a, a_step, d_b, b_step, d_diff, diff_step, width, height, n_frames, threshold);
     if (st) return st;
     if (n_frames == 0) return MI_OK;
@@ -61,7 +61,7 @@ mi_status mi_analyze_diff_u8_batch_dev(mi_ctx* c, const void* d_a, size_t a_step
 mi_status mi_analyze_diff_u8(mi_ctx* c, const uint8_t* a, size_t a_step, const uint8_t* b, size_t b_step,
                              uint8_t* diff, size_t diff_step, int width, int height, int threshold, mi_diff_stats* out)
 {
-    ENTER(c);
+    ENTER_COMPUTE(c);
     mi_status st = check_diff_args(c, a, a_step, b, b_step, diff, diff_step, width, height, 1, threshold);
     if (st) return st;
     if (!out) return fail(c, MI_ERR_BAD_ARG, "null out");
@@ -79,6 +79,8 @@ mi_status mi_analyze_diff_u8(mi_ctx* c, const uint8_t* a, size_t a_step, const u
     if ((st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, plane + 64))) return st;
     copy_rows(c->h_pin_in, (size_t)width, a, a_step, width, height);
     if (b) copy_rows(c->h_pin_in + plane, (size_t)width, b, b_step, width, height);
+    StreamDrain drain(HipStreamSync{}, drain_counter(c));        // only library-owned staging is in flight here; an error exit still leaves the stream idle
+    drain.watch(s);
     HIPCHK(c, hipMemcpyAsync(d_a, c->h_pin_in, (b ? 2 : 1) * plane, hipMemcpyHostToDevice, s));
     st = analyze_diff_dev(c, s, d_a, (size_t)width, plane, d_b, (size_t)width, plane, diff ? c->d_stage_out : nullptr, (size_t)width, plane,
                           width, height, 1, threshold, d_st);
@@ -87,6 +89,7 @@ mi_status mi_analyze_diff_u8(mi_ctx* c, const uint8_t* a, size_t a_step, const u
     mi_diff_stats* h_st = reinterpret_cast<mi_diff_stats*>(c->h_pin_out + ((plane + 15) & ~(size_t)15));
     HIPCHK(c, hipMemcpyAsync(h_st, d_st, sizeof(mi_diff_stats), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    drain.done();
     if (diff) copy_rows(diff, diff_step, c->h_pin_out, (size_t)width, width, height);
     *out = *h_st;
     return MI_OK;

@@ -4,8 +4,8 @@
 // ---- fused single-read path -----------------------------------------------------------------------------
 // Layout of the hand-off block (uint32 words; zeroed once when (re)allocated -- every launch pair leaves it ready for the next):
 //   [0..127] control words (kFused*: ticket counter, status, launch sequence number, finish arrivals, sticky statistics)
-//   cnt[cap][32] | ready[cap][32] | ghist[cap][256] | lutpub[cap][128]
-// plus a separate array of ticket stamps (d_fused_flags), one word per ticket of the largest launch seen.
+//   cnt[cap][32] | ready[cap][32] | ghist[cap][256] | lutpub[cap][128] | sflag[ticket_cap]
+// (the ticket stamps are part of the block: one word per ticket of the largest launch the block is laid out for).
 // Returns the slice size (16-byte vectors per thread) the fused kernel should run with, or 0 when the launch must take
 // the three-kernel path.  The co-residency allowance (see g_fused_ctx_live) is the conservative 1/8 of the chip when
 // other fused contexts exist on the device and half of the chip while this one is alone (an 8K frame is 405 tickets).
@@ -42,6 +42,51 @@ mi_status fused_read_stats(mi_ctx* c, hipStream_t s, uint64_t out[4])
     return MI_OK;
 }
 
+// ---- demotion -----------------------------------------------------------------------------------------------
+// A fused launch that loses the co-residency race (another process holds the compute units; the per-process allowance above
+// cannot see it) stalls for its bound -- 50 ms -- and is repaired: correct bytes, three frames late at 60 fps.  A context that
+// keeps meeting that fate gives the fused path up for a while: `fused_demote_after` repaired launches within a window of
+// kFusedWindow fused launches route the following launches through the three-kernel path (no inter-workgroup dependency,
+// nothing to stall) for `fused_reprobe_ms`; then ONE fused launch probes the GPU again, and a repair during the probe window
+// demotes at once for twice as long (up to 64x).  The host learns about repairs from a word of pinned memory the finish
+// kernel writes (FusedJob::host_repaired): no copy, no synchronisation, valid for every form including the stream-ordered ones.
+// (The reference's accelerator path has no notion of a slow or failed device call at all: OpenCLequalHist.cpp:346-367.)
+constexpr uint32_t kFusedWindow = 32;
+constexpr int kMirrorWords = 16;                                 // one word per hand-off block generation (mod 16)
+
+uint64_t fused_repaired_seen(const mi_ctx* c)
+{
+    uint64_t n = c->fused_repaired_base;
+    for (int k = 0; k < kMirrorWords; ++k) n += __atomic_load_n(c->h_mirror + k, __ATOMIC_RELAXED);
+    return n;
+}
+
+bool fused_admit(mi_ctx* c)
+{
+    if (c->fused_demote_after <= 0) return true;
+    if (c->capturing) return !c->fused_demoted;                   // a capture records whichever path is current; no bookkeeping
+    const uint64_t repaired = fused_repaired_seen(c);
+    const auto now = std::chrono::steady_clock::now();
+    if (c->fused_demoted) {
+        if (now < c->fused_reprobe_at) return false;
+        c->fused_demoted = false; c->fused_probing = true;       // the period is over: this launch probes
+        c->fused_window_start_repaired = repaired; c->fused_window_launches = 0;
+    }
+    const uint64_t limit = c->fused_probing ? 1u : (uint64_t)c->fused_demote_after;
+    if (repaired - c->fused_window_start_repaired >= limit) {
+        c->fused_reprobe_ms_now = c->fused_probing ? std::min<long long>(2LL * c->fused_reprobe_ms_now, 64LL * c->fused_reprobe_ms) : c->fused_reprobe_ms;
+        c->fused_demoted = true; c->fused_probing = false;
+        ++c->fused_demotions;
+        c->fused_reprobe_at = now + std::chrono::milliseconds(c->fused_reprobe_ms_now);
+        return false;
+    }
+    if (++c->fused_window_launches >= kFusedWindow) {            // a window without enough repairs: start the next one
+        c->fused_window_start_repaired = repaired; c->fused_window_launches = 0;
+        if (c->fused_probing) { c->fused_probing = false; c->fused_reprobe_ms_now = c->fused_reprobe_ms; }
+    }
+    return true;
+}
+
 mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
     const long long ysz = (long long)a.width * a.height;
@@ -54,52 +99,66 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     j.slice_vecs = (int)slice;
     j.T = (int)((j.nvec + slice - 1) / slice);
     j.acquire = c->fused_acquire;
+    j.timeout_ticks = (unsigned long long)std::max(1, c->fused_timeout_ms) * 100000ull;       // s_memrealtime ticks at 100 MHz
+#ifdef MI_TEST_HOOKS
     j.fault_inject = c->fused_fault_inject;
-    j.timeout_ticks = c->fused_timeout_us > 0 ? (unsigned long long)c->fused_timeout_us * 100ull     // s_memrealtime ticks at 100 MHz
-                                              : (unsigned long long)std::max(1, c->fused_timeout_ms) * 100000ull;
+    if (c->fused_timeout_us > 0) j.timeout_ticks = (unsigned long long)c->fused_timeout_us * 100ull;
+#endif
     j.U = 0;
     // UV as stand-alone 64 KiB tickets behind each frame's Y tickets: pure streaming work that fills the gaps while
     // other workgroups sit in their hand-off (measured 5 % faster than giving every Y ticket a share of the UV plane)
     if (uv && uv->bytes > 0) { j.uv = *uv; j.U = (int)((uv->bytes + 65535) / 65536); }
     const long long tickets = (long long)(j.T + j.U) * a.n_frames;
-    // capacity-based layout so the regions never move between calls with different frame counts
-    if (c->capturing && ((size_t)a.n_frames > c->fused_cap || (size_t)tickets * sizeof(uint32_t) > c->fused_flags_bytes))
-        return fail(c, MI_ERR_UNSUPPORTED, "device scratch must grow inside a stream capture: size it with one eager call of this shape first");
-    if ((size_t)a.n_frames > c->fused_cap) {
+    // A fused kernel whose finish kernel never followed (the launch in between failed) left the ticket counter and the sequence
+    // number as they were: start from a clean block instead of trusting them.
+    if (c->fused_pair_open) {
+        if (c->capturing) return fail(c, MI_ERR_UNSUPPORTED, "the fused path must be reset by an eager call after a failed launch");
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->d_fused) {
+            uint64_t st4[4];                                     // the sticky statistics live in the block: carry them over
+            mi_status st = fused_read_stats(c, s, st4);
+            if (st) return st;
+            for (int k = 0; k < 4; ++k) c->fused_stat_base[k] = st4[k];
+            const size_t words = c->fused_bytes / sizeof(uint32_t);
+            hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (words + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                               c->d_fused, words);
+            HIPCHK(c, hipGetLastError());
+            c->fused_repaired_base += __atomic_load_n(c->h_mirror + (c->fused_generation % kMirrorWords), __ATOMIC_RELAXED);
+            __atomic_store_n(c->h_mirror + (c->fused_generation % kMirrorWords), 0u, __ATOMIC_RELAXED);
+        }
+        c->fused_pair_open = false;
+    }
+    // One allocation holds the control words, the per-frame hand-off regions AND the ticket stamps, laid out by capacity so that
+    // the regions never move between calls with different frame counts.  When either capacity is exceeded the whole block is
+    // replaced: stamps, epochs and checksums always share a lifetime (a block that a captured graph still replays into keeps
+    // its own stamps -- a new block's epochs can never meet an old block's stamps).
+    if ((size_t)a.n_frames > c->fused_cap || (size_t)tickets > c->fused_ticket_cap) {
+        if (c->capturing)
+            return fail(c, MI_ERR_UNSUPPORTED, "device scratch must grow inside a stream capture: size it with one eager call of this shape first");
         size_t cap = std::max<size_t>(64, c->fused_cap);
         while (cap < (size_t)a.n_frames) cap *= 2;
-        const size_t words = kFusedCtlWords + cap * (kFlagStride + kFlagStride + 256 + kLutPubWords);
+        size_t tcap = std::max<size_t>((size_t)1 << 14, c->fused_ticket_cap);
+        while (tcap < (size_t)tickets) tcap *= 2;
+        const size_t words = kFusedCtlWords + cap * (kFlagStride + kFlagStride + 256 + kLutPubWords) + tcap;
         if (c->d_fused) {                                        // keep what the old block had counted
             uint64_t st4[4];
             mi_status st = fused_read_stats(c, s, st4);
             if (st) return st;
             for (int k = 0; k < 4; ++k) c->fused_stat_base[k] = st4[k];
         }
-        mi_status st = grow_dev(c, &c->d_fused, &c->fused_bytes, words * sizeof(uint32_t));
+        c->fused_cap = 0; c->fused_ticket_cap = 0;
+        mi_status st = grow_dev(c, &c->d_fused, &c->fused_bytes, std::max(words * sizeof(uint32_t), c->fused_bytes + 4));
         if (st) return st;
-        c->fused_cap = cap;
+        c->fused_cap = cap; c->fused_ticket_cap = tcap;
+        // hipMalloc memory is not guaranteed to be zero: epoch arithmetic starts from a clean block
         hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (words + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                            c->d_fused, words);
         HIPCHK(c, hipGetLastError());
-        if (c->d_fused_flags) {                                  // the new block restarts its epochs: old stamps must not match them
-            const size_t nwords = c->fused_flags_bytes / sizeof(uint32_t);
-            hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (nwords + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                               c->d_fused_flags, nwords);
-            HIPCHK(c, hipGetLastError());
-        }
-    }
-    {
-        // ticket stamps: stale words are harmless (they carry other launches' epochs), so growth needs no zeroing --
-        // except once, for epoch-0 safety of a fresh allocation (hipMalloc memory is not guaranteed to be zero)
-        const size_t need = (size_t)tickets * sizeof(uint32_t);
-        if (need > c->fused_flags_bytes) {
-            mi_status st = grow_dev(c, &c->d_fused_flags, &c->fused_flags_bytes, std::max(need, (size_t)1 << 16));
-            if (st) return st;
-            const size_t nwords = c->fused_flags_bytes / sizeof(uint32_t);
-            hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (nwords + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                               c->d_fused_flags, nwords);
-            HIPCHK(c, hipGetLastError());
-        }
+        // this block's word of the host mirror (repaired launches, written by the finish kernel)
+        c->fused_generation += 1;
+        uint32_t* mw = c->h_mirror + (c->fused_generation % kMirrorWords);
+        c->fused_repaired_base += __atomic_load_n(mw, __ATOMIC_RELAXED);
+        __atomic_store_n(mw, 0u, __ATOMIC_RELAXED);
     }
     const size_t cap = c->fused_cap;
     uint32_t* w = c->d_fused;
@@ -108,8 +167,10 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     j.ready = j.cnt + cap * kFlagStride;
     j.ghist = j.ready + cap * kFlagStride;
     j.lutpub = j.ghist + cap * 256;
-    j.sflag = c->d_fused_flags;
+    j.sflag = j.lutpub + cap * kLutPubWords;
+    j.host_repaired = c->h_mirror + (c->fused_generation % kMirrorWords);
     const long long grid = std::min<long long>(tickets, (long long)c->cu_count * c->fused_wgs_per_cu);
+    if (!c->capturing) c->fused_pair_open = true;
     switch (vpt) {
         case 8:  LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<8>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
         case 20: LAUNCH(c, s, MI_K_FUSED, equalize_fused_kernel<20>, dim3((unsigned)grid), dim3(kThreads), 0, j); break;
@@ -120,12 +181,13 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     // always: housekeeping in the normal case, stamp-driven repair when a bounded wait expired (kernels/equalize_fused.hip.h)
     const int fin_grid = (int)std::min<long long>(a.n_frames, (long long)c->cu_count * 4);
     LAUNCH(c, s, MI_K_FUSED_FINISH, fused_finish_kernel, dim3((unsigned)fin_grid), dim3(kThreads), 0, j);
+    c->fused_pair_open = false;
     return MI_OK;
 }
 
 mi_status equalize_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
-    if (fused_applicable(c, a, uv)) return equalize_fused_dev(c, s, a, uv);
+    if (fused_applicable(c, a, uv) && fused_admit(c)) return equalize_fused_dev(c, s, a, uv);
     for (int f0 = 0; f0 < a.n_frames; f0 += kMaxGridY) {
         const int nf = std::min(kMaxGridY, a.n_frames - f0);
         int nparts = 0;

@@ -13,8 +13,12 @@
 // so PCIe runs in both directions at once while the kernels (tens of microseconds per 4K frame) hide behind it.
 // Frames complete in submission order (mi_pipe_wait).  Host memory that was registered with mi_host_register (a recycled
 // frame pool) is DMA'd asynchronously as it is; unpinned (pageable) memory is copied through pinned staging buffers of the
-// slot by the calling thread (into them at submit, out of them at wait) -- the library never hands the runtime memory it did
-// not pin itself (host_op() in capi.inc.hpp says why); option "host_direct" = 1 restores the runtime's own pageable path.
+// slot by the calling thread and the context's helper thread (into them at submit, out of them at wait) -- the library never
+// hands the runtime memory it did not pin itself (host_op() in capi.inc.hpp says why).
+// Error paths: a failure inside submit drains the three streams before it returns (nothing stays in flight on the caller's
+// `in` / `out`) and does not occupy a slot; a failure inside wait drains them and STILL retires the slot, so the tags a caller
+// keeps (FramePool's inflight queue, Pipe._held in the Python binding) stay in step with the pipe.  One pipe per context; while
+// frames are pending the context's other compute entry points answer MI_ERR_BUSY.
 // All pipes of a process on one device share the SAME three streams: a second worker on a GPU then interleaves its frames
 // into the same queues instead of adding queues (8 streams on one device were measured 30 % SLOWER than 3: HIP multiplexes
 // streams onto 4 hardware queues, and unrelated copies end up ordered behind each other); as a side effect the fused
@@ -27,8 +31,7 @@ struct PipeSlot {
     hipEvent_t ev_h2d = nullptr, ev_k = nullptr, ev_done = nullptr;
     const uint8_t* in = nullptr; uint8_t* out = nullptr;
     uint64_t tag = 0;
-    bool out_async = false;                                       // D2H was queued at submit (pinned memory, or the slot's own staging)
-    bool out_staged = false;                                      // ... into h_out: mi_pipe_wait copies it to the caller's frame
+    bool out_staged = false;                                      // the D2H queued at submit lands in h_out: mi_pipe_wait copies it to the caller's frame
     uint8_t* h_in = nullptr; uint8_t* h_out = nullptr;            // pinned staging for frames the caller did not pin (allocated on first use)
     mi_status st = MI_OK;
 };
@@ -105,6 +108,7 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
     if (cfg->uv_mode != MI_UV_FILL128 && cfg->uv_mode != MI_UV_COPY) return fail(c, MI_ERR_BAD_ARG, "bad uv_mode");
     if (cfg->op == MI_OP_CLAHE && (cfg->tiles_x <= 0 || cfg->tiles_y <= 0)) return fail(c, MI_ERR_BAD_ARG, "tile grid must be >= 1x1");
     if (cfg->uv_policy < MI_PIPE_UV_AUTO || cfg->uv_policy > MI_PIPE_UV_DEVICE) return fail(c, MI_ERR_BAD_ARG, "bad uv_policy");
+    if (c->pipes_open > 0) return fail(c, MI_ERR_BUSY, "this context already has a pipe: one pipe per context (the pipe uses the context's scratch)");
     mi_pipe* p = new (std::nothrow) mi_pipe();
     if (!p) return fail(c, MI_ERR_OOM, "pipe allocation failed");
     p->c = c; p->cfg = *cfg;
@@ -180,6 +184,7 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
         if (st) return bail(st);
         if (e != hipSuccess) return bail(MI_ERR_HIP);
     }
+    ++c->pipes_open;
     *out = p;
     return MI_OK;
 }
@@ -187,7 +192,10 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
 void mi_pipe_destroy(mi_pipe* p)
 {
     if (!p) return;
-    std::unique_lock<std::mutex> lk(p->c->mu);
+    mi_ctx* c = p->c;
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->pipe_pending -= (int)p->count;                             // frames never waited for: pipe_free() drains the streams
+    if (c->pipes_open > 0) --c->pipes_open;
     pipe_free(p);
 }
 
@@ -213,32 +221,37 @@ mi_status mi_pipe_submit(mi_pipe* p, const uint8_t* in, uint8_t* out, uint64_t t
         *h = (uint8_t*)q;
         return MI_OK;
     };
-    // pinned memory is DMA'd as it is; anything else goes through the slot's pinned staging buffer (the calling thread's memcpy)
+    // pinned memory is DMA'd as it is; anything else goes through the slot's pinned staging buffers.  Both are settled before
+    // anything is enqueued: an allocation failure leaves nothing to undo.
+    const bool in_pinned = host_range_pinned(in, p->xfer_in, &c->pin_neg);
+    const bool out_pinned = host_range_pinned(out, p->uv_dev ? fbytes : p->ybytes, &c->pin_neg);
+    mi_status st;
+    if (!in_pinned && (st = staging(&sl.h_in, fbytes))) return st;
+    if (!out_pinned && (st = staging(&sl.h_out, fbytes))) return st;
+    sl.out_staged = !out_pinned;
     const uint8_t* h2d_src = in;
-    if (!c->host_direct && !host_range_pinned(in, p->xfer_in)) {
-        mi_status st = staging(&sl.h_in, fbytes);
-        if (st) return st;
-        memcpy(sl.h_in, in, p->xfer_in);
+    if (!in_pinned) {
+        CrewCall crew(c, p->xfer_in >= 4 * mi_host::CopyCrew::kMinBytes);
+        crew.copy(sl.h_in, p->xfer_in, in, p->xfer_in, (int)std::min<size_t>(p->xfer_in, 0x7fffffff), 1);
         h2d_src = sl.h_in;
     }
+    // from here on copies on caller memory are (about to be) in flight: every error exit waits for all three streams first
+    StreamDrain drain(HipStreamSync{}, drain_counter(c));
+    drain.watch(p->s_h2d); drain.watch(p->s_k); drain.watch(p->s_d2h);
+    // a device-form call on a caller's stream since the last frame: the kernels share this context's scratch with it
+    if (c->scratch_foreign) { HIPCHK(c, hipStreamWaitEvent(p->s_k, c->ev_scratch, 0)); c->scratch_foreign = false; }
     HIPCHK(c, hipMemcpyAsync(sl.d_in, h2d_src, p->xfer_in, hipMemcpyHostToDevice, p->s_h2d));
     HIPCHK(c, hipEventRecord(sl.ev_h2d, p->s_h2d));
     HIPCHK(c, hipStreamWaitEvent(p->s_k, sl.ev_h2d, 0));
-    mi_status st = pipe_run_op(p, sl);
-    if (st) return st;
+    if ((st = pipe_run_op(p, sl))) return st;
     HIPCHK(c, hipEventRecord(sl.ev_k, p->s_k));
-    const bool out_pinned = host_range_pinned(out, p->uv_dev ? fbytes : p->ybytes);
-    sl.out_staged = !out_pinned && !c->host_direct;
-    sl.out_async = out_pinned || sl.out_staged;
-    if (sl.out_staged && (st = staging(&sl.h_out, fbytes))) return st;
-    if (sl.out_async) {
-        HIPCHK(c, hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0));
-        HIPCHK(c, hipMemcpyAsync(sl.out_staged ? sl.h_out : out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
-        if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)
-            HIPCHK(c, hipMemcpyAsync(p->h_hard + (&sl - p->slots.data()), c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_d2h));
-        HIPCHK(c, hipEventRecord(sl.ev_done, p->s_d2h));
-    }
-    ++p->count; ++p->submitted;
+    HIPCHK(c, hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0));
+    HIPCHK(c, hipMemcpyAsync(sl.out_staged ? sl.h_out : out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
+    if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)
+        HIPCHK(c, hipMemcpyAsync(p->h_hard + (&sl - p->slots.data()), c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_d2h));
+    HIPCHK(c, hipEventRecord(sl.ev_done, p->s_d2h));
+    drain.done();                                                 // success: the frame stays in flight, that is the point of a pipe
+    ++p->count; ++p->submitted; ++c->pipe_pending;
     return MI_OK;
 }
 
@@ -257,18 +270,21 @@ mi_status mi_pipe_wait(mi_pipe* p, uint64_t* tag, uint8_t** out_frame)
         if (p->cfg.uv_mode == MI_UV_FILL128) memset(sl.out + p->ybytes, 128, p->uvbytes);
         else if (sl.out != sl.in) memmove(sl.out + p->ybytes, sl.in + p->ybytes, p->uvbytes);
     }
-    if (sl.out_async) {
-        HIPCHK(c, hipEventSynchronize(sl.ev_done));
-        if (sl.out_staged) memcpy(sl.out, sl.h_out, p->xfer_out);
-    } else {                                                      // option "host_direct": the runtime's own (blocking) pageable copy
-        HIPCHK(c, hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0));
-        HIPCHK(c, hipMemcpyAsync(sl.out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
-        if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)
-            HIPCHK(c, hipMemcpyAsync(p->h_hard + slot, c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_d2h));
-        HIPCHK(c, hipStreamSynchronize(p->s_d2h));
+    mi_status st = MI_OK;
+    const hipError_t e = MI_HOOKED(c, hipEventSynchronize(sl.ev_done));
+    if (e != hipSuccess) {
+        // the frame is lost, but nothing may stay in flight on its buffers and the slot must not be handed out while a DMA is pending
+        st = fail_hip(c, e, "hipEventSynchronize(frame done)");
+        for (hipStream_t s : {p->s_h2d, p->s_k, p->s_d2h}) (void)hipStreamSynchronize(s);
+        ++c->error_drains;
+    } else if (sl.out_staged) {
+        CrewCall crew(c, p->xfer_out >= 4 * mi_host::CopyCrew::kMinBytes);
+        crew.copy(sl.out, p->xfer_out, sl.h_out, p->xfer_out, (int)std::min<size_t>(p->xfer_out, 0x7fffffff), 1);
     }
+    // the slot is retired WHATEVER happened: one mi_pipe_wait = one tag gone, so the caller's own queue stays in step
     p->head = (p->head + 1) % p->slots.size();
-    --p->count; ++p->completed;
+    --p->count; ++p->completed; --c->pipe_pending;
+    if (st) return st;
     const uint64_t hard = c->fused_stat_base[2] + p->h_hard[slot];
     if (p->cfg.op == MI_OP_EQUALIZE && hard > c->fused_seen_hard) {
         c->fused_seen_hard = hard;

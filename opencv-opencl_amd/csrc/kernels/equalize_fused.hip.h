@@ -58,7 +58,9 @@ struct FusedJob {
     int T, U;                                       // Y tickets / UV tickets per frame
     int slice_vecs;                                 // 16-byte vectors per Y ticket (kThreads * VPT)
     int acquire;                                    // 1: consumers issue an agent acquire before reading the LUT
-    int fault_inject;                               // test hook, see equalize_fused_kernel
+#ifdef MI_TEST_HOOKS
+    int fault_inject;                               // libmi_lumaeq_test.so only, see equalize_fused_kernel
+#endif
     unsigned long long timeout_ticks;               // bound of every wait, in 100 MHz ticks
     UVJob uv;
     uint32_t* ctl;                                  // control words (kFused*)
@@ -66,8 +68,16 @@ struct FusedJob {
     uint32_t* cnt;                                  // [cap][kFlagStride] reset by the last arriver of a frame
     uint32_t* ready;                                // [cap][kFlagStride] stamped with the launch epoch
     uint32_t* lutpub;                               // [cap][kLutPubWords] checksum carries the launch epoch
-    uint32_t* sflag;                                // [n_frames * (T+U)]  ticket k done <=> sflag[k] == epoch
+    uint32_t* sflag;                                // [n_frames * (T+U)]  ticket k done <=> sflag[k] == epoch (part of the same block)
+    uint32_t* host_repaired;                        // pinned host word: "launches repaired" of this block, written by the finish kernel
 };
+
+// The three injected failures exist in libmi_lumaeq_test.so only (-DMI_TEST_HOOKS): the shipping kernel has no such branch.
+#ifdef MI_TEST_HOOKS
+#define MI_FAULT(j, n) ((j).fault_inject == (n))
+#else
+#define MI_FAULT(j, n) false
+#endif
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void zero_words_kernel(uint32_t* p, size_
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads) p[i] = 0;
 }
 
-// fault_inject (test hook, option "fused_fault_inject"):
+// fault_inject (libmi_lumaeq_test.so only, option "fused_fault_inject"):
 //   1  the last arriver of frame 0 leaves without publishing its LUT (lost producer: the consumers' waits expire);
 //   2  the workgroups holding slices 0 and 1 of frame min(1, n-1), unless they are the last arriver, receive the LUT, then
 //      raise *status and leave without writing (a frame left partly written, its LUT published);
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
         }
         __syncthreads();
         uint8_t my_lut;
-        if (sh.last && j.fault_inject == 1 && f == 0) break;         // test hook 1: a lost producer (the others must time out)
+        if (sh.last && MI_FAULT(j, 1) && f == 0) break;         // test hook 1: a lost producer (the others must time out)
         if (sh.last) {
             // ---- 3. last arriver: collect, verify, compute and publish the LUT
             uint32_t h = 0;
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
                 const uint32_t w = sh.lut_words[t];
                 uint32_t* pub = j.lutpub + (size_t)f * kLutPubWords;
                 st_agent(pub + t, w);
-                const uint32_t sum = lut_checksum(wave_sum(w), epoch) + (j.fault_inject == 3 && f == 0 ? 1u : 0u);   // test hook 3
+                const uint32_t sum = lut_checksum(wave_sum(w), epoch) + (MI_FAULT(j, 3) && f == 0 ? 1u : 0u);   // test hook 3
                 if (t == 0) {
                     st_agent(pub + 64, sum);
                     st_agent(j.cnt + (size_t)f * kFlagStride, 0u);  // all T arrivals are in: leave the counter clean for the next launch
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // write-through stores have left this CU
                 if (t == 0) st_agent(j.ready + (size_t)f * kFlagStride, epoch);
             }
-            if (j.fault_inject == 3 && f == 0) break;               // test hook 3: nobody can use this frame's LUT
+            if (MI_FAULT(j, 3) && f == 0) break;               // test hook 3: nobody can use this frame's LUT
         } else {
             // ---- 4. wait for the frame's LUT
             if (t == 0) {
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(kThreads, 4) void equalize_fused_kernel(FusedJob j)
             }
             __syncthreads();
             if (!sh.ok) break;
-            if (j.fault_inject == 2 && r <= 1 && f == (j.n_frames > 1 ? 1 : 0)) {   // test hook 2: leave a frame partly written
+            if (MI_FAULT(j, 2) && r <= 1 && f == (j.n_frames > 1 ? 1 : 0)) {   // test hook 2: leave a frame partly written
                 if (t == 0) st_agent(status, 1u);
                 break;
             }
@@ -347,8 +357,10 @@ __global__ __launch_bounds__(kThreads) void fused_finish_kernel(FusedJob j)
         const uint32_t arrived = __hip_atomic_fetch_add(j.ctl + kFusedFin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == gridDim.x - 1) {
             if (status != 0) {
-                __hip_atomic_fetch_add(stats + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t repaired = __hip_atomic_fetch_add(stats + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
                 st_agent(stats + 3, status);
+                // the host decides about demoting the fused path from this word, without a copy or a synchronisation
+                if (j.host_repaired) __hip_atomic_store(j.host_repaired, repaired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             st_agent(j.ctl + kFusedStatus, 0u);
             st_agent(j.ctl + kFusedWork, 0u); st_agent(j.ctl + kFusedWork + 1, 0u);

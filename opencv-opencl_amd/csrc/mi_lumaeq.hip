@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -19,6 +20,9 @@
 #include <new>
 #include <string>
 #include <vector>
+
+#include "host/drain_guard.hpp"           // stand-alone helpers (CPU-testable: tests/cxx/test_host_helpers.cpp)
+#include "host/copy_crew.hpp"
 
 using namespace mi;
 

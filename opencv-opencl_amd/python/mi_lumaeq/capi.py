@@ -12,6 +12,7 @@ import numpy as np
 
 _ROOT = Path(__file__).resolve().parents[2]          # opencv-opencl_amd/
 _LIB_PATH = _ROOT / "lib" / "libmi_lumaeq.so"
+_TEST_LIB_PATH = _ROOT / "lib" / "libmi_lumaeq_test.so"      # same sources + test hooks (-DMI_TEST_HOOKS); loaded by tests only
 
 UV_FILL128, UV_COPY = 0, 1
 STREAM_CTX = C.c_void_p(-1).value      # MI_STREAM_CTX: the context's private stream; 0/None = HIP null stream
@@ -62,6 +63,7 @@ class MiError(RuntimeError):
 
 
 _lib = None
+_test_lib = None
 
 
 def lib_path() -> Path:
@@ -71,9 +73,21 @@ def lib_path() -> Path:
 def lib() -> C.CDLL:
     """Load libmi_lumaeq.so.  No fallback: a missing library is an error."""
     global _lib
-    if _lib is not None:
-        return _lib
-    p = lib_path()
+    if _lib is None:
+        _lib = _load(lib_path())
+    return _lib
+
+
+def test_lib() -> C.CDLL:
+    """libmi_lumaeq_test.so: the product sources built with the test hooks (options "fused_fault_inject", "fused_timeout_us",
+    "hip_fail_after").  Tests pass it to Context(device, lib=test_lib()); nothing else loads it."""
+    global _test_lib
+    if _test_lib is None:
+        _test_lib = _load(Path(os.environ.get("MI_LUMAEQ_TEST_LIB", str(_TEST_LIB_PATH))))
+    return _test_lib
+
+
+def _load(p: Path) -> C.CDLL:
     if not p.exists():
         raise FileNotFoundError(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -133,7 +147,6 @@ def lib() -> C.CDLL:
     L.mi_pipe_depth.argtypes = [vp]
     L.mi_ctx_set_profiling.argtypes = [vp, i]
     L.mi_ctx_profile_read.argtypes = [vp, C.POINTER(_Profile), i]
-    _lib = L
     return L
 
 
@@ -202,9 +215,10 @@ atexit.register(_close_live_contexts)
 class Context:
     """mi_ctx wrapper.  One per (thread x device), like the reference's per-worker OpenCL objects."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, lib: "C.CDLL | None" = None):
+        self._L = lib if lib is not None else globals()["lib"]()
         self._h = C.c_void_p()
-        rc = lib().mi_ctx_create(int(device), C.byref(self._h))
+        rc = self._L.mi_ctx_create(int(device), C.byref(self._h))
         if rc != 0:
             raise MiError(rc, f"mi_ctx_create(device={device})")
         _live_contexts.add(self)
@@ -212,7 +226,7 @@ class Context:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             h, self._h = self._h, None
-            lib().mi_ctx_destroy(h)
+            self._L.mi_ctx_destroy(h)
 
     def __del__(self):
         # Never call into the library while the interpreter is finalising: the atexit hook has already closed
@@ -232,7 +246,7 @@ class Context:
 
     def _chk(self, rc: int, what: str):
         if rc != 0:
-            raise MiError(rc, what, lib().mi_ctx_last_error_msg(self._h).decode())
+            raise MiError(rc, what, self._L.mi_ctx_last_error_msg(self._h).decode())
 
     # ---- host-pointer forms (numpy = stand-in for cv::Mat memory) ----
     def equalize_hist(self, src: np.ndarray, dst: np.ndarray | None = None) -> np.ndarray:
@@ -241,7 +255,7 @@ class Context:
             dst = np.empty(src.shape, np.uint8)      # Mat::create semantics: reallocate only on mismatch
         _host2d(dst, "equalize_hist")
         h, w = src.shape
-        self._chk(lib().mi_equalize_hist_u8(self._h, src.ctypes.data, _step(src), dst.ctypes.data, _step(dst), w, h),
+        self._chk(self._L.mi_equalize_hist_u8(self._h, src.ctypes.data, _step(src), dst.ctypes.data, _step(dst), w, h),
                   "mi_equalize_hist_u8")
         return dst
 
@@ -251,7 +265,7 @@ class Context:
         if dst is None or dst.shape != src.shape or dst.dtype != np.uint8:
             dst = np.empty(src.shape, np.uint8)
         h, w = src.shape
-        self._chk(lib().mi_clahe_u8(self._h, src.ctypes.data, _step(src), dst.ctypes.data, _step(dst), w, h,
+        self._chk(self._L.mi_clahe_u8(self._h, src.ctypes.data, _step(src), dst.ctypes.data, _step(dst), w, h,
                                     float(clip_limit), int(tiles_x), int(tiles_y)), "mi_clahe_u8")
         return dst
 
@@ -263,7 +277,7 @@ class Context:
             raise MiError(1, "equalize_hist_nv12", "frame smaller than W*H*3/2")
         if out is None:
             out = np.empty(n, np.uint8)
-        self._chk(lib().mi_equalize_hist_nv12(self._h, frame.ctypes.data, out.ctypes.data, width, height, uv_mode),
+        self._chk(self._L.mi_equalize_hist_nv12(self._h, frame.ctypes.data, out.ctypes.data, width, height, uv_mode),
                   "mi_equalize_hist_nv12")
         return out
 
@@ -276,7 +290,7 @@ class Context:
             raise MiError(1, "clahe_nv12", "frame smaller than W*H*3/2")
         if out is None:
             out = np.empty(n, np.uint8)
-        self._chk(lib().mi_clahe_nv12(self._h, frame.ctypes.data, out.ctypes.data, width, height, uv_mode,
+        self._chk(self._L.mi_clahe_nv12(self._h, frame.ctypes.data, out.ctypes.data, width, height, uv_mode,
                                       float(clip_limit), int(tiles_x), int(tiles_y)), "mi_clahe_nv12")
         return out
 
@@ -287,7 +301,7 @@ class Context:
         ds = width if dst_step is None else dst_step
         sf = ss * height if src_frame is None else src_frame
         df = ds * height if dst_frame is None else dst_frame
-        self._chk(lib().mi_equalize_hist_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df,
+        self._chk(self._L.mi_equalize_hist_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df,
                                                       width, height, n_frames, stream), "mi_equalize_hist_u8_batch_dev")
 
     def clahe_batch_dev(self, src, dst, width, height, n_frames, clip_limit, tiles_x, tiles_y,
@@ -296,17 +310,17 @@ class Context:
         ds = width if dst_step is None else dst_step
         sf = ss * height if src_frame is None else src_frame
         df = ds * height if dst_frame is None else dst_frame
-        self._chk(lib().mi_clahe_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df, width, height,
+        self._chk(self._L.mi_clahe_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df, width, height,
                                               n_frames, float(clip_limit), tiles_x, tiles_y, stream),
                   "mi_clahe_u8_batch_dev")
 
     def equalize_hist_nv12_batch_dev(self, d_in, d_out, width, height, n_frames, uv_mode=UV_FILL128, stream=0):
-        self._chk(lib().mi_equalize_hist_nv12_batch_dev(self._h, _dptr(d_in), _dptr(d_out), width, height,
+        self._chk(self._L.mi_equalize_hist_nv12_batch_dev(self._h, _dptr(d_in), _dptr(d_out), width, height,
                                                         n_frames, uv_mode, stream), "mi_equalize_hist_nv12_batch_dev")
 
     def clahe_nv12_batch_dev(self, d_in, d_out, width, height, n_frames, uv_mode=UV_FILL128,
                              clip_limit=2.0, tiles_x=8, tiles_y=8, stream=0):
-        self._chk(lib().mi_clahe_nv12_batch_dev(self._h, _dptr(d_in), _dptr(d_out), width, height, n_frames,
+        self._chk(self._L.mi_clahe_nv12_batch_dev(self._h, _dptr(d_in), _dptr(d_out), width, height, n_frames,
                                                 uv_mode, float(clip_limit), tiles_x, tiles_y, stream),
                   "mi_clahe_nv12_batch_dev")
 
@@ -322,7 +336,7 @@ class Context:
                 raise ValueError("analyze_diff: planes differ in size")
         diff = np.empty((h, w), np.uint8) if want_diff else None
         out = (C.c_uint32 * 4)()
-        self._chk(lib().mi_analyze_diff_u8(self._h, a.ctypes.data, _step(a), b.ctypes.data if b is not None else None,
+        self._chk(self._L.mi_analyze_diff_u8(self._h, a.ctypes.data, _step(a), b.ctypes.data if b is not None else None,
                                            _step(b) if b is not None else 0, diff.ctypes.data if want_diff else None, w, w, h,
                                            int(threshold), C.cast(out, C.c_void_p)), "mi_analyze_diff_u8")
         r = {"above": int(out[0]), "max_diff": int(out[1]), "min_diff": int(out[2]), "total": int(out[3]),
@@ -340,7 +354,7 @@ class Context:
         af = as_ * height if a_frame is None else a_frame
         bf = bs_ * height if b_frame is None else b_frame
         df = ds_ * height if diff_frame is None else diff_frame
-        self._chk(lib().mi_analyze_diff_u8_batch_dev(self._h, _dptr(a), as_, af, _dptr(b) if b is not None else None, bs_, bf,
+        self._chk(self._L.mi_analyze_diff_u8_batch_dev(self._h, _dptr(a), as_, af, _dptr(b) if b is not None else None, bs_, bf,
                                                      _dptr(diff) if diff is not None else None, ds_, df, width, height, n_frames,
                                                      int(threshold), _dptr(d_stats), stream), "mi_analyze_diff_u8_batch_dev")
 
@@ -348,11 +362,11 @@ class Context:
     def hist_batch_dev(self, src, width, height, n_frames, d_hist, src_step=None, src_frame=None, stream=0):
         ss = width if src_step is None else src_step
         sf = ss * height if src_frame is None else src_frame
-        self._chk(lib().mi_hist_u8_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
+        self._chk(self._L.mi_hist_u8_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
                                              _dptr(d_hist), stream), "mi_hist_u8_batch_dev")
 
     def equalize_lut_batch_dev(self, d_hist, total, n_frames, d_lut, stream=0):
-        self._chk(lib().mi_equalize_lut_batch_dev(self._h, _dptr(d_hist), int(total), n_frames, _dptr(d_lut), stream),
+        self._chk(self._L.mi_equalize_lut_batch_dev(self._h, _dptr(d_hist), int(total), n_frames, _dptr(d_lut), stream),
                   "mi_equalize_lut_batch_dev")
 
     def lut_apply_batch_dev(self, src, dst, width, height, n_frames, d_lut, src_step=None, src_frame=None,
@@ -361,14 +375,14 @@ class Context:
         ds = width if dst_step is None else dst_step
         sf = ss * height if src_frame is None else src_frame
         df = ds * height if dst_frame is None else dst_frame
-        self._chk(lib().mi_lut_apply_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df, width, height,
+        self._chk(self._L.mi_lut_apply_u8_batch_dev(self._h, _dptr(src), ss, sf, _dptr(dst), ds, df, width, height,
                                                   n_frames, _dptr(d_lut), stream), "mi_lut_apply_u8_batch_dev")
 
     def clahe_tile_luts_batch_dev(self, src, width, height, n_frames, clip_limit, tiles_x, tiles_y, d_luts,
                                   src_step=None, src_frame=None, stream=0):
         ss = width if src_step is None else src_step
         sf = ss * height if src_frame is None else src_frame
-        self._chk(lib().mi_clahe_tile_luts_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
+        self._chk(self._L.mi_clahe_tile_luts_batch_dev(self._h, _dptr(src), ss, sf, width, height, n_frames,
                                                      float(clip_limit), tiles_x, tiles_y, _dptr(d_luts), stream),
                   "mi_clahe_tile_luts_batch_dev")
 
@@ -381,12 +395,12 @@ class Context:
         dst = np.empty(src.shape, np.uint16)
         h, w = src.shape
         sstep = int(src.strides[0]) if h > 1 else max(int(src.strides[0]), w * 2)
-        self._chk(lib().mi_clahe_u16(self._h, src.ctypes.data, sstep, dst.ctypes.data, w * 2, w, h, float(clip_limit),
+        self._chk(self._L.mi_clahe_u16(self._h, src.ctypes.data, sstep, dst.ctypes.data, w * 2, w, h, float(clip_limit),
                                      int(tiles_x), int(tiles_y)), "mi_clahe_u16")
         return dst
 
     def clahe16_batch_dev(self, src, dst, width, height, n_frames, clip_limit, tiles_x, tiles_y, stream=0):
-        self._chk(lib().mi_clahe_u16_batch_dev(self._h, _dptr(src), width * 2, width * 2 * height, _dptr(dst), width * 2,
+        self._chk(self._L.mi_clahe_u16_batch_dev(self._h, _dptr(src), width * 2, width * 2 * height, _dptr(dst), width * 2,
                                                width * 2 * height, width, height, n_frames, float(clip_limit), tiles_x, tiles_y, stream),
                   "mi_clahe_u16_batch_dev")
 
@@ -404,7 +418,7 @@ class Context:
         if dst is None or dst.shape != src.shape:
             dst = np.empty(src.shape, np.uint8)
         h, w = src.shape[:2]
-        self._chk(lib().mi_cvt_color_u8c3(self._h, src.ctypes.data, int(src.strides[0]) if h > 1 else w * 3, dst.ctypes.data,
+        self._chk(self._L.mi_cvt_color_u8c3(self._h, src.ctypes.data, int(src.strides[0]) if h > 1 else w * 3, dst.ctypes.data,
                                           int(dst.strides[0]) if h > 1 else w * 3, w, h, int(code)), "mi_cvt_color_u8c3")
         return dst
 
@@ -414,18 +428,18 @@ class Context:
         if dst is None or dst.shape != src.shape:
             dst = np.empty(src.shape, np.uint8)
         h, w = src.shape[:2]
-        self._chk(lib().mi_bgr_luma_op_u8c3(self._h, src.ctypes.data, int(src.strides[0]) if h > 1 else w * 3, dst.ctypes.data,
+        self._chk(self._L.mi_bgr_luma_op_u8c3(self._h, src.ctypes.data, int(src.strides[0]) if h > 1 else w * 3, dst.ctypes.data,
                                             int(dst.strides[0]) if h > 1 else w * 3, w, h, int(op), float(clip_limit),
                                             int(tiles_x), int(tiles_y)), "mi_bgr_luma_op_u8c3")
         return dst
 
     def cvt_color_batch_dev(self, src, dst, width, height, n_frames, code, stream=0):
-        self._chk(lib().mi_cvt_color_u8c3_batch_dev(self._h, _dptr(src), width * 3, width * 3 * height, _dptr(dst), width * 3,
+        self._chk(self._L.mi_cvt_color_u8c3_batch_dev(self._h, _dptr(src), width * 3, width * 3 * height, _dptr(dst), width * 3,
                                                     width * 3 * height, width, height, n_frames, int(code), stream),
                   "mi_cvt_color_u8c3_batch_dev")
 
     def bgr_luma_op_batch_dev(self, src, dst, width, height, n_frames, op=OP_EQUALIZE, clip_limit=3.0, tiles_x=4, tiles_y=4, stream=0):
-        self._chk(lib().mi_bgr_luma_op_u8c3_batch_dev(self._h, _dptr(src), width * 3, width * 3 * height, _dptr(dst), width * 3,
+        self._chk(self._L.mi_bgr_luma_op_u8c3_batch_dev(self._h, _dptr(src), width * 3, width * 3 * height, _dptr(dst), width * 3,
                                                       width * 3 * height, width, height, n_frames, int(op), float(clip_limit),
                                                       int(tiles_x), int(tiles_y), stream), "mi_bgr_luma_op_u8c3_batch_dev")
 
@@ -447,13 +461,13 @@ class Context:
             dst = np.empty(shape, np.uint8)
         sstep = int(src.strides[0]) if src.shape[0] > 1 else max(int(src.strides[0]), 1)
         dstep = int(dst.strides[0]) if dst.shape[0] > 1 else max(int(dst.strides[0]), 1)
-        self._chk(lib().mi_cvt_color_420_u8(self._h, src.ctypes.data, sstep, dst.ctypes.data, dstep, w, h, int(code)), "mi_cvt_color_420_u8")
+        self._chk(self._L.mi_cvt_color_420_u8(self._h, src.ctypes.data, sstep, dst.ctypes.data, dstep, w, h, int(code)), "mi_cvt_color_420_u8")
         return dst
 
     def cvt_color_420_batch_dev(self, src, dst, width, height, n_frames, code, stream=0):
         c3, pl = width * 3, width
         enc = code == COLOR_BGR2YUV_I420
-        self._chk(lib().mi_cvt_color_420_u8_batch_dev(self._h, _dptr(src), c3 if enc else pl, (c3 * height) if enc else pl * height * 3 // 2,
+        self._chk(self._L.mi_cvt_color_420_u8_batch_dev(self._h, _dptr(src), c3 if enc else pl, (c3 * height) if enc else pl * height * 3 // 2,
                                                       _dptr(dst), pl if enc else c3, (pl * height * 3 // 2) if enc else c3 * height,
                                                       width, height, n_frames, int(code), stream), "mi_cvt_color_420_u8_batch_dev")
 
@@ -465,35 +479,35 @@ class Context:
             raise MiError(1, "nv12_bgr_equalize", "NV12 frame must hold width*height*3/2 bytes")
         if out is None:
             out = np.empty_like(nv12)
-        self._chk(lib().mi_nv12_bgr_equalize(self._h, nv12.ctypes.data, out.ctypes.data, int(width), int(height)), "mi_nv12_bgr_equalize")
+        self._chk(self._L.mi_nv12_bgr_equalize(self._h, nv12.ctypes.data, out.ctypes.data, int(width), int(height)), "mi_nv12_bgr_equalize")
         return out
 
     def nv12_bgr_equalize_batch_dev(self, src, dst, width, height, n_frames, stream=0, frame_stride=None):
         fs = width * height * 3 // 2 if frame_stride is None else int(frame_stride)
-        self._chk(lib().mi_nv12_bgr_equalize_batch_dev(self._h, _dptr(src), fs, _dptr(dst), fs, width, height, n_frames, stream),
+        self._chk(self._L.mi_nv12_bgr_equalize_batch_dev(self._h, _dptr(src), fs, _dptr(dst), fs, width, height, n_frames, stream),
                   "mi_nv12_bgr_equalize_batch_dev")
 
     def synchronize(self, stream=0):
         """Wait for `stream`; raises only if the fused path met a frame it refused to repair (see get_stat)."""
-        self._chk(lib().mi_ctx_synchronize(self._h, stream), "mi_ctx_synchronize")
+        self._chk(self._L.mi_ctx_synchronize(self._h, stream), "mi_ctx_synchronize")
 
     def get_stat(self, name: str) -> int:
         """Sticky counters of the fused path's fail-soft machinery (mi_ctx_get_stat); synchronise the work's stream first."""
         v = C.c_uint64(0)
-        self._chk(lib().mi_ctx_get_stat(self._h, name.encode(), C.byref(v)), "mi_ctx_get_stat")
+        self._chk(self._L.mi_ctx_get_stat(self._h, name.encode(), C.byref(v)), "mi_ctx_get_stat")
         return int(v.value)
 
     def set_option(self, name: str, value: int):
-        self._chk(lib().mi_ctx_set_option(self._h, name.encode(), int(value)), "mi_ctx_set_option")
+        self._chk(self._L.mi_ctx_set_option(self._h, name.encode(), int(value)), "mi_ctx_set_option")
 
     # ---- profiling ----
     def set_profiling(self, on):
         """False / 0: off.  True / 1: HIP events around every kernel.  2: every kernel but the housekeeping launch behind a fused kernel."""
-        self._chk(lib().mi_ctx_set_profiling(self._h, int(on)), "mi_ctx_set_profiling")
+        self._chk(self._L.mi_ctx_set_profiling(self._h, int(on)), "mi_ctx_set_profiling")
 
     def profile_read(self, reset: bool = True) -> dict:
         p = _Profile()
-        self._chk(lib().mi_ctx_profile_read(self._h, C.byref(p), 1 if reset else 0), "mi_ctx_profile_read")
+        self._chk(self._L.mi_ctx_profile_read(self._h, C.byref(p), 1 if reset else 0), "mi_ctx_profile_read")
         return {KERNEL_NAMES[k]: {"total_ms": p.total_ms[k], "launches": int(p.launches[k]), "min_ms": p.min_ms[k], "p10_ms": p.p10_ms[k],
                                   "p50_ms": p.p50_ms[k], "p90_ms": p.p90_ms[k], "max_ms": p.max_ms[k]} for k in range(_K)}
 
@@ -508,13 +522,13 @@ class Pipe:
         self._h = C.c_void_p()
         self._held = {}
         cfg = _PipeConfig(int(width), int(height), int(op), int(uv_mode), float(clip_limit), int(tiles_x), int(tiles_y), int(depth), int(uv_policy))
-        ctx._chk(lib().mi_pipe_create(ctx._h, C.byref(cfg), C.byref(self._h)), "mi_pipe_create")
+        ctx._chk(self._ctx._L.mi_pipe_create(ctx._h, C.byref(cfg), C.byref(self._h)), "mi_pipe_create")
         self.frame_bytes = width * height * 3 // 2
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             h, self._h = self._h, None
-            lib().mi_pipe_destroy(h)
+            self._ctx._L.mi_pipe_destroy(h)
             self._held.clear()
 
     def __enter__(self):
@@ -525,18 +539,18 @@ class Pipe:
 
     @property
     def pending(self) -> int:
-        return int(lib().mi_pipe_pending(self._h))
+        return int(self._ctx._L.mi_pipe_pending(self._h))
 
     @property
     def depth(self) -> int:
-        return int(lib().mi_pipe_depth(self._h))
+        return int(self._ctx._L.mi_pipe_depth(self._h))
 
     def submit(self, frame_in: np.ndarray, frame_out: np.ndarray, tag: int) -> bool:
         """False when the pipe is full (MI_ERR_BUSY: call wait() first)."""
         for a in (frame_in, frame_out):
             if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or not a.flags.c_contiguous or a.size < self.frame_bytes:
                 raise MiError(1, "mi_pipe_submit", "frames must be contiguous uint8 arrays of W*H*3/2 bytes")
-        rc = lib().mi_pipe_submit(self._h, frame_in.ctypes.data, frame_out.ctypes.data, int(tag))
+        rc = self._ctx._L.mi_pipe_submit(self._h, frame_in.ctypes.data, frame_out.ctypes.data, int(tag))
         if rc == ERR_BUSY:
             return False
         self._ctx._chk(rc, "mi_pipe_submit")
@@ -546,7 +560,7 @@ class Pipe:
     def wait(self):
         """Blocks for the oldest pending frame; returns (tag, output array)."""
         tag, ptr = C.c_uint64(0), C.c_void_p()
-        rc = lib().mi_pipe_wait(self._h, C.byref(tag), C.byref(ptr))
+        rc = self._ctx._L.mi_pipe_wait(self._h, C.byref(tag), C.byref(ptr))
         held = self._held.pop(int(tag.value), (None, None))
         self._ctx._chk(rc, "mi_pipe_wait")
         return int(tag.value), held[1]

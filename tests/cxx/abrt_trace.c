@@ -12,11 +12,55 @@
 #include <signal.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 static struct sigaction g_prev[65];
 static int g_fd = -1;
+
+/* The locked-memory state of the process at the moment of death: the one abort site on record was a runtime path that pins the
+ * caller's pages (hsa_amd_memory_lock_to_pool); a lock that failed against RLIMIT_MEMLOCK or the locked-page accounting would show
+ * here.  Async-signal-safe: open / read / write only, fixed buffers. */
+static void put_num(int fd, const char* label, unsigned long long v, int unlimited)
+{
+    char b[96]; int n = 0;
+    while (label[n] && n < 60) { b[n] = label[n]; ++n; }
+    if (unlimited) { memcpy(b + n, "unlimited", 9); n += 9; }
+    else {
+        char d[24]; int k = 0;
+        do { d[k++] = (char)('0' + v % 10); v /= 10; } while (v && k < 24);
+        while (k) b[n++] = d[--k];
+    }
+    b[n++] = '\n';
+    (void)!write(fd, b, (size_t)n);
+}
+
+static void dump_memlock(int fd)
+{
+    static const char hdr[] = "[abrt_trace] locked / pinned memory of the process (RLIMIT_MEMLOCK soft, hard in bytes; /proc/self/status):\n";
+    (void)!write(fd, hdr, sizeof hdr - 1);
+    struct rlimit rl;
+    if (getrlimit(RLIMIT_MEMLOCK, &rl) == 0) {
+        put_num(fd, "  RLIMIT_MEMLOCK soft: ", (unsigned long long)rl.rlim_cur, rl.rlim_cur == RLIM_INFINITY);
+        put_num(fd, "  RLIMIT_MEMLOCK hard: ", (unsigned long long)rl.rlim_max, rl.rlim_max == RLIM_INFINITY);
+    }
+    const int sfd = open("/proc/self/status", O_RDONLY | O_CLOEXEC);
+    if (sfd < 0) return;
+    static char buf[8192];
+    ssize_t got = read(sfd, buf, sizeof buf - 1);
+    close(sfd);
+    if (got <= 0) return;
+    buf[got] = 0;
+    static const char* keys[] = {"VmLck:", "VmPin:", "VmRSS:", "VmHWM:", "Threads:"};
+    for (unsigned k = 0; k < sizeof keys / sizeof keys[0]; ++k) {
+        const char* p = strstr(buf, keys[k]);
+        if (!p) continue;
+        const char* e = strchr(p, '\n');
+        (void)!write(fd, "  ", 2);
+        (void)!write(fd, p, e ? (size_t)(e - p + 1) : strlen(p));
+    }
+}
 
 static void on_fatal(int sig)
 {
@@ -25,9 +69,11 @@ static void on_fatal(int sig)
     const int n = backtrace(frames, 96);
     (void)!write(2, msg, sizeof msg - 1);
     backtrace_symbols_fd(frames, n, 2);
+    dump_memlock(2);
     if (g_fd >= 0) {
         (void)!write(g_fd, msg, sizeof msg - 1);
         backtrace_symbols_fd(frames, n, g_fd);
+        dump_memlock(g_fd);
         (void)fsync(g_fd);
     }
     if (sig > 0 && sig < 65) sigaction(sig, &g_prev[sig], 0);      /* the previous owner (faulthandler, or SIG_DFL) */

@@ -24,3 +24,5 @@ def test_abrt_tracer_leaves_the_native_chain_in_a_file(tmp_path):
     text = log.read_text()
     assert "[abrt_trace] fatal signal" in text and "abort" in text, text
     assert "[abrt_trace] fatal signal" in r.stderr                # and on stderr, when there is one
+    # the locked-memory state at the moment of death (the one abort site on record pins caller pages: DESIGN.md "the abort")
+    assert "RLIMIT_MEMLOCK soft:" in text and "VmLck:" in text and "VmPin:" in text, text

@@ -18,6 +18,12 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
+def hooks_ctx():
+    """A context of libmi_lumaeq_test.so: the product sources built with -DMI_TEST_HOOKS (fault injection into the fused kernel's
+    hand-off, microsecond wait bounds, forced failures of checked HIP calls).  The product library knows none of these options."""
+    return mi_lumaeq.Context(0, lib=mi_lumaeq.test_lib())
+
+
 @pytest.mark.parametrize("shape", SMALL, ids=str)
 @pytest.mark.parametrize("dist", synth.DISTS)
 def test_equalize_host_form(ctx, shape, dist):
@@ -696,7 +702,7 @@ def test_fused_bounded_wait_expiry_is_repaired_on_device(mode, in_place):
     w, h, n = 1920, 1080, 3
     frames = np.stack([synth.nv12_frame(w, h, "D2", 700 + k) for k in range(n)])
     want = [oracle.nv12_frame(frames[k], w, h, uv_mode=0, op=0) for k in range(n)]
-    c = mi_lumaeq.Context(0)
+    c = hooks_ctx()
     try:
         d_in = dev(frames)
         d_out = d_in if in_place else torch.zeros_like(d_in)
@@ -746,8 +752,9 @@ def test_fused_repair_under_naturally_expiring_waits(in_place):
     w, h, n = 1920, 1080, 6
     frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 1500 + k) for k in range(n)])
     want = [[oracle.nv12_frame(frames[k], w, h, uv_mode=uv, op=0) for k in range(n)] for uv in (0, 1)]
-    c = mi_lumaeq.Context(0)
+    c = hooks_ctx()
     try:
+        c.set_option("fused_demote_after", 0)                       # this test wants every launch on the fused path, however often it is repaired
         total_fallbacks = 0
         for us in (1, 2, 4, 8, 16, 40):
             c.set_option("fused_timeout_us", us)
@@ -778,7 +785,7 @@ def test_fused_failure_statistics_survive_later_launches_and_block_growth():
     """A failure in launch N must still be visible after launch N+1 ... N+k (the statistics words are never cleared by the
     per-launch housekeeping) and after the hand-off block was re-allocated for a larger batch."""
     w, h = 640, 368
-    c = mi_lumaeq.Context(0)
+    c = hooks_ctx()
     try:
         f4 = np.stack([synth.nv12_frame(w, h, "D1", 40 + k) for k in range(4)])
         d_in, d_out = dev(f4), torch.zeros(f4.shape, dtype=torch.uint8, device="cuda:0")
@@ -809,10 +816,11 @@ def test_fused_failure_inside_a_replayed_graph():
     """A captured fused launch carries its finish kernel with it: a hand-off failure inside a REPLAY is repaired like an eager one,
     replay after replay (all per-launch state lives in the hand-off block, nothing on the host)."""
     w, h, n = 1280, 720, 3
-    c = mi_lumaeq.Context(0)
+    c = hooks_ctx()
     try:
         d_in = synth.nv12_batch_torch(w, h, n, "D2", "cuda:0", seed=5)
         d_out = torch.zeros_like(d_in)
+        c.set_option("fused_demote_after", 0)                             # keep the eager calls below on the fused path
         c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)           # sizes the scratch (allocations are not capturable)
         c.synchronize()
         c.set_option("fused_fault_inject", 1)
@@ -1138,32 +1146,46 @@ def test_photo_like_scene(ctx):
     assert np.array_equal(d_out[0].cpu().numpy(), oracle.nv12_bgr_equalize(frames[0], w, h))
 
 
-def test_host_forms_staged_and_direct_agree(ctx):
-    """Option "host_direct": unpinned contiguous host planes go through the context's pinned staging buffers (default, 0) or are handed
-    to the runtime's own pageable-copy path (1) -- same bytes either way, for every host-pointer form; memory the caller pinned
-    (here: a pinned torch tensor, which the library recognises through hipPointerGetAttributes) takes the direct path in both."""
-    w, h = 640, 360
+def test_host_forms_unpinned_and_pinned_memory_agree(ctx):
+    """Unpinned host planes are packed through the context's pinned staging buffers (by the calling thread alone or together with the
+    context's helper thread, option "host_copy_threads"); memory the caller pinned (here: pinned torch tensors, which the library
+    recognises through hipPointerGetAttributes) is DMA'd as it is.  Same bytes every way, for every host-pointer form; the
+    library has no mode any more in which pageable memory reaches hipMemcpyAsync."""
+    w, h = 1920, 1080                                               # large enough for the helper thread to take part (>= 1 MiB planes)
     y = synth.y_plane(w, h, "D2", 3)
     nv = _nv12_frames(w, h, 1, 4)[0]
     bgr = _bgr(w, h, 5)
     s16 = (np.random.default_rng(6).integers(0, 4096, (h, w))).astype(np.uint16)
+    with pytest.raises(mi_lumaeq.MiError):
+        ctx.set_option("host_direct", 1)                            # the option of rounds 1-2 is gone
     try:
         outs = []
-        for direct in (1, 0):
-            ctx.set_option("host_direct", direct)
+        shared0 = ctx.get_stat("host_copies_shared")
+        for threads in (2, 1):
+            ctx.set_option("host_copy_threads", threads)
             outs.append((ctx.equalize_hist(y), ctx.clahe(y, 2.0, 8, 8), ctx.equalize_hist_nv12(nv, w, h, mi_lumaeq.UV_COPY),
                          ctx.clahe_nv12(nv, w, h, mi_lumaeq.UV_FILL128, 3.0, 4, 4), ctx.bgr_luma_op(bgr, mi_lumaeq.OP_EQUALIZE),
                          ctx.cvt_color(bgr, mi_lumaeq.COLOR_BGR2YUV), ctx.cvt_color_420(bgr, mi_lumaeq.COLOR_BGR2YUV_I420),
                          ctx.nv12_bgr_equalize(nv, w, h), ctx.clahe16(s16, 2.0, 8, 8)))
+            if threads == 2:
+                shared1 = ctx.get_stat("host_copies_shared")
+        assert ctx.get_stat("host_copies_shared") == shared1        # one thread: the helper took part in nothing
+        assert shared1 >= shared0                                   # (it may lose every race for its half on a loaded host: >=, not >)
         for a, b in zip(*outs):
             assert np.array_equal(a, b)
         assert np.array_equal(outs[0][0], oracle.equalize_hist(y)) and np.array_equal(outs[1][1], oracle.clahe(y, 2.0, 8, 8))
-        ctx.set_option("host_direct", 0)
+        # strided views through the helper as well
+        big = np.zeros((h + 4, w + 64), np.uint8)
+        big[2:2 + h, 32:32 + w] = y
+        dstbig = np.zeros_like(big)
+        ctx.set_option("host_copy_threads", 2)
+        ctx.equalize_hist(big[2:2 + h, 32:32 + w], dstbig[2:2 + h, 32:32 + w])
+        assert np.array_equal(dstbig[2:2 + h, 32:32 + w], outs[0][0]) and not dstbig[:2].any() and not dstbig[:, :32].any()
         pin_in, pin_out = torch.from_numpy(y.copy()).pin_memory(), torch.empty((h, w), dtype=torch.uint8).pin_memory()
         got = ctx.equalize_hist(pin_in.numpy(), pin_out.numpy())
         assert np.array_equal(got, outs[0][0]) and got.ctypes.data == pin_out.numpy().ctypes.data
     finally:
-        ctx.set_option("host_direct", 0)
+        ctx.set_option("host_copy_threads", 2)
 
 
 def test_clahe_fp_contract_mode(ctx):
@@ -1294,7 +1316,7 @@ def test_pipe_odd_geometries(shape):
 
 
 def test_pipe_argument_errors_and_fail_soft():
-    c = mi_lumaeq.Context(0)
+    c = hooks_ctx()
     try:
         for bad in (dict(width=0), dict(width=641), dict(op=5), dict(uv_mode=3), dict(uv_policy=9), dict(op=mi_lumaeq.OP_CLAHE, tiles_x=0)):
             kw = dict(width=640, height=360, op=mi_lumaeq.OP_EQUALIZE, uv_mode=0, uv_policy=0, tiles_x=8, tiles_y=8)

@@ -1,0 +1,292 @@
+"""GPU tests of the library's behaviour under failure and contention (run with -m gpu): error exits that drain their streams,
+pipes that stay in step with their callers, MI_ERR_BUSY rules, demotion of the fused path after repeated repairs, lifetime of the
+fused kernel's ticket stamps.  The injected failures come from libmi_lumaeq_test.so (the product sources + -DMI_TEST_HOOKS);
+every byte is still compared with the CPU oracle.  Reference for what "error handling" replaces: the accelerator worker that
+catches a type nobody throws and pushes the frame on regardless, /root/reference OpenCLequalHist.cpp:346-367."""
+import time
+
+import numpy as np
+import pytest
+
+import mi_lumaeq
+import oracle
+from mi_lumaeq import synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def hooks_ctx():
+    return mi_lumaeq.Context(0, lib=mi_lumaeq.test_lib())
+
+
+def test_product_library_knows_no_test_hook():
+    assert "+test-hooks" in mi_lumaeq.test_lib().mi_version().decode() and "+test-hooks" not in mi_lumaeq.version()
+    with mi_lumaeq.Context(0) as c:
+        for name in ("fused_fault_inject", "fused_timeout_us", "hip_fail_after", "host_direct"):
+            with pytest.raises(mi_lumaeq.MiError) as e:
+                c.set_option(name, 1)
+            assert e.value.status == 1
+
+
+def test_fused_path_is_demoted_after_repeated_repairs_and_probed_again():
+    """A context whose fused launches keep losing their hand-off (here: an injected lost producer, 300 us bound) must stop
+    paying the stall: three repaired launches, then the three-kernel path -- the oracle's bytes on every call -- then ONE probe after
+    the demotion period, a second demotion for twice as long when the probe is repaired too, and the fused path back for good once
+    a probe window stays clean."""
+    w, h = 1920, 1080
+    ys = [synth.y_plane(w, h, synth.DISTS[k % 5], 900 + k) for k in range(4)]
+    want = [oracle.equalize_hist(y) for y in ys]
+    c = hooks_ctx()
+    try:
+        c.set_option("fused_reprobe_ms", 400)
+        c.set_option("fused_timeout_us", 300)
+        c.set_option("fused_fault_inject", 1)
+        stall, quick = [], []
+        for k in range(12):
+            t0 = time.perf_counter()
+            got = c.equalize_hist(ys[k % 4])
+            (stall if k < 3 else quick).append(time.perf_counter() - t0)
+            assert np.array_equal(got, want[k % 4]), k
+        assert c.get_stat("fused_fallbacks") == 3, "launches 4..12 must not have been fused"
+        assert c.get_stat("fused_demotions") == 1 and c.get_stat("fused_demoted") == 1
+        assert c.get_stat("fused_hard_errors") == 0
+        # the device forms obey the same verdict without any synchronisation of their own
+        d_in = dev(np.stack([synth.nv12_frame(w, h, "D2", 5 + k) for k in range(3)]))
+        d_out = torch.zeros_like(d_in)
+        c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, 3, 0)
+        c.synchronize()
+        assert c.get_stat("fused_fallbacks") == 3
+        assert np.array_equal(d_out[2].cpu().numpy(), oracle.nv12_frame(d_in[2].cpu().numpy(), w, h, uv_mode=0, op=0))
+        # after the period: one probe (repaired: the fault is still injected) -> demoted again, for twice as long
+        time.sleep(0.45)
+        assert np.array_equal(c.equalize_hist(ys[0]), want[0])
+        assert c.get_stat("fused_fallbacks") == 4
+        assert np.array_equal(c.equalize_hist(ys[1]), want[1])
+        assert c.get_stat("fused_demotions") == 2 and c.get_stat("fused_demoted") == 1 and c.get_stat("fused_fallbacks") == 4
+        time.sleep(0.45)                                            # 400 ms have passed, 800 have not
+        assert np.array_equal(c.equalize_hist(ys[2]), want[2])
+        assert c.get_stat("fused_demoted") == 1 and c.get_stat("fused_fallbacks") == 4
+        # the GPU is free again: the next probe stays clean and the fused path is back
+        c.set_option("fused_fault_inject", 0)
+        c.set_option("fused_timeout_ms", 50)
+        time.sleep(0.45)
+        for k in range(40):
+            assert np.array_equal(c.equalize_hist(ys[k % 4]), want[k % 4]), k
+        assert c.get_stat("fused_demoted") == 0 and c.get_stat("fused_demotions") == 2 and c.get_stat("fused_fallbacks") == 4
+        prof_before = c.profile_read(reset=True)
+        c.set_profiling(1)
+        c.equalize_hist(ys[0])
+        c.set_profiling(0)
+        assert c.profile_read()["equalize_fused_kernel"]["launches"] == 1      # really the fused kernel again
+        # "fused_demote_after" = 0 switches the mechanism off
+        c.set_option("fused_demote_after", 0)
+        c.set_option("fused_timeout_us", 300)
+        c.set_option("fused_fault_inject", 1)
+        for k in range(5):
+            assert np.array_equal(c.equalize_hist(ys[k % 4]), want[k % 4])
+        assert c.get_stat("fused_fallbacks") == 9 and c.get_stat("fused_demotions") == 2
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned"])
+def test_host_form_error_exits_drain_the_stream_and_leave_the_context_usable(pinned):
+    """Every checked HIP call of a host-pointer form is made to REPORT a failure once, after it was issued (option "hip_fail_after"
+    of the test library): the call must return MI_ERR_HIP, must not return before the copies it queued on the caller's planes have
+    finished (statistic "error_drains"), and the next call on the same context must produce the oracle's bytes."""
+    w, h = 1280, 720
+    y = synth.y_plane(w, h, "D2", 31)
+    want_eq, want_cl = oracle.equalize_hist(y), oracle.clahe(y, 2.0, 8, 8)
+    c = hooks_ctx()
+    try:
+        if pinned:
+            src_t, dst_t = torch.from_numpy(y.copy()).pin_memory(), torch.empty((h, w), dtype=torch.uint8).pin_memory()
+            src, dst = src_t.numpy(), dst_t.numpy()
+        else:
+            src, dst = y.copy(), np.empty_like(y)
+        assert np.array_equal(c.equalize_hist(src, dst), want_eq)   # sizes every buffer: the sweep below meets steady-state calls
+        failures = 0
+        for op in ("equalize", "clahe"):
+            for n in range(1, 60):
+                c.set_option("hip_fail_after", n)
+                drains0 = c.get_stat("error_drains")
+                try:
+                    got = c.equalize_hist(src, dst) if op == "equalize" else c.clahe(src, 2.0, 8, 8, dst)
+                except mi_lumaeq.MiError as e:
+                    assert e.status == 3, e
+                    failures += 1
+                    assert c.get_stat("error_drains") >= drains0   # (>=: a failure before anything was queued has nothing to drain)
+                    c.set_option("hip_fail_after", 0)
+                    dst[:] = 0
+                    got = c.equalize_hist(src, dst) if op == "equalize" else c.clahe(src, 2.0, 8, 8, dst)
+                    assert np.array_equal(got, want_eq if op == "equalize" else want_cl), (op, n)
+                    continue
+                c.set_option("hip_fail_after", 0)
+                assert np.array_equal(got, want_eq if op == "equalize" else want_cl), (op, n)
+                break                                               # n exceeds the number of checked calls: the sweep is complete
+            else:
+                pytest.fail("a host form makes more than 60 checked HIP calls?")
+        assert failures >= 8                                        # copies, launches, events, synchronisations were all hit
+        assert c.get_stat("error_drains") >= failures // 2
+        # the less travelled host forms share stage_in / stage_out
+        nv = synth.nv12_frame(w, h, "D1", 8)
+        want_nv = oracle.nv12_bgr_equalize(nv, w, h)
+        for n in range(1, 12):
+            c.set_option("hip_fail_after", n)
+            try:
+                c.nv12_bgr_equalize(nv, w, h)
+            except mi_lumaeq.MiError as e:
+                assert e.status == 3
+            c.set_option("hip_fail_after", 0)
+            assert np.array_equal(c.nv12_bgr_equalize(nv, w, h), want_nv), n
+    finally:
+        c.close()
+
+
+def test_pipe_errors_keep_the_caller_and_the_pipe_in_step():
+    """mi_pipe_submit that fails occupies no slot and leaves nothing in flight; mi_pipe_wait that fails has still retired the oldest
+    frame.  Either way the frames around the failed one come back under their own tags with the oracle's bytes."""
+    w, h = 1280, 720
+    frames = [synth.nv12_frame(w, h, synth.DISTS[k % 5], 60 + k) for k in range(6)]
+    want = [oracle.nv12_frame(f, w, h, uv_mode=0, op=0) for f in frames]
+    c = hooks_ctx()
+    try:
+        with mi_lumaeq.Pipe(c, w, h, depth=3) as pipe:
+            outs = [np.zeros_like(f) for f in frames]
+            assert pipe.submit(frames[0], outs[0], 100)
+            for n in range(1, 30):                                  # every checked call of a submit fails once
+                c.set_option("hip_fail_after", n)
+                try:
+                    ok = pipe.submit(frames[1], outs[1], 101)
+                except mi_lumaeq.MiError as e:
+                    assert e.status == 3
+                    assert pipe.pending == 1                        # the failed frame took no slot
+                    continue
+                finally:
+                    c.set_option("hip_fail_after", 0)
+                assert ok and pipe.pending == 2
+                break
+            else:
+                pytest.fail("mi_pipe_submit makes more than 29 checked HIP calls?")
+            assert c.get_stat("error_drains") >= 1
+            assert pipe.submit(frames[2], outs[2], 102)
+            tag, out = pipe.wait()
+            assert tag == 100 and np.array_equal(out, want[0])
+            # a failing wait: its frame is reported lost, the slot is retired, the NEXT wait returns the next tag
+            c.set_option("hip_fail_after", 1)
+            with pytest.raises(mi_lumaeq.MiError) as e:
+                pipe.wait()
+            assert e.value.status == 3 and pipe.pending == 1
+            c.set_option("hip_fail_after", 0)
+            tag, out = pipe.wait()
+            assert tag == 102 and np.array_equal(out, want[2])
+            assert pipe.pending == 0
+            # the pipe works on as if nothing had happened
+            for k in range(3, 6):
+                assert pipe.submit(frames[k], outs[k], 200 + k)
+            for k in range(3, 6):
+                tag, out = pipe.wait()
+                assert tag == 200 + k and np.array_equal(out, want[k]), k
+    finally:
+        c.close()
+
+
+def test_pipe_and_context_busy_rules():
+    """One pipe per context; while frames are pending the context's other compute entry points answer MI_ERR_BUSY (they would race the
+    pipe's streams for the context's scratch); with nothing pending they work, and a device-form call on a caller's stream is
+    ordered in front of the next frame's kernels."""
+    w, h = 1920, 1080
+    f = synth.nv12_frame(w, h, "D2", 3)
+    y = f[: w * h].reshape(h, w)
+    want = oracle.nv12_frame(f, w, h, uv_mode=0, op=0)
+    with mi_lumaeq.Context(0) as c:
+        with mi_lumaeq.Pipe(c, w, h, depth=2) as pipe:
+            with pytest.raises(mi_lumaeq.MiError) as e:
+                mi_lumaeq.Pipe(c, w, h, depth=2)
+            assert e.value.status == mi_lumaeq.ERR_BUSY
+            o = np.zeros_like(f)
+            assert pipe.submit(f, o, 1)
+            d = dev(f[None])
+            for call in (lambda: c.equalize_hist(y), lambda: c.clahe(y, 2.0, 8, 8), lambda: c.equalize_hist_nv12_batch_dev(d, d, w, h, 1, 0),
+                         lambda: c.analyze_diff(y, y), lambda: c.nv12_bgr_equalize(f, w, h)):
+                with pytest.raises(mi_lumaeq.MiError) as e:
+                    call()
+                assert e.value.status == mi_lumaeq.ERR_BUSY
+            assert c.get_stat("fused_fallbacks") == 0               # statistics and options stay available
+            assert pipe.wait()[0] == 1 and np.array_equal(o, want)
+            # nothing pending: a long device-form batch on torch's stream, then a frame through the pipe straight away.  Both use the
+            # context's hand-off block; the pipe's compute stream must wait for the batch (event recorded when the call returned).
+            n = 48
+            batch = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 400 + k) for k in range(4)])
+            d_in = dev(batch).repeat(n // 4, 1)
+            d_out = torch.zeros_like(d_in)
+            for rep in range(3):
+                c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 1, stream=torch.cuda.current_stream().cuda_stream)
+                o2 = np.zeros_like(f)
+                assert pipe.submit(f, o2, 7 + rep)
+                assert pipe.wait()[0] == 7 + rep and np.array_equal(o2, want)
+                torch.cuda.synchronize()
+                got = d_out.cpu().numpy()
+                for k in (0, 1, 2, 3, n - 1):
+                    assert np.array_equal(got[k], oracle.nv12_frame(batch[k % 4], w, h, uv_mode=1, op=0)), (rep, k)
+            assert c.get_stat("fused_fallbacks") == 0
+        # the pipe is gone: a new one may be created
+        with mi_lumaeq.Pipe(c, w, h, depth=2) as pipe:
+            o = np.zeros_like(f)
+            assert pipe.submit(f, o, 9) and pipe.wait()[0] == 9 and np.array_equal(o, want)
+
+
+def test_ticket_stamps_share_the_lifetime_of_their_hand_off_block():
+    """A captured graph keeps replaying into the hand-off block it was recorded with -- its own sequence numbers, its own ticket stamps
+    -- after a larger batch made the context allocate a new block whose epochs start over.  Replays and eager launches are
+    interleaved, both with injected hand-off failures, so both blocks run their stamp-driven repair again and again: with shared
+    stamps an eager launch's epoch could meet a replay's stamps (or the reverse) and a ticket that was never written would count
+    as done.  Every output byte is compared."""
+    w, h, n = 1280, 720, 3
+    c = hooks_ctx()
+    try:
+        c.set_option("fused_demote_after", 0)
+        c.set_option("fused_timeout_us", 400)
+        d_in = synth.nv12_batch_torch(w, h, n, "D2", "cuda:0", seed=5)
+        d_out = torch.zeros_like(d_in)
+        c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
+        c.synchronize()
+        c.set_option("fused_fault_inject", 2)                       # frames left partly written: the repair goes by the stamps
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0, stream=torch.cuda.current_stream().cuda_stream)
+        # regrow: 80 frames > the first block's 64-frame layout -> a new block (the old one is kept for the graph)
+        n2 = 80
+        e_src = [synth.nv12_frame(w, h, synth.DISTS[k % 5], 40 + k) for k in range(4)]
+        e_in = dev(np.stack(e_src)).repeat(n2 // 4, 1)
+        e_out = torch.zeros_like(e_in)
+        e_want = [oracle.nv12_frame(f, w, h, uv_mode=1, op=0) for f in e_src]
+        for rep in range(6):
+            # eager launch into the NEW block (its epochs restarted at 1), alternately with 3 frames (same ticket range as the graph) and 80
+            m = n if rep % 2 == 0 else n2
+            e_out.zero_()
+            c.equalize_hist_nv12_batch_dev(e_in, e_out, w, h, m, 1)
+            # replay into the OLD block
+            d_in.copy_(synth.nv12_batch_torch(w, h, n, synth.DISTS[rep % 5], "cuda:0", seed=300 + rep))
+            d_out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            c.synchronize()
+            got = e_out.cpu().numpy()
+            for k in range(m if m == n else 8):
+                assert np.array_equal(got[k], e_want[k % 4]), ("eager", rep, k)
+            assert np.array_equal(got[m - 1], e_want[(m - 1) % 4]), ("eager", rep, m - 1)
+            src, out = d_in.cpu().numpy(), d_out.cpu().numpy()
+            for k in range(n):
+                assert np.array_equal(out[k], oracle.nv12_frame(src[k], w, h, uv_mode=0, op=0)), ("replay", rep, k)
+        assert c.get_stat("fused_fallbacks") >= 6 and c.get_stat("fused_hard_errors") == 0
+        del g
+        torch.cuda.synchronize()
+    finally:
+        c.close()

@@ -7,7 +7,11 @@ import torch, mi_lumaeq
 from mi_lumaeq import synth
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 random.seed(7)
-fused_a, fused_b, ref = mi_lumaeq.Context(0), mi_lumaeq.Context(0), mi_lumaeq.Context(0)
+# the repair phase needs microsecond wait bounds: a test hook, so the soak runs on libmi_lumaeq_test.so (same sources + -DMI_TEST_HOOKS)
+TL = mi_lumaeq.test_lib()
+fused_a, fused_b, ref = mi_lumaeq.Context(0, lib=TL), mi_lumaeq.Context(0, lib=TL), mi_lumaeq.Context(0, lib=TL)
+for c_ in (fused_a, fused_b):
+    c_.set_option("fused_demote_after", 0)                # the soak wants every launch on the fused path, however often it is repaired
 ref.set_option("fused", 0)
 shapes = [(3840, 2160), (1920, 1080), (1280, 720), (640, 360), (256, 64), (3840, 1088), (2560, 1440)]
 t0 = time.time(); launches = frames = mismatches = errors = 0
@@ -66,7 +70,7 @@ while time.time() - t1 < min(10.0, budget / 4):
 # repair phase (round 2): the bound of the waits is set to a few MICROseconds, so ordinary hand-offs expire at random points of random
 # launches (consumers give up while the LUT is being published, frames are left partly written, tickets are never drawn); whatever a
 # launch ends in, the finish kernel must produce the three-kernel path's bytes, in place included.
-ref = mi_lumaeq.Context(0); ref.set_option("fused", 0)
+ref = mi_lumaeq.Context(0, lib=TL); ref.set_option("fused", 0)
 repair_launches = 0
 fb0 = fused_a.get_stat("fused_fallbacks")
 t2 = time.time()
