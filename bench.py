@@ -2,21 +2,27 @@
 """bench.py -- frames/s of the NV12 luma equalizeHist hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
+        N = 1: runs in this process.  N > 1 with WORLD_SIZE unset: this process starts N fresh children -- one per GPU, with
+        RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set -- BEFORE it makes any GPU call itself, relays
+        rank 0's JSON line and exits with the worst child's code (it never re-executes a process that has touched the GPU).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+        the same ranks started by torchrun (WORLD_SIZE set: no self-launch).
 
 One "step" = one pass of the hot path (mi_equalize_hist_nv12_batch_dev: histogram -> CDF/LUT ->
 LUT apply + UV fill) over one batch of `--batch` synthetic 3840x2160 NV12 frames that are already
 resident in HBM (BASELINE.json configs[1], batched so the working set exceeds the 256 MiB
-Infinity Cache).  Frames are sharded one batch per GPU, no data-path collective (weak scaling);
-value = frames all ranks processed / max-over-ranks time.
+Infinity Cache).  Every GPU processes its own replica batch (frame k -> GPU k mod N), no data-path
+collective (weak scaling); value = frames all ranks processed / max-over-ranks time.  Each rank first
+binds itself to the CPUs of its GPU's NUMA node (mi_thread_bind_near_device; --no-numa-bind to skip).
 
 The JSON line also carries
-  roofline     -- the LUT-apply kernel's algorithmic bytes per launch / its average launch duration
-                  (HIP events recorded by the library on the launch stream inside the timed region)
-                  against the 8 TB/s HBM peak;
+  roofline     -- the dominant kernel's algorithmic bytes per launch (for the fused single-read kernel: the whole
+                  path's 3.5 W H per frame) / its average launch duration (HIP events stamped by the dispatches
+                  themselves on the launch stream inside the timed region; for N > 1 averaged over the ranks,
+                  with the slowest and fastest rank beside it) against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle (a port of OpenCV 4.4's arithmetic, see oracle/) timed on this
-                  host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+                  host's cores on a bounded sample of the same workload (rank 0, after the other ranks have left).
 The oracle is used here only for that leg and for a one-frame parity spot check.
 """
 from __future__ import annotations
@@ -36,7 +42,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0  # same guide: float4 copy ceiling
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -56,7 +62,82 @@ def parse_args():
                     help="nccl (=RCCL) for real multi-GPU runs; gloo only to rehearse the N>1 path on a 1-GPU box")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="rehearsal only: every rank uses this GPU index instead of LOCAL_RANK")
-    return ap.parse_args()
+    ap.add_argument("--no-numa-bind", action="store_true", help="do not bind each rank to the CPUs of its GPU's NUMA node")
+    return ap.parse_args(argv)
+
+
+# ---- self-launch for N > 1 -----------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_children(n, argv, child_cmd=None, grace_s=30.0, env_extra=None):
+    """Start n fresh processes of this script, one per GPU (RANK / LOCAL_RANK = 0..n-1, WORLD_SIZE = n, rendezvous on 127.0.0.1),
+    relay rank 0's JSON line(s) to stdout and everything else to stderr, return the worst exit code.  The calling process must
+    not have touched the GPU: nothing here does, and nothing is exec'd in place -- the children are ordinary child processes.
+    When a rank dies, the others get `grace_s` seconds to notice (they may sit in a collective with it) and are then ended, by
+    their own PIDs.  `child_cmd` replaces `python bench.py` (the CPU test passes a stub)."""
+    import subprocess
+    import threading
+    port = _free_port()
+    cmd = list(child_cmd) if child_cmd else [sys.executable, str(Path(__file__).resolve())]
+    procs, pumps, rank0_lines = [], [], []
+
+    def pump(rank, stream):
+        for line in stream:
+            if rank == 0 and line.lstrip().startswith("{"):
+                rank0_lines.append(line)
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(f"[rank {rank}] {line}")
+                sys.stderr.flush()
+
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL on this pool: dmabuf IPC only
+        if env_extra:
+            env.update(env_extra)
+        p = subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+        t = threading.Thread(target=pump, args=(r, p.stdout), daemon=True)
+        t.start()
+        procs.append(p)
+        pumps.append(t)
+    deadline, own_failure = None, 0
+    while any(p.poll() is None for p in procs):
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.monotonic() + grace_s                 # a rank failed: the rest may be waiting for it forever
+            own_failure = next(p.poll() for p in procs if p.poll() not in (None, 0))     # ... and ITS code is the job's, not the
+                                                                  # SIGTERM the launcher hands the others afterwards
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for t in pumps:
+        t.join(timeout=10)
+    codes = [p.wait() for p in procs]
+    worst = own_failure
+    for c in codes:
+        if c != 0 and worst == 0:
+            worst = c
+    if worst == 0 and not rank0_lines:
+        print("bench.py launcher: rank 0 printed no JSON line", file=sys.stderr)
+        worst = 1
+    if worst < 0:
+        worst = 128 - worst                                        # killed by a signal: shell convention
+    return worst
 
 
 def cpu_baseline(args, w, h):
@@ -147,6 +228,9 @@ def opencv_cross_check(ctx, w, h, dist_name):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (no torch import yet).
+        sys.exit(launch_children(args.gpus, sys.argv[1:]))
     import torch
     import torch.distributed as dist
     import mi_lumaeq
@@ -178,8 +262,6 @@ def main():
         backend_used, world_seen = None, 1
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("for --gpus N>1 launch with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     device = torch.device("cuda", local_rank)
@@ -189,12 +271,21 @@ def main():
     ysz = w * h
     fbytes = ysz + ysz // 2
     uv_mode = mi_lumaeq.UV_COPY if args.uv == "copy" else mi_lumaeq.UV_FILL128
+    # placement before the context exists: its pinned buffers and helper thread then live next to this rank's GPU
+    placement = {"node": None, "cpus": 0, "why": "NUMA binding off (--no-numa-bind)"}
+    if not args.no_numa_bind:
+        try:
+            placement = mi_lumaeq.bind_thread_near_device(local_rank)
+        except mi_lumaeq.MiError as e:
+            placement = {"node": None, "cpus": 0, "why": f"not bound: {e}"}
     ctx = mi_lumaeq.Context(local_rank)
 
-    # this rank's shard: global frame indices k with k mod world == rank (no collective on the data path)
+    # this rank's shard: global frame indices k with k mod world == rank (no collective on the data path); the synthetic batch is
+    # seeded by the first of them, so every rank works on different frames of the same distribution
     my_frames = shard.frames_for_rank(B * world, rank, world)
-    assert len(my_frames) == B
-    d_in = synth.nv12_batch_torch(w, h, B, args.dist, device, seed=0x5EED0000 + rank)
+    if len(my_frames) != B:
+        raise SystemExit(f"sharding error: rank {rank} got {len(my_frames)} frames for a batch of {B}")
+    d_in = synth.nv12_batch_torch(w, h, B, args.dist, device, seed=0x5EED0000 + my_frames[0])
     d_out = torch.empty_like(d_in)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -299,21 +390,11 @@ def main():
                       "max_ms_max": red(mine.get("max_ms", -1.0), "max"), "late_total": int(red(mine.get("late", 0), "sum")),
                       "errors_total": int(red(mine.get("errors", 0), "sum")),
                       "unpaced_frames_per_s_total": round(red(mine.get("unpaced_frames_per_s", 0.0), "sum"), 1)}
-    if rank != 0:
-        if world > 1:
-            dist.barrier()                       # leave together with rank 0 (it is still printing the result line)
-            dist.destroy_process_group()
-        return
-
-    total_frames = B * world * args.steps
-    fps = total_frames / elapsed
-    ms_step = elapsed / args.steps * 1e3
-
-    # ---- roofline of the dominant kernel -------------------------------------------------------
+    # ---- kernel timing of THIS rank, then the figures every rank contributes to (before anybody leaves) ----------------
     # Algorithmic bytes per frame (SURVEY.md 8d / DESIGN.md): equalizeHist on Y = 3*W*H (histogram read +
     # apply read + apply write); + UV fill W*H/2 (write) or UV copy 2*(W*H/2).  The fused kernel performs
     # the WHOLE path in one launch, so its algorithmic bytes are the whole-path figure; its HBM traffic is
-    # lower (the Y plane is read once and kept in registers) -- see `traffic` (PMC) and `min_hbm_bytes`.
+    # lower (the Y plane is read once and kept in registers) -- see `traffic` (PMC) and `moved_bytes_per_launch`.
     uv_bytes = (ysz // 2) * (2 if args.uv == "copy" else 1)
     per_kernel_alg = {"hist_partial_kernel": ysz * B, "lut_apply_kernel": (2 * ysz + uv_bytes) * B,
                       "equalize_fused_kernel": (3 * ysz + uv_bytes) * B,
@@ -327,8 +408,27 @@ def main():
             if name in per_kernel_alg:
                 e["alg_GBs"] = round(per_kernel_alg[name] / (avg_ms * 1e-3) / 1e9, 1)
             kinfo[name] = e
-    cands = [k for k in kinfo if k in per_kernel_alg]
+    cands = sorted(k for k in kinfo if k in per_kernel_alg)
     dom = max(cands, key=lambda k: kinfo[k]["avg_ms"] * kinfo[k]["launches"]) if cands else None
+    # the dominant kernel's average launch time on every rank: mean, fastest and slowest GPU (the same kernel dominates everywhere:
+    # all ranks run the same configuration; a rank without timings contributes a negative value and voids the mean)
+    dom_ms_mine = kinfo[dom]["avg_ms"] if dom else -1.0
+    dgroup = dist if world > 1 else None
+    dom_ms_sum = shard.reduce_over_ranks(dom_ms_mine, dgroup, "sum")
+    dom_ms_max = shard.reduce_over_ranks(dom_ms_mine, dgroup, "max")
+    dom_ms_min = -shard.reduce_over_ranks(-dom_ms_mine, dgroup, "max")
+    fallbacks_all = int(shard.reduce_over_ranks(float(max(fused_fallbacks, 0)), dgroup, "sum"))
+    ranks_bound = int(shard.reduce_over_ranks(1.0 if placement.get("cpus", 0) > 0 else 0.0, dgroup, "sum"))
+    if world > 1:
+        dist.barrier()                           # every reduction is done: the ranks leave together, rank 0 goes on alone
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+
+    total_frames = B * world * args.steps
+    fps = total_frames / elapsed
+    ms_step = elapsed / args.steps * 1e3
+
     # `traffic` is NOT measured by this run: PMC counters need rocprofv3 (separate --pmc passes, tools/collect_profiles.sh).
     # It is the committed per-launch figure of the same kernel / workload, and `traffic_source` says where it came from.
     traffic, traffic_source = None, None
@@ -343,18 +443,22 @@ def main():
         except Exception:
             traffic = None
     roofline = None
-    if dom:
-        alg_bytes = per_kernel_alg[dom]
-        achieved = alg_bytes / (kinfo[dom]["avg_ms"] * 1e-3) / 1e9
+    if dom and dom_ms_min > 0:
+        alg_bytes = per_kernel_alg[dom]                              # per launch = per GPU: every rank launches on its own batch
+        avg_ms_all = dom_ms_sum / world                              # mean over the ranks of each rank's average launch duration
+        achieved = alg_bytes / (avg_ms_all * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kinfo[dom]["avg_ms"],
-                    "launch_ms_p10_p50_p90": [kinfo[dom]["p10_ms"], kinfo[dom]["p50_ms"], kinfo[dom]["p90_ms"]]}
+                    "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms_all, 5),
+                    "avg_launch_ms_fastest_rank": round(dom_ms_min, 5), "avg_launch_ms_slowest_rank": round(dom_ms_max, 5),
+                    "frac_slowest_rank": round(alg_bytes / (dom_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "ranks": world, "per": "GPU (each rank's own launches; mean over ranks)",
+                    "launch_ms_p10_p50_p90_rank0": [kinfo[dom]["p10_ms"], kinfo[dom]["p50_ms"], kinfo[dom]["p90_ms"]]}
         # the same launch priced on the bytes that MOVE: the fused kernel reads Y once (2*W*H + UV per frame), every other
         # kernel moves its algorithmic bytes.  frac_moved_bytes is against the 8 TB/s peak, and the second figure against the
         # 6.29 TB/s a plain copy kernel reaches on this chip (MI355X_MICROARCH.md).
         moved = (2 * ysz + uv_bytes) * B if dom == "equalize_fused_kernel" else alg_bytes
-        moved_GBs = moved / (kinfo[dom]["avg_ms"] * 1e-3) / 1e9
+        moved_GBs = moved / (avg_ms_all * 1e-3) / 1e9
         roofline["moved_bytes_per_launch"] = moved
         roofline["moved_GBs"] = round(moved_GBs, 1)
         roofline["frac_moved_bytes"] = round(moved_GBs / HBM_PEAK_GBS, 4)
@@ -371,14 +475,15 @@ def main():
                                f"(BASELINE.json configs[1] batched), Y distribution {args.dist}",
                    "path": "fused single-read kernel" if "equalize_fused_kernel" in kinfo else "staged kernels",
                    "frames_per_gpu_per_step": B, "width": w, "height": h, "uv": args.uv, "op": args.op,
-                   "sharding": f"frame k -> GPU k mod {world}, no collective"},
+                   "sharding": f"one replica batch per GPU (frame k -> GPU k mod {world}), no data-path collective",
+                   "numa": {"rank0": placement.get("why"), "ranks_bound": ranks_bound, "ranks": world}},
         "parity_spot_check": parity,
-        "fused_fallbacks_in_run": fused_fallbacks,
+        "fused_fallbacks_in_run": fallbacks_all,
         "dist_backend_used": backend_used, "world_seen_by_backend": world_seen,
         "whole_path_alg_GBs": round((3 * ysz + uv_bytes) * fps / 1e9, 1),
         "nv12_1080p": second,
         "roofline": roofline,
-        "kernels": kinfo,
+        "kernels_rank0": kinfo,
     }
 
     # secondary figures must never cost the headline its JSON line
@@ -394,12 +499,9 @@ def main():
         out["opencv_cross_check"] = guarded(opencv_cross_check, ctx, w, h, args.dist)
     if world == 1 and not args.no_extras:
         out["extras"] = guarded(extras, ctx, args, torch, mi_lumaeq, synth)
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:                                   # N > 1 as well: rank 0 alone by now, the other ranks have exited
         out["cpu_baseline"] = guarded(cpu_baseline, args, w, h)
     print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def stream_config4(w, h, device=None):
@@ -428,6 +530,7 @@ def stream_config4(w, h, device=None):
     m = re.search(r"errors=(\d+)", r.stdout)
     if m:
         res["errors"] = int(m.group(1))
+    res["placement"] = re.findall(r"^placement: (.*)$", r.stdout, flags=re.M)      # where the streamer's threads and frame ring live
     u = subprocess.run(base + ["--frames", "2000"], capture_output=True, text=True, timeout=180, env=env)
     m = re.search(r"= ([0-9.]+) frames/s", u.stdout)
     if m:

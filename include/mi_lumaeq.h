@@ -75,6 +75,22 @@ const char* mi_status_str(mi_status s);
 const char* mi_version(void);
 int         mi_device_count(void);                         /* 0 when no HIP device is usable       */
 
+/* ---- placement of a GPU's host worker -----------------------------------------------------------
+ * The frame-sharded stream runs one host worker per GPU (reference: the worker pool of OpenCVequalHist.cpp:397-402, which
+ * places nothing).  mi_thread_bind_near_device() binds the CALLING THREAD to the CPUs of the NUMA node the device's PCIe
+ * root complex hangs off (device -> PCI address -> /sys/bus/pci/devices/<bdf>/numa_node -> that node's cpulist, intersected
+ * with the CPUs the process may use; sched_setaffinity in-process).  Call it BEFORE mi_ctx_create / mi_pipe_create on that
+ * thread: the pinned staging buffers they allocate are then first touched next to the GPU, and threads the library starts
+ * later inherit the binding.  Never fatal: when the platform reports no node (-1) or none of its CPUs is available, the
+ * thread stays where it is and `why` says so.  MI_LUMAEQ_NUMA_BIND=0 in the environment turns every call into a no-op. */
+typedef struct mi_numa_binding {
+    int  node;                   /* NUMA node of the device, -1 unknown                    */
+    int  cpus;                   /* CPUs the thread is now bound to, 0 = left where it was */
+    char why[192];               /* one line for a banner / log                            */
+} mi_numa_binding;
+mi_status mi_device_pci_bus_id(int device, char* buf, size_t buf_len);         /* "0000:c1:00.0" */
+mi_status mi_thread_bind_near_device(int device, mi_numa_binding* out);        /* out may be NULL */
+
 /* ---- host-pointer forms: the cv::Mat boundary -----------------------------------------------
  * Synchronous: on return dst is fully written in host memory (SURVEY 8b "Semantics to keep").
  * src/dst are CV_8UC1 planes with row pitch `*_step` >= width (ROI views: clahevideo.cpp:179);

@@ -41,6 +41,36 @@ int mi_device_count(void)
     return n;
 }
 
+mi_status mi_device_pci_bus_id(int device, char* buf, size_t buf_len)
+{
+    if (!buf || buf_len < 13) return MI_ERR_BAD_ARG;
+    buf[0] = 0;
+    const int n = mi_device_count();
+    if (n <= 0 || device < 0 || device >= n) return MI_ERR_NO_DEVICE;
+    if (hipDeviceGetPCIBusId(buf, (int)std::min<size_t>(buf_len, 64), device) != hipSuccess) { (void)hipGetLastError(); buf[0] = 0; return MI_ERR_HIP; }
+    return MI_OK;
+}
+
+mi_status mi_thread_bind_near_device(int device, mi_numa_binding* out)
+{
+    mi_numa_binding b{};
+    b.node = -1;
+    auto finish = [&](mi_status st, const std::string& why) {
+        snprintf(b.why, sizeof b.why, "%s", why.c_str());
+        if (out) *out = b;
+        return st;
+    };
+    char bdf[64];
+    const mi_status st = mi_device_pci_bus_id(device, bdf, sizeof bdf);
+    if (st) return finish(st, "no PCI address for this device");
+    const char* off = getenv("MI_LUMAEQ_NUMA_BIND");
+    const bool apply = !(off && atoi(off) == 0);
+    const mi_host::NumaBinding r = mi_host::bind_thread_near_pci(bdf, "/sys", apply);
+    b.node = r.node;
+    b.cpus = apply ? r.cpus : 0;
+    return finish(MI_OK, apply ? r.why : r.why + " (MI_LUMAEQ_NUMA_BIND=0: not applied)");
+}
+
 // Once per process: were the kernels built with separately rounded float steps?  (0 = not yet known, 1 = yes, -1 = no)
 static std::atomic<int> g_contract_ok{0};
 static int contract_probe()

@@ -12,7 +12,8 @@
 // ColoropenCVCwqualHist.cpp:165), --frames N, --input/--output raw NV12 files, --paced, --depth D (frames a worker keeps in flight on
 // its GPU), --uv-policy host|device (who writes the UV half), --no-pin (leave the frame ring pageable; by default it is registered
 // once, the way a GstBufferPool's memory would be), --loop (rewind --input at its end: clahevideo.cpp:294-302), --dump-every K
-// (write only every K-th delivered frame to --output).  --workers may exceed the GPU count (worker w -> GPU w mod N), up to 64.
+// (write only every K-th delivered frame to --output), --no-numa-bind (do not bind each worker to the CPUs of its GPU's NUMA node;
+// the binding is printed in the banner).  --workers may exceed the GPU count (worker w -> GPU w mod N), up to 64.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -37,7 +38,7 @@ int main(int argc, char** argv)
     using namespace micv;
     int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8, depth = 4;
     double clip = 2.0;
-    bool paced = false, pin = true, loop = false;
+    bool paced = false, pin = true, loop = false, numa_bind = true;
     int dump_every = 1;
     std::string op = "equalize", uv = "fill128", uv_policy = "host", input, output, v;
     for (int i = 1; i < argc; ++i) {
@@ -58,12 +59,21 @@ int main(int argc, char** argv)
         else if (strcmp(argv[i], "--pin") == 0) pin = true;          // (default) register the frame ring like a pinned GstBufferPool
         else if (strcmp(argv[i], "--no-pin") == 0) pin = false;
         else if (strcmp(argv[i], "--loop") == 0) loop = true;
+        else if (strcmp(argv[i], "--no-numa-bind") == 0) numa_bind = false;
         else if (kv(argv[i], "dump-every", v, i, argc, argv)) dump_every = std::max(1, atoi(v.c_str()));
         else fprintf(stderr, "Warning: ignoring unknown arg: %s\n", argv[i]);
     }
     if (width <= 0 || height <= 0 || frames <= 0) { fprintf(stderr, "bad size\n"); return 1; }
     const size_t fb = (size_t)width * height + (size_t)width * height / 2;
     const int ring = 32;                                            // frames in flight (input + output ring)
+    // every worker on one GPU (one worker, or a one-GPU process -- how bench.py runs one streamer per GPU): the submitting thread
+    // and the frame ring it first-touches below belong next to that GPU as well
+    std::string main_placement = "submitting thread: not bound (workers spread over several GPUs)";
+    if (!numa_bind) main_placement = "submitting thread: NUMA binding off";
+    else if (workers == 1 || getDeviceCount() == 1) {
+        mi_numa_binding nb{};
+        main_placement = std::string("submitting thread + frame ring: ") + (mi_thread_bind_near_device(0, &nb) == MI_OK ? nb.why : "not bound");
+    }
     std::vector<std::vector<unsigned char>> in(ring, std::vector<unsigned char>(fb)), out(ring, std::vector<unsigned char>(fb));
     FILE* fin = input.empty() ? nullptr : fopen(input.c_str(), "rb");
     FILE* fout = output.empty() ? nullptr : fopen(output.c_str(), "wb");
@@ -92,9 +102,11 @@ int main(int argc, char** argv)
                            delivered.fetch_add(1);
                        },
                        clip, Size(tile, tile), ring / (size_t)workers > 2 ? ring / (size_t)workers - 1 : 1, depth,
-                       uv_policy == "device" ? MI_PIPE_UV_DEVICE : MI_PIPE_UV_HOST);
+                       uv_policy == "device" ? MI_PIPE_UV_DEVICE : MI_PIPE_UV_HOST, numa_bind);
         printf("nv12_stream: %dx%d %s uv=%s (uv-policy %s) workers=%d depth=%d gpus=%d frames=%d%s%s\n", width, height, op.c_str(), uv.c_str(),
                uv_policy.c_str(), workers, depth, getDeviceCount(), frames, paced ? " paced" : "", pin ? " pinned-ring" : " pageable-ring");
+        printf("placement: %s\n", main_placement.c_str());
+        for (const std::string& line : pool.placement()) printf("placement: %s\n", line.c_str());
         // synthetic source: the ring's frames exist before the clock starts (a camera / decoder hands over finished frames;
         // generating 12 MB of noise per frame on the submitting thread would otherwise be the slowest stage of the first lap)
         if (!fin) for (int k = 0; k < ring && k < frames; ++k) synth(in[k], k);

@@ -11,6 +11,10 @@
 // write / task / read at a time (OpenCLequalHist.cpp:356-365): it drives an mi_pipe, so the upload of
 // frame k+2, the kernels of frame k+1 and the download of frame k overlap and ONE worker per GPU keeps
 // the PCIe link busy in both directions.  No collective: frames are independent.
+// Placement: before it creates its context, each worker binds itself to the CPUs of its GPU's NUMA node
+// (mi_thread_bind_near_device), so the pinned staging it allocates and the UV half it writes stay next to
+// that GPU's PCIe root complex -- the reference places nothing (OpenCVequalHist.cpp:397-402).  `numa_bind = false`
+// (or MI_LUMAEQ_NUMA_BIND=0) leaves the threads where the scheduler puts them.
 #ifndef MI_POOL_HPP_
 #define MI_POOL_HPP_
 
@@ -48,15 +52,17 @@ public:
 
     // depth: frames a worker keeps in flight on its GPU (2..16); uv_policy: MI_PIPE_UV_AUTO / _HOST / _DEVICE (mi_lumaeq.h)
     FramePool(int workers, int width, int height, Op op, UVMode uv, Sink sink,
-              double clip = 2.0, Size tiles = Size(8, 8), size_t max_queue = 16, int depth = 4, int uv_policy = MI_PIPE_UV_AUTO)
+              double clip = 2.0, Size tiles = Size(8, 8), size_t max_queue = 16, int depth = 4, int uv_policy = MI_PIPE_UV_AUTO,
+              bool numa_bind = true)
         : width_(width), height_(height), op_(op), uv_(uv), clip_(clip), tiles_(tiles), sink_(std::move(sink)), max_queue_(max_queue),
-          depth_(depth < 2 ? 2 : (depth > 16 ? 16 : depth)), uv_policy_(uv_policy)
+          depth_(depth < 2 ? 2 : (depth > 16 ? 16 : depth)), uv_policy_(uv_policy), numa_bind_(numa_bind)
     {
         if (workers < 1) workers = 1;
         if (workers > 64) workers = 64;
         const int ndev = getDeviceCount();
         if (ndev <= 0) MI_CV_ERROR(GpuNotSupported, "no HIP device (this backend has no CPU fallback)");
         queues_.resize(workers);
+        placement_.resize(workers);
         for (int w = 0; w < workers; ++w) threads_.emplace_back([this, w, ndev] { run(w, w % ndev); });
         // wait until every worker has created its context and sized its staging/scratch for W x H, so the first real
         // frame does not pay ~100 ms of one-time allocation (it would blow a 16.7 ms frame budget)
@@ -66,6 +72,8 @@ public:
     ~FramePool() { finish(); }
 
     int workers() const { return (int)threads_.size(); }
+    // one line per worker: which GPU, which NUMA node, how many CPUs it was bound to (valid once the constructor has returned)
+    std::vector<std::string> placement() const { std::lock_guard<std::mutex> lk(mu_); return placement_; }
     const PoolStats& stats() const { return stats_; }
     size_t queue_depth() const { std::lock_guard<std::mutex> lk(mu_); size_t n = 0; for (auto& q : queues_) n += q.size(); return n; }
 
@@ -102,6 +110,15 @@ private:
 
     void run(int w, int device)
     {
+        {   // placement first: the context created below allocates its pinned staging from this thread
+            mi_numa_binding nb{};
+            std::string line = "worker " + std::to_string(w) + " -> GPU " + std::to_string(device) + ": ";
+            if (!numa_bind_) line += "NUMA binding off";
+            else if (mi_thread_bind_near_device(device, &nb) == MI_OK) line += nb.why;
+            else line += std::string("not bound (") + nb.why + ")";
+            std::lock_guard<std::mutex> lk(mu_);
+            placement_[w] = line;
+        }
         setDevice(device);
         mi_ctx* c = nullptr;
         mi_pipe* pipe = nullptr;
@@ -190,6 +207,8 @@ private:
     Sink sink_;
     size_t max_queue_;
     int depth_, uv_policy_;
+    bool numa_bind_;
+    std::vector<std::string> placement_;
     mutable std::mutex mu_;
     std::condition_variable cv_work_, cv_space_, cv_done_;
     std::vector<std::deque<FrameJob>> queues_;

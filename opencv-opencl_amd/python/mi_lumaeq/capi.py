@@ -41,6 +41,7 @@ DECLARED_SYMBOLS = [
     "mi_cvt_color_u8c3", "mi_cvt_color_u8c3_batch_dev", "mi_bgr_luma_op_u8c3", "mi_bgr_luma_op_u8c3_batch_dev",
     "mi_nv12_bgr_equalize", "mi_nv12_bgr_equalize_batch_dev", "mi_cvt_color_420_u8", "mi_cvt_color_420_u8_batch_dev",
     "mi_analyze_diff_u8", "mi_analyze_diff_u8_batch_dev",
+    "mi_device_pci_bus_id", "mi_thread_bind_near_device",
 ]
 
 _K = len(KERNEL_NAMES)
@@ -49,6 +50,10 @@ _K = len(KERNEL_NAMES)
 class _Profile(C.Structure):
     _fields_ = [("total_ms", C.c_double * _K), ("launches", C.c_uint64 * _K), ("min_ms", C.c_double * _K), ("p10_ms", C.c_double * _K),
                 ("p50_ms", C.c_double * _K), ("p90_ms", C.c_double * _K), ("max_ms", C.c_double * _K)]
+
+
+class _NumaBinding(C.Structure):
+    _fields_ = [("node", C.c_int), ("cpus", C.c_int), ("why", C.c_char * 192)]
 
 
 class _PipeConfig(C.Structure):
@@ -147,6 +152,8 @@ def _load(p: Path) -> C.CDLL:
     L.mi_pipe_depth.argtypes = [vp]
     L.mi_ctx_set_profiling.argtypes = [vp, i]
     L.mi_ctx_profile_read.argtypes = [vp, C.POINTER(_Profile), i]
+    L.mi_device_pci_bus_id.argtypes = [i, C.c_char_p, sz]
+    L.mi_thread_bind_near_device.argtypes = [i, C.POINTER(_NumaBinding)]
     return L
 
 
@@ -163,6 +170,24 @@ def version() -> str:
 
 def device_count() -> int:
     return int(lib().mi_device_count())
+
+
+def device_pci_bus_id(device: int) -> str:
+    buf = C.create_string_buffer(64)
+    rc = lib().mi_device_pci_bus_id(int(device), buf, 64)
+    if rc != 0:
+        raise MiError(rc, "mi_device_pci_bus_id")
+    return buf.value.decode()
+
+
+def bind_thread_near_device(device: int) -> dict:
+    """Bind the CALLING thread to the CPUs of the device's NUMA node (mi_thread_bind_near_device): call before Context(device).
+    Returns {"node", "cpus", "why"}; never raises for a platform that reports no node."""
+    b = _NumaBinding()
+    rc = lib().mi_thread_bind_near_device(int(device), C.byref(b))
+    if rc != 0:
+        raise MiError(rc, "mi_thread_bind_near_device", b.why.decode(errors="replace"))
+    return {"node": int(b.node), "cpus": int(b.cpus), "why": b.why.decode(errors="replace")}
 
 
 def host_register(a: np.ndarray) -> None:

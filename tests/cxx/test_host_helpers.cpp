@@ -2,7 +2,9 @@
 //   host/drain_guard.hpp  "never return while a DMA on caller memory is in flight": every exit path of a function that has not
 //                         itself waited for its streams synchronises them (stubbed synchronise call, stubbed failures)
 //   host/copy_crew.hpp    the calling thread + one helper copying a plane into / out of pinned staging
+//   host/numa_affinity.hpp  GPU PCI address -> NUMA node -> CPU list -> thread affinity, against a FAKE sysfs tree
 // No GPU, no HIP: both headers are written against injected / standard facilities so that their exit paths can be checked here.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +13,10 @@
 
 #include "../../opencv-opencl_amd/csrc/host/copy_crew.hpp"
 #include "../../opencv-opencl_amd/csrc/host/drain_guard.hpp"
+#include "../../opencv-opencl_amd/csrc/host/numa_affinity.hpp"
+
+#include <sys/stat.h>
+#include <unistd.h>
 
 static int g_fail = 0;
 #define CHECK(cond)                                                                  \
@@ -149,10 +155,87 @@ static void test_copy_crew()
     }
 }
 
+// ---- NUMA placement ------------------------------------------------------------------------------------
+static void mkdirs(const std::string& path)
+{
+    for (size_t i = 1; i <= path.size(); ++i)
+        if (i == path.size() || path[i] == '/') mkdir(path.substr(0, i).c_str(), 0777);
+}
+static void put(const std::string& path, const std::string& text)
+{
+    mkdirs(path.substr(0, path.rfind('/')));
+    FILE* f = fopen(path.c_str(), "w");
+    if (f) { fputs(text.c_str(), f); fclose(f); }
+}
+
+static void test_numa_affinity()
+{
+    using namespace mi_host;
+    CHECK((parse_cpulist("0-3,8,10-11\n") == std::vector<int>{0, 1, 2, 3, 8, 10, 11}));
+    CHECK((parse_cpulist("5") == std::vector<int>{5}));
+    CHECK(parse_cpulist("").empty() && parse_cpulist("\n").empty());
+    CHECK((parse_cpulist("0-1,x") == std::vector<int>{0, 1}));         // malformed tail: what was parsed before it
+    CHECK(parse_cpulist("7-3").empty());
+    CHECK(normalize_bdf("0000:C1:00.0\n") == "0000:c1:00.0" && normalize_bdf("c1:00.0") == "0000:c1:00.0");
+
+    // a fake two-socket machine: the CPUs this process may use are split over "node 0" and "node 1"
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    CHECK(sched_getaffinity(0, sizeof allowed, &allowed) == 0);
+    std::vector<int> mine;
+    for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) mine.push_back(c);
+    CHECK(!mine.empty());
+    char tmpl[] = "/tmp/mi_fake_sysfs_XXXXXX";
+    const char* root_c = mkdtemp(tmpl);
+    CHECK(root_c != nullptr);
+    if (!root_c) return;
+    const std::string root = root_c;
+    auto list = [](const std::vector<int>& v) { std::string s; for (size_t i = 0; i < v.size(); ++i) s += (i ? "," : "") + std::to_string(v[i]); return s + "\n"; };
+    const std::vector<int> n0(mine.begin(), mine.begin() + (mine.size() + 1) / 2), n1(mine.begin() + (mine.size() + 1) / 2, mine.end());
+    put(root + "/devices/system/node/node0/cpulist", list(n0));
+    put(root + "/devices/system/node/node1/cpulist", n1.empty() ? "\n" : list(n1));
+    put(root + "/devices/system/node/node2/cpulist", "100000-100003\n");          // a node whose CPUs this process cannot use
+    put(root + "/bus/pci/devices/0000:c1:00.0/numa_node", "0\n");
+    put(root + "/bus/pci/devices/0000:e3:00.0/numa_node", "1\n");
+    put(root + "/bus/pci/devices/0000:05:00.0/numa_node", "-1\n");                // single-node platforms say -1
+    put(root + "/bus/pci/devices/0000:07:00.0/numa_node", "2\n");
+    CHECK(numa_node_of_pci("0000:C1:00.0", root) == 0 && numa_node_of_pci("e3:00.0", root) == 1);
+    CHECK(numa_node_of_pci("0000:05:00.0", root) == -1 && numa_node_of_pci("0000:99:00.0", root) == -1);   // unknown device: no file
+    CHECK(cpus_of_node(0, root) == n0 && cpus_of_node(5, root).empty());
+
+    NumaBinding b = bind_thread_near_pci("0000:c1:00.0", root);
+    CHECK(b.node == 0 && b.cpus == (int)n0.size());
+    cpu_set_t now;
+    CPU_ZERO(&now);
+    CHECK(sched_getaffinity(0, sizeof now, &now) == 0);
+    for (int c : mine) CHECK((CPU_ISSET(c, &now) != 0) == (std::find(n0.begin(), n0.end(), c) != n0.end()));
+    // a thread started AFTER the binding inherits it (the library's helper thread is created from the bound worker)
+    int inherited = -1;
+    std::thread([&] { cpu_set_t t; CPU_ZERO(&t); sched_getaffinity(0, sizeof t, &t); inherited = CPU_COUNT(&t); }).join();
+    CHECK(inherited == (int)n0.size());
+    CHECK(sched_setaffinity(0, sizeof allowed, &allowed) == 0);                     // back to the full set for the cases below
+    b = bind_thread_near_pci("0000:05:00.0", root);
+    CHECK(b.node == -1 && b.cpus == 0 && b.why.find("not bound") != std::string::npos);
+    b = bind_thread_near_pci("0000:07:00.0", root);
+    CHECK(b.node == 2 && b.cpus == 0 && b.why.find("none of its CPUs") != std::string::npos);
+    b = bind_thread_near_pci("0000:c1:00.0", root, /*apply=*/false);                // "disabled": reports, does not bind
+    CHECK(b.node == 0 && b.cpus == (int)n0.size());
+    CPU_ZERO(&now);
+    CHECK(sched_getaffinity(0, sizeof now, &now) == 0 && CPU_COUNT(&now) == (int)mine.size());
+    if (!n1.empty()) {
+        b = bind_thread_near_pci("0000:e3:00.0", root);
+        CHECK(b.node == 1 && b.cpus == (int)n1.size());
+        CHECK(sched_setaffinity(0, sizeof allowed, &allowed) == 0);
+    }
+    const std::string rm = "rm -rf " + root;
+    (void)!system(rm.c_str());
+}
+
 int main()
 {
     test_drain_guard();
     test_copy_crew();
+    test_numa_affinity();
     if (g_fail) { fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
     printf("host helpers ok\n");
     return 0;

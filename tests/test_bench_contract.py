@@ -30,6 +30,92 @@ def test_cpu_baseline_fields():
     assert "640x360" in cb["sample"]
 
 
+_STUB = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+print(f"hello from rank {rank} of {world}: argv={sys.argv[1:]}", flush=True)
+if mode == "ok":
+    time.sleep(0.2 * (world - rank))                      # rank 0 finishes last, like the real bench
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "n_gpus": world, "port": int(os.environ["MASTER_PORT"])}), flush=True)
+elif mode == "rank1_fails":
+    if rank == 1:
+        sys.exit(7)
+    time.sleep(600)                                       # "blocked in a collective with the dead rank"
+elif mode == "no_line":
+    pass
+'''
+
+
+def test_self_launcher_starts_one_fresh_child_per_gpu(tmp_path, capfd):
+    """`python bench.py --gpus N` with WORLD_SIZE unset becomes a launcher (bench.launch_children): N children with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0's JSON line relayed to stdout, everything else to stderr, the worst
+    exit code returned, and ranks left waiting for a dead one are ended after the grace period.  Stub children: no GPU here."""
+    import json
+    import time
+    import bench
+    stub = tmp_path / "stub_child.py"
+    stub.write_text(_STUB)
+    cmd = [sys.executable, str(stub)]
+    rc = bench.launch_children(3, ["ok", "--steps", "5"], child_cmd=cmd)
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 3
+    for r in range(3):
+        assert f"[rank {r}] hello from rank {r} of 3: argv=['ok', '--steps', '5']" in err
+    t0 = time.monotonic()
+    rc = bench.launch_children(2, ["rank1_fails"], child_cmd=cmd, grace_s=1.0)
+    assert rc == 7 and time.monotonic() - t0 < 30                # rank 0 did not keep the launcher for its 600 s
+    capfd.readouterr()
+    assert bench.launch_children(2, ["no_line"], child_cmd=cmd) == 1     # all ranks fine but no result: still a failure
+
+
+def test_plain_invocation_with_gpus_n_launches_instead_of_exiting(tmp_path):
+    """The round-2 bench exited with "launch with torch.distributed.run" here.  Without a GPU the children fail loudly (no CPU fallback),
+    and the launcher passes their failure on -- but they WERE started, each with its own rank."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_two_ranks_contract_on_gpu")
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dist-backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stderr or "needs HIP devices" in r.stderr, r.stderr[-2000:]
+    assert "torch.distributed.run" not in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_contract_on_gpu():
+    """N > 1 from a plain invocation: two ranks rehearsed on ONE GPU over gloo (asked for by name; the real thing is RCCL on 2+ GPUs,
+    which only the driver's 8-GPU node can run).  The line must carry what a SCALE line is graded on: n_gpus, whole-job value,
+    roofline with the per-rank spread, cpu_baseline, the sharding wording, the backend that really connected the ranks."""
+    import json
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--all-ranks-on-device", "0",
+                        "--steps", "5", "--warmup", "2", "--no-extras", "--cpu-seconds", "1.5", "--batch", "32"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert d["dist_backend_used"] == "gloo" and d["world_seen_by_backend"] == 2
+    assert abs(d["value"] - 2 * 32 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 0.01          # whole job: both ranks' frames
+    assert "one replica batch per GPU" in d["config"]["sharding"] and "no data-path collective" in d["config"]["sharding"]
+    assert d["config"]["numa"]["ranks"] == 2
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["ranks"] == 2 and rf["kernel"] in ("equalize_fused_kernel", "lut_apply_kernel")
+    assert 0 < rf["avg_launch_ms_fastest_rank"] <= rf["avg_launch_ms"] <= rf["avg_launch_ms_slowest_rank"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert d["parity_spot_check"] is True and isinstance(d["fused_fallbacks_in_run"], int)
+
+
 @pytest.mark.gpu
 def test_bench_line_contract_on_gpu():
     """`python bench.py` prints ONE JSON line with the fields the driver reads, the roofline and cpu_baseline objects, and the
@@ -56,3 +142,5 @@ def test_bench_line_contract_on_gpu():
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and "3840x2160" in cb["sample"]
     assert d["nv12_1080p"]["value"] > d["value"]                       # four times fewer pixels per frame
     assert d["dist_backend_used"] is None and d["world_seen_by_backend"] == 1
+    assert rf["ranks"] == 1 and rf["avg_launch_ms_fastest_rank"] == rf["avg_launch_ms_slowest_rank"] == rf["avg_launch_ms"]
+    assert "one replica batch per GPU" in d["config"]["sharding"] and d["config"]["numa"]["ranks"] == 1
