@@ -234,7 +234,7 @@ def main():
     import torch
     import torch.distributed as dist
     import mi_lumaeq
-    from mi_lumaeq import synth, shard
+    from mi_lumaeq import synth, shard, xfer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -331,8 +331,8 @@ def main():
         import oracle
         parity = True
         for k in sorted({0, B // 2, B - 1}):
-            got = d_out[k].cpu().numpy()
-            want = oracle.nv12_frame(d_in[k].cpu().numpy(), w, h, uv_mode=uv_mode, op=1 if args.op == "clahe" else 0,
+            got = xfer.to_host(d_out[k])
+            want = oracle.nv12_frame(xfer.to_host(d_in[k]), w, h, uv_mode=uv_mode, op=1 if args.op == "clahe" else 0,
                                      clip_limit=2.0, tiles_x=8, tiles_y=8)
             parity = parity and bool(np.array_equal(got, want))
     # one verdict for the whole job, shared BEFORE anybody exits, so no rank is left blocked in a barrier
@@ -542,6 +542,7 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     """Secondary figures outside the timed region (N=1 only): single-frame latency, device-resident and
     through the host cv::Mat boundary (PCIe-inclusive; never the headline value), and CLAHE."""
     import numpy as np
+    from mi_lumaeq import xfer
     w, h = args.width, args.height
     res = {}
     # the north star also asks for the stand-alone LUT-apply kernel's roofline: run the three-kernel path briefly
@@ -671,7 +672,7 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
         if gctx is not None:
             torch.cuda.synchronize()
             gctx.close()
-    y = frame[0, : w * h].cpu().numpy().reshape(h, w)
+    y = xfer.to_host(frame[0, : w * h]).reshape(h, w)
     dst = np.empty_like(y)
     res["host_mat_equalize_ms_pcie_inclusive"] = round(timeit(lambda: ctx.equalize_hist(y, dst), 20), 3)
     res["host_mat_clahe8x8_ms_pcie_inclusive"] = round(timeit(lambda: ctx.clahe(y, 2.0, 8, 8, dst), 20), 3)
@@ -720,7 +721,7 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     for k in range(Bp):                                        # every frame a different window of the tiling
         fr[k, : w * h] = big[13 * k: 13 * k + h, 29 * k: 29 * k + w].reshape(-1)
         fr[k, w * h:] = 128
-    d_in = torch.from_numpy(fr).cuda()
+    d_in = xfer.to_device(fr)
     d_out = torch.empty_like(d_in)
     ms = timeit(lambda: ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, Bp, mi_lumaeq.UV_FILL128, stream=stream), 20)
     res["photo_like_equalize_frames_per_s"] = round(Bp / (ms * 1e-3), 1)

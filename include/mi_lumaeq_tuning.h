@@ -39,4 +39,12 @@
 #define MI_OPT_HOST_COPY_THREADS   "host_copy_threads"   /* 1 / 2, default 2: threads that pack unpinned planes through the pinned
                                                            * staging buffers (the caller alone, or the caller and the context's helper) */
 
+#define MI_OPT_HOST_COPY_STREAMS   "host_copy_streams"   /* 1 / 2, default 2: streams the chunk DMAs of a staged plane alternate between (the
+                                                           * copy engine idles ~10 us between dependent copies of one stream)          */
+#define MI_OPT_PIPE_COPY_STREAMS   "pipe_copy_streams"   /* 1 / 2, default 2: copy streams per direction of a pipe created afterwards:
+                                                           * consecutive frames alternate between them                                */
+/* The same knobs from the environment, read by mi_ctx_create (for A/B runs of unmodified programs):
+ * MI_LUMAEQ_FUSED, MI_LUMAEQ_FUSED_WGS_PER_CU, MI_LUMAEQ_FUSED_VPT, MI_LUMAEQ_FUSED_ACQUIRE, MI_LUMAEQ_HOST_COPY_THREADS,
+ * MI_LUMAEQ_HOST_COPY_STREAMS, MI_LUMAEQ_PIPE_COPY_STREAMS. */
+
 #endif /* MI_LUMAEQ_TUNING_H_ */

@@ -108,23 +108,25 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
     mi_ctx* c = new (std::nothrow) mi_ctx();
     if (!c) return MI_ERR_OOM;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess) {
         (void)hipGetLastError();
         delete c;
         return MI_ERR_HIP;
     }
+    // (the context's own stream is created by the first entry point that needs one -- ensure_stream(): a streaming worker's
+    // context never does, and every stream a process creates competes for the runtime's few hardware queues, see pipe_stream_create)
     {   // one line of pinned, device-writable host memory: the finish kernel of the fused path reports repaired launches into it
         void* q = nullptr;
-        if (hipHostMalloc(&q, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        if (hipHostMalloc(&q, 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
             || hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (q) (void)hipHostFree(q);
-            (void)hipStreamDestroy(c->stream);
+            for (hipEvent_t e : {c->ev_scratch, c->ev_b, c->ev_k}) if (e) (void)hipEventDestroy(e);
             delete c;
             return MI_ERR_HIP;
         }
         c->h_mirror = (uint32_t*)q;
-        memset(c->h_mirror, 0, 64);
+        memset(c->h_mirror, 0, 128);
     }
     // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
@@ -140,6 +142,10 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
     if (const char* e = getenv("MI_LUMAEQ_FUSED_WGS_PER_CU")) c->fused_wgs_per_cu = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("MI_LUMAEQ_FUSED_VPT")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 20 || v == 24) c->fused_vpt = v; }
     if (const char* e = getenv("MI_LUMAEQ_FUSED_ACQUIRE")) c->fused_acquire = atoi(e) != 0;
+    if (const char* e = getenv("MI_LUMAEQ_PIPE_COPY_STREAMS")) c->pipe_copy_streams = atoi(e) > 1 ? 2 : 1;      // A/B runs of nv12_stream
+    if (const char* e = getenv("MI_LUMAEQ_PIPE_PRIVATE_STREAMS")) c->pipe_private_streams = atoi(e) != 0;
+    if (const char* e = getenv("MI_LUMAEQ_HOST_COPY_STREAMS")) c->host_copy_streams = atoi(e) > 1 ? 2 : 1;
+    if (const char* e = getenv("MI_LUMAEQ_HOST_COPY_THREADS")) c->host_copy_threads = atoi(e) > 1 ? 2 : 1;
     *out = c;
     return MI_OK;
 }
@@ -150,6 +156,7 @@ void mi_ctx_destroy(mi_ctx* c)
     if (c->fused_slot && c->device >= 0 && c->device < kMaxDevices) g_fused_ctx_live[c->device].fetch_sub(1);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     for (auto e : c->chunk_events) (void)hipEventDestroy(e);
@@ -161,7 +168,8 @@ void mi_ctx_destroy(mi_ctx* c)
     if (c->d_c16) (void)hipFree(c->d_c16);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_mirror) (void)hipHostFree(c->h_mirror);
-    if (c->ev_scratch) (void)hipEventDestroy(c->ev_scratch);
+    for (hipEvent_t e : {c->ev_scratch, c->ev_b, c->ev_k}) if (e) (void)hipEventDestroy(e);
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     delete c->crew;
     if (c->d_stage_in) (void)hipFree(c->d_stage_in);
     if (c->d_stage_out) (void)hipFree(c->d_stage_out);
@@ -270,6 +278,9 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "clahe_xcd_map")) { c->clahe_xcd_map = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe16_transposed")) { c->clahe16_transposed = value != 0; return MI_OK; }
+    if (!strcmp(name, "pipe_private_streams")) { c->pipe_private_streams = value != 0; return MI_OK; }
+    if (!strcmp(name, "pipe_copy_streams")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "pipe_copy_streams must be 1 or 2"); c->pipe_copy_streams = value; return MI_OK; }
+    if (!strcmp(name, "host_copy_streams")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "host_copy_streams must be 1 or 2"); c->host_copy_streams = value; return MI_OK; }
     if (!strcmp(name, "host_copy_threads")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "host_copy_threads must be 1 or 2"); c->host_copy_threads = value; return MI_OK; }
 #ifdef MI_TEST_HOOKS
     // ---- test hooks (this is libmi_lumaeq_test.so)
@@ -286,6 +297,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
 mi_status mi_ctx_synchronize(mi_ctx* c, void* stream)
 {
     ENTER(c);
+    if (mi_status st0 = ensure_stream(c)) return st0;
     hipStream_t s = pick_stream(c, stream);
     HIPCHK(c, hipStreamSynchronize(s));
     if (!c->d_fused) return MI_OK;
@@ -318,8 +330,9 @@ mi_status mi_ctx_get_stat(mi_ctx* c, const char* name, uint64_t* out)
     for (int k = 0; k < 4; ++k)
         if (!strcmp(name, names[k])) {
             uint64_t st4[4];
-            mi_status st = fused_read_stats(c, c->stream, st4);
+            mi_status st = ensure_stream(c);
             if (st) return st;
+            if ((st = fused_read_stats(c, c->stream, st4))) return st;
             *out = st4[k];
             return MI_OK;
         }
@@ -499,41 +512,59 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     mi_status st;
     if ((st = grow_dev(c, &c->d_stage_in, &c->stage_in_bytes, ybytes))) return st;
     if ((st = grow_dev(c, &c->d_stage_out, &c->stage_out_bytes, ybytes))) return st;
-    hipStream_t s = c->stream;
+    if (!c->stream_b && c->host_copy_streams > 1) {
+        // the second copy stream exists only in contexts that run host forms on unpinned planes (a streaming worker's context never
+        // does: every stream a process creates competes for the runtime's few hardware queues, see pipe_stream_create)
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_k, hipEventDisableTiming));
+    }
+    hipStream_t s = c->stream, sb = c->stream_b ? c->stream_b : c->stream;
     const bool in_pinned = src_step == (size_t)width && host_range_pinned(src, ybytes, &c->pin_neg);
     const bool out_pinned = dst_step == (size_t)width && host_range_pinned(dst, ybytes, &c->pin_neg);
     if (!in_pinned && (st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, ybytes))) return st;
     if (!out_pinned && (st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, ybytes))) return st;
     CrewCall crew(c, !(in_pinned && out_pinned) && ybytes >= 4 * mi_host::CopyCrew::kMinBytes);
     StreamDrain drain(HipStreamSync{}, drain_counter(c));
-    drain.watch(s);
-    const int rows_per_chunk = std::max(1, (int)((size_t)(2u << 20) / (size_t)width));
+    drain.watch(s); drain.watch(sb);
+    // Staged planes move in chunks whose host copies overlap the DMA of the chunks before.  The chunks ALTERNATE between two
+    // streams: the copy engine idles ~10-13 us between two dependent copies of one stream (measured: seven chunks took 268 us
+    // instead of 157), and the other stream's transfer covers that gap.  Chunk sizes ramp 256 KiB -> 2 MiB on the way up (the
+    // engine starts after a short first host copy) and back down at the end (the last host copy, which nothing overlaps, is a
+    // short one): 256 KiB, 512 KiB, then 1 MiB chunks -- the best of a 4 x 5 sweep of chunk size x ramp on a 4K plane
+    // (profiles/r03_b_host_chunk_sweep.txt: 0.406 ms per call against 0.464 with 2 MiB chunks ramped from 256 KiB).
+    static const int chunk_kb = [] { const char* e = getenv("MI_LUMAEQ_HOST_CHUNK_KB"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 1024; }();
+    static const int ramp0 = [] { const char* e = getenv("MI_LUMAEQ_HOST_CHUNK_RAMP"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 4; }();
+    const int rows_per_chunk = std::max(1, (int)(((size_t)chunk_kb << 10) / (size_t)width));
+    const bool two = c->host_copy_streams > 1 && c->stream_b && c->ev_b && c->ev_k;
     if (in_pinned) {
         HIPCHK(c, hipMemcpyAsync(c->d_stage_in, src, ybytes, hipMemcpyHostToDevice, s));
     } else {
-        // chunks grow from 256 KiB to 2 MiB: the copy engine starts after a short first host copy instead of a 2 MiB one
-        int y0 = 0;
-        for (int ramp = 8; y0 < height; ramp = std::max(1, ramp / 2)) {
+        int y0 = 0, i = 0;
+        bool used_b = false;
+        for (int ramp = ramp0; y0 < height; ramp = std::max(1, ramp / 2), ++i) {
             const int nr = std::min(std::max(1, rows_per_chunk / ramp), height - y0);
             const size_t off = (size_t)y0 * width;
             crew.copy(c->h_pin_in + off, (size_t)width, src + (size_t)y0 * src_step, src_step, width, nr);
-            HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, s));
+            const bool on_b = two && (i & 1);
+            HIPCHK(c, hipMemcpyAsync(c->d_stage_in + off, c->h_pin_in + off, (size_t)nr * width, hipMemcpyHostToDevice, on_b ? sb : s));
+            used_b |= on_b;
             y0 += nr;
+        }
+        if (used_b) {                                            // the kernels (on s) need stream_b's chunks as well
+            HIPCHK(c, hipEventRecord(c->ev_b, sb));
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_b, 0));
         }
     }
     PlaneArgs a{c->d_stage_in, (size_t)width, ybytes, c->d_stage_out, (size_t)width, ybytes, width, height, 1};
     st = is_clahe ? clahe_dev(c, s, a, clip_limit, tiles_x, tiles_y, nullptr) : equalize_dev(c, s, a, nullptr);
     if (st) return st;
-    // the "unrecoverable frame" counter of the fused path rides along behind the kernels (4 bytes, pinned): the repair itself
-    // has already happened on the device by the time the copies below run
+    // "unrecoverable frame" counter of the fused path: the finish kernel mirrors it into pinned host memory (FusedJob::host_hard),
+    // so it is simply read once the downloads -- which follow the finish kernel in stream order -- have completed: no extra copy
     const bool check_status = !is_clahe && c->d_fused;
-    if (check_status) {
-        if (!c->h_status) { void* q = nullptr; HIPCHK(c, hipHostMalloc(&q, 64, hipHostMallocDefault)); c->h_status = (uint32_t*)q; }
-        HIPCHK(c, hipMemcpyAsync(c->h_status + 8, c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    }
     auto hard_error = [&]() {
         if (!check_status) return false;
-        const uint64_t hard = c->fused_stat_base[2] + c->h_status[8];
+        const uint64_t hard = fused_hard_seen(c);
         if (hard <= c->fused_seen_hard) return false;
         c->fused_seen_hard = hard;
         return true;
@@ -548,6 +579,7 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         HIPCHK(c, hipMemcpyAsync(dst, c->d_stage_out, ybytes, hipMemcpyDeviceToHost, s));
         host_uv();                                              // the copy is asynchronous: the UV work overlaps the DMA itself
         HIPCHK(c, hipStreamSynchronize(s));
+        if (!in_pinned && two) HIPCHK(c, hipStreamSynchronize(sb));   // (idle by now: the kernels waited for its last upload)
         drain.done();
         if (hard_error()) return fail(c, MI_ERR_HIP, kHardMsg);
         return MI_OK;
@@ -555,10 +587,10 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     // device -> pinned in chunks, each followed by an event; then drain chunk by chunk into the caller's rows
     struct Chunk { size_t off, bytes; int y0, nr; };
     std::vector<Chunk> chunks;
-    {   // ... and shrink from 2 MiB to 256 KiB at the end: the last host copy, which nothing overlaps, is a short one
+    {
         std::vector<int> sizes;
         int left = height;
-        for (int ramp = 8; left > 0; ramp = std::max(1, ramp / 2)) { const int nr = std::min(std::max(1, rows_per_chunk / ramp), left); sizes.push_back(nr); left -= nr; }
+        for (int ramp = ramp0; left > 0; ramp = std::max(1, ramp / 2)) { const int nr = std::min(std::max(1, rows_per_chunk / ramp), left); sizes.push_back(nr); left -= nr; }
         int y0 = 0;
         for (size_t i = sizes.size(); i-- > 0;) { chunks.push_back({(size_t)y0 * width, (size_t)sizes[i] * width, y0, sizes[i]}); y0 += sizes[i]; }
     }
@@ -567,9 +599,14 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->chunk_events.push_back(e);
     }
+    if (two && chunks.size() > 1) {                              // stream_b's downloads wait for the kernels
+        HIPCHK(c, hipEventRecord(c->ev_k, s));
+        HIPCHK(c, hipStreamWaitEvent(sb, c->ev_k, 0));
+    }
     for (size_t i = 0; i < chunks.size(); ++i) {
-        HIPCHK(c, hipMemcpyAsync(c->h_pin_out + chunks[i].off, c->d_stage_out + chunks[i].off, chunks[i].bytes, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipEventRecord(c->chunk_events[i], s));
+        hipStream_t cs = (two && (i & 1)) ? sb : s;
+        HIPCHK(c, hipMemcpyAsync(c->h_pin_out + chunks[i].off, c->d_stage_out + chunks[i].off, chunks[i].bytes, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipEventRecord(c->chunk_events[i], cs));
     }
     host_uv();
     for (size_t i = 0; i < chunks.size(); ++i) {
@@ -577,7 +614,7 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
         if (i == 0 && hard_error()) return fail(c, MI_ERR_HIP, kHardMsg);     // (the guard drains the remaining chunks)
         crew.copy(dst + (size_t)chunks[i].y0 * dst_step, dst_step, c->h_pin_out + chunks[i].off, (size_t)width, width, chunks[i].nr);
     }
-    drain.done();                                               // the last chunk's event has been waited for: the stream is idle
+    drain.done();                                               // every chunk's event has been waited for: both streams are idle
     return MI_OK;
 }
 

@@ -70,6 +70,10 @@ struct mi_ctx {
     int device = -1;
     bool fused_slot = false;                                     // this context holds one of the per-device fused slots
     hipStream_t stream = nullptr;
+    hipStream_t stream_b = nullptr;                              // second copy stream of the host forms: chunk DMAs alternate between the two, so the
+                                                                 // ~10 us the copy engine idles between two dependent copies of ONE stream is covered
+                                                                 // by the other stream's transfer (profiles/r03_a_host_form_timeline.txt)
+    hipEvent_t ev_b = nullptr, ev_k = nullptr;                   // stream_b's uploads done -> kernels; kernels done -> stream_b's downloads
     std::mutex mu;
     int last_hip = 0;
     std::string last_msg = "ok";
@@ -91,8 +95,9 @@ struct mi_ctx {
     uint32_t* h_status = nullptr;                                // pinned mirror of the device statistics words (blocking reads)
     // Demotion of the fused path (equalize_fused.inc.hpp): the finish kernel also writes its "launches repaired" counter into a
     // word of pinned host memory, so the host learns about repaired launches without a copy or a synchronisation.
-    uint32_t* h_mirror = nullptr;                                // pinned, device-written: [0] repaired launches of the current block
-    uint64_t fused_repaired_base = 0;                            // ... of blocks since replaced
+    uint32_t* h_mirror = nullptr;                                // pinned, device-written: [g % 16] repaired launches, [16 + g % 16] unrecoverable
+                                                                 // frames of hand-off block generation g
+    uint64_t fused_repaired_base = 0, fused_hard_base = 0;       // ... of blocks since replaced
     uint64_t fused_window_start_repaired = 0;                    // repaired launches seen when the current observation window began
     uint32_t fused_window_launches = 0;                          // fused launches issued in the window
     uint64_t fused_demotions = 0;                                // statistic "fused_demotions"
@@ -112,6 +117,9 @@ struct mi_ctx {
     unsigned long long error_drains = 0;                                // statistic "error_drains": error exits that had to drain a stream first
     PinnedNegCache pin_neg;
     mi_host::CopyCrew* crew = nullptr;                           // helper thread for staging copies of the host forms (created on first use)
+    int pipe_private_streams = 0;                                // option "pipe_private_streams": a pipe created from now on owns its streams instead of sharing the device's
+    int pipe_copy_streams = 2;                                   // option "pipe_copy_streams": copy streams per direction of a pipe created from now on
+    int host_copy_streams = 2;                                   // option "host_copy_streams": 1 = every chunk DMA of a host form on the one stream
     int host_copy_threads = 2;                                   // option "host_copy_threads": 1 = the calling thread copies alone
     bool capturing = false;                                      // the stream of the call in progress is being captured (hipGraph)
     bool graph_captured = false;                                 // a capture has been seen: scratch referenced by graph nodes is never freed

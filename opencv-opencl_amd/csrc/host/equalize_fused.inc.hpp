@@ -61,6 +61,14 @@ uint64_t fused_repaired_seen(const mi_ctx* c)
     return n;
 }
 
+// unrecoverable frames, as mirrored by the finish kernel (exact once the stream the launch ran on has been waited for)
+uint64_t fused_hard_seen(const mi_ctx* c)
+{
+    uint64_t n = c->fused_hard_base;
+    for (int k = 0; k < kMirrorWords; ++k) n += __atomic_load_n(c->h_mirror + kMirrorWords + k, __ATOMIC_RELAXED);
+    return n;
+}
+
 bool fused_admit(mi_ctx* c)
 {
     if (c->fused_demote_after <= 0) return true;
@@ -123,8 +131,11 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
             hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (words + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                                c->d_fused, words);
             HIPCHK(c, hipGetLastError());
-            c->fused_repaired_base += __atomic_load_n(c->h_mirror + (c->fused_generation % kMirrorWords), __ATOMIC_RELAXED);
-            __atomic_store_n(c->h_mirror + (c->fused_generation % kMirrorWords), 0u, __ATOMIC_RELAXED);
+            for (int half = 0; half < 2; ++half) {              // the block restarts from zero: what its mirror words held moves into the bases
+                uint32_t* mw = c->h_mirror + half * kMirrorWords + (c->fused_generation % kMirrorWords);
+                (half ? c->fused_hard_base : c->fused_repaired_base) += __atomic_load_n(mw, __ATOMIC_RELAXED);
+                __atomic_store_n(mw, 0u, __ATOMIC_RELAXED);
+            }
         }
         c->fused_pair_open = false;
     }
@@ -159,6 +170,8 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
         uint32_t* mw = c->h_mirror + (c->fused_generation % kMirrorWords);
         c->fused_repaired_base += __atomic_load_n(mw, __ATOMIC_RELAXED);
         __atomic_store_n(mw, 0u, __ATOMIC_RELAXED);
+        c->fused_hard_base += __atomic_load_n(mw + kMirrorWords, __ATOMIC_RELAXED);
+        __atomic_store_n(mw + kMirrorWords, 0u, __ATOMIC_RELAXED);
     }
     const size_t cap = c->fused_cap;
     uint32_t* w = c->d_fused;
@@ -169,6 +182,7 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     j.lutpub = j.ghist + cap * 256;
     j.sflag = j.lutpub + cap * kLutPubWords;
     j.host_repaired = c->h_mirror + (c->fused_generation % kMirrorWords);
+    j.host_hard = j.host_repaired + kMirrorWords;
     const long long grid = std::min<long long>(tickets, (long long)c->cu_count * c->fused_wgs_per_cu);
     if (!c->capturing) c->fused_pair_open = true;
     switch (vpt) {

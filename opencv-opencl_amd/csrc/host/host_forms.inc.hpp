@@ -32,11 +32,20 @@ struct Guard {
     Guard guard__(ctx);                                              \
     if (guard__.err != hipSuccess) return fail_hip((ctx), guard__.err, "hipSetDevice")
 
+// The context's private stream (MI_STREAM_CTX, the host-pointer forms, statistics reads), created on first use.
+mi_status ensure_stream(mi_ctx* c)
+{
+    if (c->stream) return MI_OK;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    return MI_OK;
+}
+
 // Entry points that use the context's scratch: refused while frames are pending in the context's pipe (include/mi_lumaeq.h:
 // "the context's other entry points may be used while no frame is pending") -- the pipe's streams would race them for it.
 #define ENTER_COMPUTE(ctx)                                           \
     ENTER(ctx);                                                      \
-    if ((ctx)->pipe_pending > 0) return fail((ctx), MI_ERR_BUSY, "frames are pending in this context's pipe: call mi_pipe_wait first")
+    if ((ctx)->pipe_pending > 0) return fail((ctx), MI_ERR_BUSY, "frames are pending in this context's pipe: call mi_pipe_wait first"); \
+    if (mi_status st_es__ = ensure_stream(ctx)) return st_es__
 
 // Also notes whether the chosen stream is being captured into a hipGraph: scratch growth is refused then, and from the
 // first capture on no scratch a graph node may reference is ever freed (grow_dev).

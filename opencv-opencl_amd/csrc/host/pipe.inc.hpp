@@ -19,14 +19,18 @@
 // `in` / `out`) and does not occupy a slot; a failure inside wait drains them and STILL retires the slot, so the tags a caller
 // keeps (FramePool's inflight queue, Pipe._held in the Python binding) stay in step with the pipe.  One pipe per context; while
 // frames are pending the context's other compute entry points answer MI_ERR_BUSY.
-// All pipes of a process on one device share the SAME three streams: a second worker on a GPU then interleaves its frames
+// All pipes of a process on one device share the SAME streams: a second worker on a GPU then interleaves its frames
 // into the same queues instead of adding queues (8 streams on one device were measured 30 % SLOWER than 3: HIP multiplexes
 // streams onto 4 hardware queues, and unrelated copies end up ordered behind each other); as a side effect the fused
 // kernels of different contexts never overlap on a device when they come from pipes.
+// Each copy direction has TWO streams and consecutive frames alternate between them (option "pipe_copy_streams", default 2):
+// the copy engine idles ~10-13 us between two dependent copies of one stream (profiles/r03_a_host_form_timeline.txt), 6-8 % of
+// a 4K plane's transfer time; with the next frame's copy already running on the other stream the link never waits for it.
 // UV handling: "host" (default for Y-only ops) moves only the Y plane over the bus and fills / copies the UV half on the
 // host inside mi_pipe_wait while the engines are busy; "device" ships whole NV12 frames and lets the kernels do it.
 
 struct PipeSlot {
+    int lane = 0;                                                 // which of the two copy streams per direction carries this frame
     uint8_t* d_in = nullptr; uint8_t* d_out = nullptr;
     hipEvent_t ev_h2d = nullptr, ev_k = nullptr, ev_done = nullptr;
     const uint8_t* in = nullptr; uint8_t* out = nullptr;
@@ -37,14 +41,28 @@ struct PipeSlot {
 };
 
 // process-wide stream triple per device, created by the first pipe, destroyed with the last
-struct PipeStreams { hipStream_t h2d = nullptr, k = nullptr, d2h = nullptr; int users = 0; };
+struct PipeStreams {
+    hipStream_t h2d[2] = {nullptr, nullptr}, k = nullptr, d2h[2] = {nullptr, nullptr};
+    int users = 0;
+    hipStream_t* all(int i) { return i == 0 ? &h2d[0] : i == 1 ? &h2d[1] : i == 2 ? &k : i == 3 ? &d2h[0] : &d2h[1]; }
+};
 static std::mutex g_pipe_streams_mu;
 static PipeStreams g_pipe_streams[kMaxDevices];
+static std::atomic<uint32_t> g_pipe_lane[kMaxDevices];          // frames submitted on the device by ALL pipes: picks the copy lane
+// One frame's enqueue sequence (H2D, event, wait, kernels, event, wait, D2H, event) is issued under this per-device lock.  The
+// runtime dispatches directly from the calling thread and some of these calls block for tens of microseconds while holding the
+// stream's lock; two workers interleaving their calls on the shared streams call by call made EACH sequence slower (2 workers
+// 4650 frames/s against 5400 for one; with AMD_DIRECT_DISPATCH=0 -- submission from the runtime's own thread -- 5290).  Frame by
+// frame the streams see exactly the one-worker call pattern, while the workers' own work (UV half, staging copies, delivery,
+// waiting) still runs in parallel.
+static std::mutex g_pipe_submit_mu[kMaxDevices];
 
 struct mi_pipe {
     mi_ctx* c = nullptr;
     mi_pipe_config cfg{};
-    hipStream_t s_h2d = nullptr, s_k = nullptr, s_d2h = nullptr;
+    hipStream_t s_h2d[2] = {nullptr, nullptr}, s_k = nullptr, s_d2h[2] = {nullptr, nullptr};
+    int n_copy = 2;                                               // copy streams per direction in use (1 or 2)
+    bool private_streams = false;                                 // option "pipe_private_streams": this pipe owns its five streams
     std::vector<PipeSlot> slots;
     size_t head = 0, count = 0;
     size_t ybytes = 0, uvbytes = 0, xfer_in = 0, xfer_out = 0;
@@ -68,11 +86,27 @@ mi_status pipe_run_op(mi_pipe* p, PipeSlot& sl)
     return g.op == MI_OP_CLAHE ? clahe_dev(c, p->s_k, a, g.clip_limit, g.tiles_x, g.tiles_y, puv) : equalize_dev(c, p->s_k, a, puv);
 }
 
+// The runtime multiplexes HIP streams onto a few hardware queues (4 per priority level), and a hardware queue executes its
+// packets in order: the marker behind a 170 us device->host copy, sharing a hardware queue with the compute stream, holds the
+// next frame's kernels back until that copy is done (measured: a second worker's streams shifted the mapping and cost 14 %;
+// GPU_MAX_HW_QUEUES=16 restored it).  The runtime keeps a separate pool of hardware queues per stream priority, so the three
+// roles get three priorities: kernels high, uploads normal, downloads low -- a kernel packet can then never queue up behind a
+// copy's marker, whatever else the process has created.  (Priority only orders compute queues; copies go to the DMA engines.)
+hipError_t pipe_stream_create(hipStream_t* s, int role /* 0,1 upload lanes; 2 kernels; 3,4 download lanes */)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    int prio = role == 2 ? greatest : (role >= 3 ? least : (least + greatest) / 2);
+    if (const char* v = getenv("MI_LUMAEQ_PIPE_UPLOAD_PRIORITY")) { if (role < 2) prio = atoi(v) ? greatest : least; }
+    if (getenv("MI_LUMAEQ_PIPE_FLAT_PRIORITY")) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
+}
+
 void pipe_free(mi_pipe* p)
 {
     if (!p) return;
     (void)hipSetDevice(p->c->device);
-    for (hipStream_t s : {p->s_h2d, p->s_k, p->s_d2h}) if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : {p->s_h2d[0], p->s_h2d[1], p->s_k, p->s_d2h[0], p->s_d2h[1]}) if (s) (void)hipStreamSynchronize(s);
     for (auto& sl : p->slots) {
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_out) (void)hipFree(sl.d_out);
@@ -81,11 +115,13 @@ void pipe_free(mi_pipe* p)
         for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_done}) if (e) (void)hipEventDestroy(e);
     }
     if (p->h_hard) (void)hipHostFree(p->h_hard);
-    if (p->s_k) {
+    if (p->s_k && p->private_streams) {
+        for (hipStream_t s : {p->s_h2d[0], p->s_h2d[1], p->s_k, p->s_d2h[0], p->s_d2h[1]}) if (s) (void)hipStreamDestroy(s);
+    } else if (p->s_k) {
         std::lock_guard<std::mutex> lk(g_pipe_streams_mu);
         PipeStreams& ps = g_pipe_streams[p->c->device];
         if (--ps.users == 0) {
-            for (hipStream_t s : {ps.h2d, ps.k, ps.d2h}) if (s) (void)hipStreamDestroy(s);
+            for (int i = 0; i < 5; ++i) if (*ps.all(i)) (void)hipStreamDestroy(*ps.all(i));
             ps = PipeStreams{};
         }
     }
@@ -120,22 +156,36 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
     p->xfer_out = p->ybytes + (p->uv_dev ? p->uvbytes : 0);
     auto bail = [&](mi_status st) { pipe_free(p); return st; };
     if (c->device >= kMaxDevices) { fail(c, MI_ERR_UNSUPPORTED, "pipe: device index too large"); return bail(MI_ERR_UNSUPPORTED); }
-    {
+    p->private_streams = c->pipe_private_streams != 0;
+    if (p->private_streams) {
+        PipeStreams own;
+        for (int i = 0; i < 5; ++i) {
+            hipError_t e = pipe_stream_create(own.all(i), i);
+            if (e != hipSuccess) {
+                for (int q = 0; q < 5; ++q) if (*own.all(q)) (void)hipStreamDestroy(*own.all(q));
+                fail_hip(c, e, "hipStreamCreateWithFlags");
+                return bail(MI_ERR_HIP);
+            }
+        }
+        p->s_h2d[0] = own.h2d[0]; p->s_h2d[1] = own.h2d[1]; p->s_k = own.k; p->s_d2h[0] = own.d2h[0]; p->s_d2h[1] = own.d2h[1];
+        p->n_copy = c->pipe_copy_streams > 1 ? 2 : 1;
+    } else {
         std::lock_guard<std::mutex> lk(g_pipe_streams_mu);
         PipeStreams& ps = g_pipe_streams[c->device];
         if (ps.users == 0) {
-            for (hipStream_t* s : {&ps.h2d, &ps.k, &ps.d2h}) {
-                hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+            for (int i = 0; i < 5; ++i) {
+                hipError_t e = pipe_stream_create(ps.all(i), i);
                 if (e != hipSuccess) {
-                    for (hipStream_t q : {ps.h2d, ps.k, ps.d2h}) if (q) (void)hipStreamDestroy(q);
+                    for (int q = 0; q < 5; ++q) if (*ps.all(q)) (void)hipStreamDestroy(*ps.all(q));
                     ps = PipeStreams{};
-                    fail_hip(c, e, "hipStreamCreateWithFlags");
+                    fail_hip(c, e, "hipStreamCreateWithPriority");
                     return bail(MI_ERR_HIP);
                 }
             }
         }
         ++ps.users;
-        p->s_h2d = ps.h2d; p->s_k = ps.k; p->s_d2h = ps.d2h;
+        p->s_h2d[0] = ps.h2d[0]; p->s_h2d[1] = ps.h2d[1]; p->s_k = ps.k; p->s_d2h[0] = ps.d2h[0]; p->s_d2h[1] = ps.d2h[1];
+        p->n_copy = c->pipe_copy_streams > 1 ? 2 : 1;
     }
     p->slots.resize((size_t)p->cfg.depth);
     const size_t fbytes = p->ybytes + p->uvbytes;
@@ -168,16 +218,19 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
         if (e != hipSuccess) { fail_hip(c, e, "hipHostMalloc"); return bail(MI_ERR_HIP); }
         memset(pin, 128, wb);
         auto step = [&](hipError_t r, const char* what) { if (r != hipSuccess && e == hipSuccess) { e = r; fail_hip(c, r, what); } };
-        step(hipMemsetAsync(sl.d_in, 128, fbytes, p->s_h2d), "hipMemsetAsync");
-        step(hipMemcpyAsync(sl.d_in, pin, wb, hipMemcpyHostToDevice, p->s_h2d), "hipMemcpyAsync");
-        step(hipEventRecord(sl.ev_h2d, p->s_h2d), "hipEventRecord");
-        step(hipStreamWaitEvent(p->s_k, sl.ev_h2d, 0), "hipStreamWaitEvent");
-        mi_status st = e == hipSuccess ? pipe_run_op(p, sl) : MI_ERR_HIP;
-        if (st == MI_OK) {
-            step(hipEventRecord(sl.ev_k, p->s_k), "hipEventRecord");
-            step(hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0), "hipStreamWaitEvent");
-            step(hipMemcpyAsync(pin, sl.d_out, wb, hipMemcpyDeviceToHost, p->s_d2h), "hipMemcpyAsync");
-            step(hipStreamSynchronize(p->s_d2h), "hipStreamSynchronize");
+        mi_status st = MI_OK;
+        for (int lane = 0; lane < p->n_copy && st == MI_OK && e == hipSuccess; ++lane) {       // every stream a frame will travel on
+            step(hipMemsetAsync(sl.d_in, 128, fbytes, p->s_h2d[lane]), "hipMemsetAsync");
+            step(hipMemcpyAsync(sl.d_in, pin, wb, hipMemcpyHostToDevice, p->s_h2d[lane]), "hipMemcpyAsync");
+            step(hipEventRecord(sl.ev_h2d, p->s_h2d[lane]), "hipEventRecord");
+            step(hipStreamWaitEvent(p->s_k, sl.ev_h2d, 0), "hipStreamWaitEvent");
+            st = e == hipSuccess ? pipe_run_op(p, sl) : MI_ERR_HIP;
+            if (st == MI_OK) {
+                step(hipEventRecord(sl.ev_k, p->s_k), "hipEventRecord");
+                step(hipStreamWaitEvent(p->s_d2h[lane], sl.ev_k, 0), "hipStreamWaitEvent");
+                step(hipMemcpyAsync(pin, sl.d_out, wb, hipMemcpyDeviceToHost, p->s_d2h[lane]), "hipMemcpyAsync");
+                step(hipStreamSynchronize(p->s_d2h[lane]), "hipStreamSynchronize");
+            }
         }
         (void)hipStreamSynchronize(p->s_k);
         (void)hipHostFree(pin);
@@ -236,20 +289,25 @@ mi_status mi_pipe_submit(mi_pipe* p, const uint8_t* in, uint8_t* out, uint64_t t
         h2d_src = sl.h_in;
     }
     // from here on copies on caller memory are (about to be) in flight: every error exit waits for all three streams first
+    std::unique_lock<std::mutex> submit_lk(g_pipe_submit_mu[c->device], std::defer_lock);
+    if (!p->private_streams) submit_lk.lock();
+    // consecutive frames ON THE DEVICE (whichever pipe they come from) travel on alternate copy streams
+    sl.lane = p->n_copy > 1 ? (int)(g_pipe_lane[c->device].fetch_add(1, std::memory_order_relaxed) & 1) : 0;
+    hipStream_t s_h2d = p->s_h2d[sl.lane], s_d2h = p->s_d2h[sl.lane];
     StreamDrain drain(HipStreamSync{}, drain_counter(c));
-    drain.watch(p->s_h2d); drain.watch(p->s_k); drain.watch(p->s_d2h);
+    drain.watch(s_h2d); drain.watch(p->s_k); drain.watch(s_d2h);
     // a device-form call on a caller's stream since the last frame: the kernels share this context's scratch with it
     if (c->scratch_foreign) { HIPCHK(c, hipStreamWaitEvent(p->s_k, c->ev_scratch, 0)); c->scratch_foreign = false; }
-    HIPCHK(c, hipMemcpyAsync(sl.d_in, h2d_src, p->xfer_in, hipMemcpyHostToDevice, p->s_h2d));
-    HIPCHK(c, hipEventRecord(sl.ev_h2d, p->s_h2d));
+    HIPCHK(c, hipMemcpyAsync(sl.d_in, h2d_src, p->xfer_in, hipMemcpyHostToDevice, s_h2d));
+    HIPCHK(c, hipEventRecord(sl.ev_h2d, s_h2d));
     HIPCHK(c, hipStreamWaitEvent(p->s_k, sl.ev_h2d, 0));
     if ((st = pipe_run_op(p, sl))) return st;
     HIPCHK(c, hipEventRecord(sl.ev_k, p->s_k));
-    HIPCHK(c, hipStreamWaitEvent(p->s_d2h, sl.ev_k, 0));
-    HIPCHK(c, hipMemcpyAsync(sl.out_staged ? sl.h_out : out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, p->s_d2h));
+    HIPCHK(c, hipStreamWaitEvent(s_d2h, sl.ev_k, 0));
+    HIPCHK(c, hipMemcpyAsync(sl.out_staged ? sl.h_out : out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, s_d2h));
     if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)
-        HIPCHK(c, hipMemcpyAsync(p->h_hard + (&sl - p->slots.data()), c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_d2h));
-    HIPCHK(c, hipEventRecord(sl.ev_done, p->s_d2h));
+        HIPCHK(c, hipMemcpyAsync(p->h_hard + (&sl - p->slots.data()), c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s_d2h));
+    HIPCHK(c, hipEventRecord(sl.ev_done, s_d2h));
     drain.done();                                                 // success: the frame stays in flight, that is the point of a pipe
     ++p->count; ++p->submitted; ++c->pipe_pending;
     return MI_OK;
@@ -271,11 +329,22 @@ mi_status mi_pipe_wait(mi_pipe* p, uint64_t* tag, uint8_t** out_frame)
         else if (sl.out != sl.in) memmove(sl.out + p->ybytes, sl.in + p->ybytes, p->uvbytes);
     }
     mi_status st = MI_OK;
-    const hipError_t e = MI_HOOKED(c, hipEventSynchronize(sl.ev_done));
+    // Wait by polling hipEventQuery: hipEventSynchronize holds runtime locks while it blocks, and a second worker's enqueue calls on
+    // the same device then queue up behind it (2 workers 4600 frames/s against 5400 for one).
+    hipError_t e = hipSuccess;
+    if (getenv("MI_LUMAEQ_PIPE_WAIT_SYNC")) e = hipEventSynchronize(sl.ev_done);
+    else {
+        for (unsigned spins = 0;; ++spins) {
+            e = hipEventQuery(sl.ev_done);
+            if (e != hipErrorNotReady) break;
+            if (spins < 2000) __builtin_ia32_pause(); else std::this_thread::yield();
+        }
+    }
+    e = MI_HOOKED(c, e);
     if (e != hipSuccess) {
         // the frame is lost, but nothing may stay in flight on its buffers and the slot must not be handed out while a DMA is pending
         st = fail_hip(c, e, "hipEventSynchronize(frame done)");
-        for (hipStream_t s : {p->s_h2d, p->s_k, p->s_d2h}) (void)hipStreamSynchronize(s);
+        for (hipStream_t s : {p->s_h2d[sl.lane], p->s_k, p->s_d2h[sl.lane]}) (void)hipStreamSynchronize(s);
         ++c->error_drains;
     } else if (sl.out_staged) {
         CrewCall crew(c, p->xfer_out >= 4 * mi_host::CopyCrew::kMinBytes);

@@ -70,6 +70,7 @@ struct FusedJob {
     uint32_t* lutpub;                               // [cap][kLutPubWords] checksum carries the launch epoch
     uint32_t* sflag;                                // [n_frames * (T+U)]  ticket k done <=> sflag[k] == epoch (part of the same block)
     uint32_t* host_repaired;                        // pinned host word: "launches repaired" of this block, written by the finish kernel
+    uint32_t* host_hard;                            // pinned host word: "unrecoverable frames" of this block, likewise
 };
 
 // The three injected failures exist in libmi_lumaeq_test.so only (-DMI_TEST_HOOKS): the shipping kernel has no such branch.
@@ -361,6 +362,9 @@ __global__ __launch_bounds__(kThreads) void fused_finish_kernel(FusedJob j)
                 st_agent(stats + 3, status);
                 // the host decides about demoting the fused path from this word, without a copy or a synchronisation
                 if (j.host_repaired) __hip_atomic_store(j.host_repaired, repaired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // every workgroup's count of refused frames was added before it arrived here (the barrier above drains its atomics)
+                const uint32_t hard = __hip_atomic_load(stats + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j.host_hard && hard) __hip_atomic_store(j.host_hard, hard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             st_agent(j.ctl + kFusedStatus, 0u);
             st_agent(j.ctl + kFusedWork, 0u); st_agent(j.ctl + kFusedWork + 1, 0u);

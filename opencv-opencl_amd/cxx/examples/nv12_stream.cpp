@@ -13,7 +13,8 @@
 // its GPU), --uv-policy host|device (who writes the UV half), --no-pin (leave the frame ring pageable; by default it is registered
 // once, the way a GstBufferPool's memory would be), --loop (rewind --input at its end: clahevideo.cpp:294-302), --dump-every K
 // (write only every K-th delivered frame to --output), --no-numa-bind (do not bind each worker to the CPUs of its GPU's NUMA node;
-// the binding is printed in the banner).  --workers may exceed the GPU count (worker w -> GPU w mod N), up to 64.
+// the binding is printed in the banner), --max-workers-per-gpu K (default 2; 0 = no cap).  --workers may exceed the GPU count
+// (worker w -> GPU w mod N), up to 64; at most K of them are started per GPU.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -36,7 +37,7 @@ static bool kv(const char* arg, const char* key, std::string& v, int& i, int arg
 int main(int argc, char** argv)
 {
     using namespace micv;
-    int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8, depth = 4;
+    int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8, depth = 4, per_gpu = 2;
     double clip = 2.0;
     bool paced = false, pin = true, loop = false, numa_bind = true;
     int dump_every = 1;
@@ -60,6 +61,7 @@ int main(int argc, char** argv)
         else if (strcmp(argv[i], "--no-pin") == 0) pin = false;
         else if (strcmp(argv[i], "--loop") == 0) loop = true;
         else if (strcmp(argv[i], "--no-numa-bind") == 0) numa_bind = false;
+        else if (kv(argv[i], "max-workers-per-gpu", v, i, argc, argv)) per_gpu = atoi(v.c_str());    // 0 = no cap (measurements only)
         else if (kv(argv[i], "dump-every", v, i, argc, argv)) dump_every = std::max(1, atoi(v.c_str()));
         else fprintf(stderr, "Warning: ignoring unknown arg: %s\n", argv[i]);
     }
@@ -102,9 +104,11 @@ int main(int argc, char** argv)
                            delivered.fetch_add(1);
                        },
                        clip, Size(tile, tile), ring / (size_t)workers > 2 ? ring / (size_t)workers - 1 : 1, depth,
-                       uv_policy == "device" ? MI_PIPE_UV_DEVICE : MI_PIPE_UV_HOST, numa_bind);
+                       uv_policy == "device" ? MI_PIPE_UV_DEVICE : MI_PIPE_UV_HOST, numa_bind, per_gpu);
         printf("nv12_stream: %dx%d %s uv=%s (uv-policy %s) workers=%d depth=%d gpus=%d frames=%d%s%s\n", width, height, op.c_str(), uv.c_str(),
-               uv_policy.c_str(), workers, depth, getDeviceCount(), frames, paced ? " paced" : "", pin ? " pinned-ring" : " pageable-ring");
+               uv_policy.c_str(), pool.workers(), depth, getDeviceCount(), frames, paced ? " paced" : "", pin ? " pinned-ring" : " pageable-ring");
+        if (pool.workers() != pool.requested())
+            printf("workers: %d requested, %d started (at most %d per GPU: more only add contention on the copy engines)\n", pool.requested(), pool.workers(), per_gpu);
         printf("placement: %s\n", main_placement.c_str());
         for (const std::string& line : pool.placement()) printf("placement: %s\n", line.c_str());
         // synthetic source: the ring's frames exist before the clock starts (a camera / decoder hands over finished frames;
@@ -141,6 +145,12 @@ int main(int argc, char** argv)
         printf("done: %llu frames in %.3f s = %.1f frames/s (host NV12 in -> host NV12 out, PCIe inclusive), errors=%llu\n",
                (unsigned long long)pool.stats().frames_out.load(), el, pool.stats().frames_out.load() / el,
                (unsigned long long)pool.stats().processing_errors.load());
+        {
+            const double n = (double)std::max<uint64_t>(1, pool.stats().frames_out.load());
+            printf("worker time per frame (us, summed over %d worker(s)): submit %.1f, wait %.1f, deliver %.1f, idle %.1f\n", pool.workers(),
+                   pool.stats().ns_submit.load() / n / 1e3, pool.stats().ns_wait.load() / n / 1e3, pool.stats().ns_deliver.load() / n / 1e3,
+                   pool.stats().ns_idle.load() / n / 1e3);
+        }
         // submit -> in-order delivery latency (the reference only prints averages: clahevideo.cpp:54-84)
         std::vector<float> lat;
         for (int k = 0; k < frames; ++k) if (latency_ms[k] >= 0.f) lat.push_back(latency_ms[k]);

@@ -19,6 +19,7 @@
 #define MI_POOL_HPP_
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -35,6 +36,9 @@ namespace micv {
 
 struct PoolStats {                       // the counters of OpenCVequalHist.cpp:20-30 / :200-234
     std::atomic<uint64_t> frames_in{0}, frames_out{0}, processing_errors{0};
+    // where the workers' time goes, summed over all workers, in nanoseconds (the reference prints per-stage averages the same way:
+    // clahevideo.cpp:54-84 "CLAHE / memory / total")
+    std::atomic<uint64_t> ns_submit{0}, ns_wait{0}, ns_deliver{0}, ns_idle{0};
 };
 
 struct FrameJob {
@@ -53,7 +57,7 @@ public:
     // depth: frames a worker keeps in flight on its GPU (2..16); uv_policy: MI_PIPE_UV_AUTO / _HOST / _DEVICE (mi_lumaeq.h)
     FramePool(int workers, int width, int height, Op op, UVMode uv, Sink sink,
               double clip = 2.0, Size tiles = Size(8, 8), size_t max_queue = 16, int depth = 4, int uv_policy = MI_PIPE_UV_AUTO,
-              bool numa_bind = true)
+              bool numa_bind = true, int max_workers_per_gpu = 2)
         : width_(width), height_(height), op_(op), uv_(uv), clip_(clip), tiles_(tiles), sink_(std::move(sink)), max_queue_(max_queue),
           depth_(depth < 2 ? 2 : (depth > 16 ? 16 : depth)), uv_policy_(uv_policy), numa_bind_(numa_bind)
     {
@@ -61,6 +65,13 @@ public:
         if (workers > 64) workers = 64;
         const int ndev = getDeviceCount();
         if (ndev <= 0) MI_CV_ERROR(GpuNotSupported, "no HIP device (this backend has no CPU fallback)");
+        // The reference's --workers N buys CPU parallelism (OpenCVequalHist.cpp:397-402).  Here a worker only feeds a GPU, and ONE
+        // worker already keeps a GPU's copy engines ~95 % busy (5.4 k 4K frames/s); two are no slower; four on one GPU were measured
+        // at 2.4 k frames/s -- sixteen frames in flight make the runtime spread the copies over more DMA engines, and single
+        // transfers then take 4x as long (profiles/r03_c_nv12_stream_workers.txt).  So at most `max_workers_per_gpu` workers are
+        // started per GPU; requested() still reports what was asked for.
+        requested_ = workers;
+        if (max_workers_per_gpu >= 1 && workers > ndev * max_workers_per_gpu) workers = ndev * max_workers_per_gpu;
         queues_.resize(workers);
         placement_.resize(workers);
         for (int w = 0; w < workers; ++w) threads_.emplace_back([this, w, ndev] { run(w, w % ndev); });
@@ -71,7 +82,8 @@ public:
     }
     ~FramePool() { finish(); }
 
-    int workers() const { return (int)threads_.size(); }
+    int workers() const { return (int)threads_.size(); }        // workers actually started (<= max_workers_per_gpu per GPU)
+    int requested() const { return requested_; }
     // one line per worker: which GPU, which NUMA node, how many CPUs it was bound to (valid once the constructor has returned)
     std::vector<std::string> placement() const { std::lock_guard<std::mutex> lk(mu_); return placement_; }
     const PoolStats& stats() const { return stats_; }
@@ -140,10 +152,13 @@ private:
             cv_done_.notify_all();
         }
         std::deque<FrameJob> inflight;                          // submitted to the pipe, oldest first
+        using clk = std::chrono::steady_clock;
+        auto since = [](clk::time_point t) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t).count(); };
         for (;;) {
             FrameJob j;
             bool have = false;
             {
+                const auto t_idle = clk::now();
                 std::unique_lock<std::mutex> lk(mu_);
                 if (inflight.empty()) cv_work_.wait(lk, [&] { return !queues_[w].empty() || stop_; });
                 if (!queues_[w].empty() && (int)inflight.size() < depth_) {
@@ -154,9 +169,12 @@ private:
                 } else if (inflight.empty()) {
                     break;                                      // stopped and drained
                 }
+                stats_.ns_idle.fetch_add(since(t_idle), std::memory_order_relaxed);
             }
             if (have) {                                         // keep the pipe full before waiting for anything
+                const auto t_sub = clk::now();
                 mi_status st = pipe ? mi_pipe_submit(pipe, j.in, j.out, j.index) : MI_ERR_HIP;
+                stats_.ns_submit.fetch_add(since(t_sub), std::memory_order_relaxed);
                 if (st == MI_OK) { inflight.push_back(j); continue; }
                 j.ok = false;                                   // per-frame drop-and-count, OpenCVequalHist.cpp:189-193
                 j.error = pipe ? std::string("mi_pipe_submit: ") + mi_status_str(st) + " (" + mi_ctx_last_error_msg(c) + ")" : pipe_error;
@@ -167,13 +185,17 @@ private:
             FrameJob d = inflight.front();                      // pipe full, or nothing new to submit: complete the oldest frame
             inflight.pop_front();
             uint64_t tag = 0;
+            const auto t_wait = clk::now();
             const mi_status st = mi_pipe_wait(pipe, &tag, nullptr);
+            stats_.ns_wait.fetch_add(since(t_wait), std::memory_order_relaxed);
             d.ok = st == MI_OK && tag == d.index;
             if (!d.ok) {
                 d.error = std::string("mi_pipe_wait: ") + mi_status_str(st) + " (" + mi_ctx_last_error_msg(c) + ")";
                 stats_.processing_errors.fetch_add(1, std::memory_order_relaxed);
             }
+            const auto t_del = clk::now();
             deliver(d);
+            stats_.ns_deliver.fetch_add(since(t_del), std::memory_order_relaxed);
         }
         if (pipe) mi_pipe_destroy(pipe);
     }
@@ -208,6 +230,7 @@ private:
     size_t max_queue_;
     int depth_, uv_policy_;
     bool numa_bind_;
+    int requested_ = 0;
     std::vector<std::string> placement_;
     mutable std::mutex mu_;
     std::condition_variable cv_work_, cv_space_, cv_done_;

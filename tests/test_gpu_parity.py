@@ -5,7 +5,7 @@ import pytest
 
 import mi_lumaeq
 import oracle
-from mi_lumaeq import synth
+from mi_lumaeq import synth, xfer
 
 pytestmark = pytest.mark.gpu
 
@@ -15,7 +15,11 @@ SMALL = [(1, 1), (1, 17), (3, 4097), (47, 63), (48, 64), (15, 16), (135, 241), (
 
 
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    """host array -> device tensor WITHOUT handing pageable memory to the runtime (mi_lumaeq.xfer says why)"""
+    return xfer.to_device(a)
+
+
+host = xfer.to_host                                     # device tensor -> numpy, likewise through pinned staging
 
 
 def hooks_ctx():
@@ -95,7 +99,7 @@ def test_equalize_roi_views_by_pitch(ctx, pitch):
         ctx.equalize_hist_batch_dev(d_src.data_ptr() + so, d_dst.data_ptr() + do, w, h, n, src_step=pitch, src_frame=(h + 6) * pitch,
                                     dst_step=dpitch, dst_frame=(h + 6) * dpitch)
         ctx.synchronize()
-        out = d_dst.cpu().numpy()
+        out = host(d_dst)
         for k in range(n):
             want = oracle.equalize_hist(src[k, 2:2 + h, 29:29 + w])
             assert np.array_equal(out[k, 3:3 + h, 7:7 + w], want), (pitch, dpitch, k)
@@ -164,7 +168,7 @@ def test_analyze_diff_batch_dev_is_how_full_size_batches_are_compared(ctx):
     stats = torch.full((n, 4), 0xFFFFFFFF, dtype=torch.int64, device="cuda:0").to(torch.int32)
     ctx.analyze_diff_batch_dev(fused, staged, w, h * 3 // 2, n, stats, threshold=1, a_frame=fb, b_frame=fb)
     torch.cuda.synchronize()
-    s = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    s = host(stats).astype(np.int64) & 0xFFFFFFFF
     assert (s[:, 0] == 0).all() and (s[:, 1] == 0).all() and (s[:, 2] == 0).all() and (s[:, 3] == fb).all()
     staged[3, 12345] = fused[3, 12345] ^ 1                                  # within the reference's tolerance: seen by max_diff, not by `above`
     v = int(fused[9, 777])
@@ -172,7 +176,7 @@ def test_analyze_diff_batch_dev_is_how_full_size_batches_are_compared(ctx):
     diff = torch.empty_like(d_in)
     ctx.analyze_diff_batch_dev(fused, staged, w, h * 3 // 2, n, stats, threshold=1, diff=diff, a_frame=fb, b_frame=fb, diff_frame=fb)
     torch.cuda.synchronize()
-    s = stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    s = host(stats).astype(np.int64) & 0xFFFFFFFF
     assert s[3].tolist() == [0, 1, 0, fb] and s[9].tolist() == [1, 2, 0, fb]
     assert s[[i for i in range(n) if i not in (3, 9)], :3].sum() == 0
     assert int(diff[3, 12345]) == 1 and int(diff[9, 777]) == 2 and int(diff.sum()) == 3
@@ -190,7 +194,7 @@ def test_stage_apis(ctx):
     d_dst = torch.empty_like(d_src)
     ctx.lut_apply_batch_dev(d_src, d_dst, w, h, n, d_lut)
     torch.cuda.synchronize()
-    hist, lut, dst = d_hist.cpu().numpy(), d_lut.cpu().numpy(), d_dst.cpu().numpy()
+    hist, lut, dst = host(d_hist), host(d_lut), host(d_dst)
     for k in range(n):
         oh = oracle.hist(ys[k])
         assert np.array_equal(hist[k], oh)
@@ -207,13 +211,13 @@ def test_nv12_batch_dev(ctx, uv_mode):
     d_out = torch.empty_like(d_in)
     ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    out = d_out.cpu().numpy()
+    out = host(d_out)
     for k in range(n):
         assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), k
     # in place
     ctx.equalize_hist_nv12_batch_dev(d_in, d_in, w, h, n, uv_mode, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert np.array_equal(d_in.cpu().numpy(), out)
+    assert np.array_equal(host(d_in), out)
 
 
 def test_nv12_host_form(ctx):
@@ -260,7 +264,7 @@ def test_clahe_wide_tile_grids(ctx, case):
             d_out = torch.zeros_like(d_in)
             ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, 3, mi_lumaeq.UV_COPY, 3.0, tx, ty)
             ctx.synchronize()
-            out = d_out.cpu().numpy()
+            out = host(d_out)
             for k in range(3):
                 assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=1, op=1, clip_limit=3.0, tiles_x=tx, tiles_y=ty)), (case, k)
     finally:
@@ -284,7 +288,7 @@ def test_clahe_tile_luts_stage(ctx):
         d_luts = torch.zeros((tx * ty, 256), dtype=torch.uint8, device="cuda:0")
         ctx.clahe_tile_luts_batch_dev(dev(src), w, h, 1, clip, tx, ty, d_luts)
         torch.cuda.synchronize()
-        assert np.array_equal(d_luts.cpu().numpy(), oracle.clahe_tile_luts(src, clip, tx, ty)), (w, h, tx, ty)
+        assert np.array_equal(host(d_luts), oracle.clahe_tile_luts(src, clip, tx, ty)), (w, h, tx, ty)
 
 
 @pytest.mark.parametrize("wh,cfg", [((3840, 2160), (2.0, 8, 8)), ((1920, 1080), (2.0, 8, 8)), ((1919, 1079), (3.0, 4, 4)),
@@ -309,7 +313,7 @@ def test_clahe_strided_and_batch(ctx):
     d_out = torch.empty_like(d_in)
     ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 1, 2.0, 8, 8, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    out = d_out.cpu().numpy()
+    out = host(d_out)
     for k in range(n):
         assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=1, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8)), k
 
@@ -339,7 +343,7 @@ def test_full_size_batch_properties(ctx):
         nzv = torch.nonzero(hi).view(-1)
         assert (torch.diff(lut[nzv]) >= 0).all() and int(lut[first]) == 0
     k = 5
-    assert np.array_equal(d_out[k].cpu().numpy(), oracle.nv12_frame(d_in[k].cpu().numpy(), w, h, uv_mode=1, op=0))
+    assert np.array_equal(host(d_out[k]), oracle.nv12_frame(host(d_in[k]), w, h, uv_mode=1, op=0))
 
 
 def test_profiling_counters(ctx):
@@ -386,7 +390,7 @@ def test_equalize_paths_agree(ctx, opts):
                 d_out = torch.zeros_like(d_in)
                 ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode)
                 ctx.synchronize()
-                out = d_out.cpu().numpy()
+                out = host(d_out)
                 for k in range(n):
                     assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), (w, h, k, uv_mode)
     finally:
@@ -488,17 +492,17 @@ def test_unaligned_device_batches(ctx):
     fb = frames.shape[1]
     pad = torch.zeros(n * fb + 5, dtype=torch.uint8, device="cuda:0")
     d_in = pad[3:3 + n * fb]                                      # misaligned base
-    d_in.copy_(torch.from_numpy(frames.reshape(-1)))
+    d_in.copy_(dev(frames.reshape(-1)))
     d_out = torch.zeros(n * fb + 7, dtype=torch.uint8, device="cuda:0")[7:]
     for uv_mode in (0, 1):
         ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode)
         ctx.synchronize()
-        out = d_out.cpu().numpy().reshape(n, fb)
+        out = host(d_out).reshape(n, fb)
         for k in range(n):
             assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), (k, uv_mode)
         ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode, 2.0, 8, 8)
         ctx.synchronize()
-        out = d_out.cpu().numpy().reshape(n, fb)
+        out = host(d_out).reshape(n, fb)
         for k in range(n):
             assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8)), (k, uv_mode)
 
@@ -536,12 +540,12 @@ def test_color_strided_and_batch(ctx):
     d_out = torch.empty_like(d_in)
     ctx.bgr_luma_op_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.OP_EQUALIZE)
     ctx.synchronize()
-    out = d_out.cpu().numpy()
+    out = host(d_out)
     for k in range(n):
         assert np.array_equal(out[k], oracle.bgr_luma_op(frames[k], 0)), k
     ctx.cvt_color_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.COLOR_BGR2YUV)
     ctx.synchronize()
-    out = d_out.cpu().numpy()
+    out = host(d_out)
     for k in range(n):
         assert np.array_equal(out[k], oracle.bgr2yuv(frames[k])), k
     with pytest.raises(mi_lumaeq.MiError):
@@ -586,13 +590,13 @@ def test_randomized_differential(ctx):
         uv_mode = int(rng.integers(0, 2))
         ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode)
         ctx.synchronize()
-        out = d_out.cpu().numpy()
+        out = host(d_out)
         for k in range(n):
             assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), ("nv12", case, w, h, k)
         tx = int(rng.integers(1, 12)); ty = int(rng.integers(1, 12))
         ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, uv_mode, 2.0, tx, ty)
         ctx.synchronize()
-        out = d_out.cpu().numpy()
+        out = host(d_out)
         for k in range(n):
             assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=1, clip_limit=2.0, tiles_x=tx, tiles_y=ty)), ("nv12-clahe", case, w, h, k)
 
@@ -611,7 +615,7 @@ def test_many_contexts_share_one_gpu():
         for c in ctxs:
             c.synchronize(mi_lumaeq.STREAM_CTX)
         for o in outs:
-            got = o.cpu().numpy()
+            got = host(o)
             for k in range(n):
                 assert np.array_equal(got[k], want[k])
     finally:
@@ -665,19 +669,19 @@ def test_hip_graph_capture_and_replay():
             d_out.zero_()
             g.replay()
             torch.cuda.synchronize()
-            src, out = d_in.cpu().numpy(), d_out.cpu().numpy()
+            src, out = host(d_in), host(d_out)
             for k in range(n):
                 assert np.array_equal(out[k], oracle.nv12_frame(src[k], w, h, uv_mode=1, op=0)), (rep, k)
         # eager calls on the same context keep working after replays
         c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
         c.synchronize()
-        assert np.array_equal(d_out[0].cpu().numpy(), oracle.nv12_frame(d_in[0].cpu().numpy(), w, h, uv_mode=0, op=0))
+        assert np.array_equal(host(d_out[0]), oracle.nv12_frame(host(d_in[0]), w, h, uv_mode=0, op=0))
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2):
             c.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 0, 2.0, 8, 8, stream=torch.cuda.current_stream().cuda_stream)
         g2.replay()
         torch.cuda.synchronize()
-        assert np.array_equal(d_out[1].cpu().numpy(), oracle.nv12_frame(d_in[1].cpu().numpy(), w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
+        assert np.array_equal(host(d_out[1]), oracle.nv12_frame(host(d_in[1]), w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
         # destroy the graphs while the context (whose scratch their kernel nodes point at) is still alive
         del g, g2
         torch.cuda.synchronize()
@@ -713,7 +717,7 @@ def test_fused_bounded_wait_expiry_is_repaired_on_device(mode, in_place):
         c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()                                   # the caller's own synchronisation: no library call needed
         assert time.perf_counter() - t0 < 5.0                      # bounded: the grid drained
-        out = d_out.cpu().numpy()
+        out = host(d_out)
         for k in range(n):
             assert np.array_equal(out[k], want[k]), (mode, in_place, k)
         c.synchronize()                                            # ... and the library reports no error either
@@ -726,7 +730,7 @@ def test_fused_bounded_wait_expiry_is_repaired_on_device(mode, in_place):
         d_out2 = torch.zeros_like(d_in2)
         c.equalize_hist_nv12_batch_dev(d_in2, d_out2, w, h, n, 1)
         c.synchronize()
-        out = d_out2.cpu().numpy()
+        out = host(d_out2)
         for k in range(n):
             assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=1, op=0)), k
         assert _stats(c)["fallbacks"] == 1                         # sticky, and not re-triggered
@@ -764,7 +768,7 @@ def test_fused_repair_under_naturally_expiring_waits(in_place):
                 d_out = d_in if in_place else torch.zeros_like(d_in)
                 c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, uv)
                 c.synchronize()
-                out = d_out.cpu().numpy()
+                out = host(d_out)
                 for k in range(n):
                     assert np.array_equal(out[k], want[uv][k]), (us, rep, k)
             fb = c.get_stat("fused_fallbacks")
@@ -776,7 +780,7 @@ def test_fused_repair_under_naturally_expiring_waits(in_place):
         c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
         c.synchronize()
         assert c.get_stat("fused_fallbacks") == total_fallbacks
-        assert np.array_equal(d_out[n - 1].cpu().numpy(), want[0][n - 1])
+        assert np.array_equal(host(d_out[n - 1]), want[0][n - 1])
     finally:
         c.close()
 
@@ -796,7 +800,7 @@ def test_fused_failure_statistics_survive_later_launches_and_block_growth():
             c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, 4, 0)
         c.synchronize()
         assert _stats(c)["fallbacks"] == 1
-        out = d_out.cpu().numpy()
+        out = host(d_out)
         for k in range(4):
             assert np.array_equal(out[k], oracle.nv12_frame(f4[k], w, h, uv_mode=0, op=0)), k
         n_big = 130                                                # > the block's initial capacity of 64 frames
@@ -805,7 +809,7 @@ def test_fused_failure_statistics_survive_later_launches_and_block_growth():
         c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n_big, 1)
         c.synchronize()
         assert _stats(c)["fallbacks"] == 1 and _stats(c)["hard_errors"] == 0
-        out = d_out.cpu().numpy()
+        out = host(d_out)
         for k in (0, 63, 64, 129):
             assert np.array_equal(out[k], oracle.nv12_frame(big[k], w, h, uv_mode=1, op=0)), k
     finally:
@@ -833,7 +837,7 @@ def test_fused_failure_inside_a_replayed_graph():
             d_out.zero_()
             g.replay()
             torch.cuda.synchronize()
-            src, out = d_in.cpu().numpy(), d_out.cpu().numpy()
+            src, out = host(d_in), host(d_out)
             for k in range(n):
                 assert np.array_equal(out[k], oracle.nv12_frame(src[k], w, h, uv_mode=0, op=0)), (rep, k)
         assert _stats(c)["fallbacks"] == 3
@@ -843,11 +847,11 @@ def test_fused_failure_inside_a_replayed_graph():
         e_out = torch.zeros_like(e_in)
         c.equalize_hist_nv12_batch_dev(e_in, e_out, w, h, n2, 1)
         c.synchronize()
-        assert np.array_equal(e_out[n2 - 1].cpu().numpy(), oracle.nv12_frame(e_in[n2 - 1].cpu().numpy(), w, h, uv_mode=1, op=0))
+        assert np.array_equal(host(e_out[n2 - 1]), oracle.nv12_frame(host(e_in[n2 - 1]), w, h, uv_mode=1, op=0))
         d_out.zero_()
         g.replay()
         torch.cuda.synchronize()
-        assert np.array_equal(d_out[1].cpu().numpy(), oracle.nv12_frame(d_in[1].cpu().numpy(), w, h, uv_mode=0, op=0))
+        assert np.array_equal(host(d_out[1]), oracle.nv12_frame(host(d_in[1]), w, h, uv_mode=0, op=0))
         # growth INSIDE a capture is refused, loudly, instead of corrupting the capture
         n3 = 200
         f_in = synth.nv12_batch_torch(w, h, n3, "D1", "cuda:0", seed=10)
@@ -901,29 +905,29 @@ def test_clahe16_value_ranges(ctx, cfg):
     odd = rng.integers(700, 3000, (271, 479), dtype=np.uint16)                                        # padded tiles, unaligned rows
     assert np.array_equal(ctx.clahe16(odd, clip, tx, ty), oracle.clahe16(odd, clip, tx, ty))
     batch = np.stack(frames)
-    d_in = torch.from_numpy(batch.view(np.int16)).to("cuda:0")
+    d_in = dev(batch.view(np.int16))
     d_out = torch.empty_like(d_in)
     ctx.clahe16_batch_dev(d_in, d_out, w, h, len(frames), clip, tx, ty)
     ctx.synchronize()
-    out = d_out.cpu().numpy().view(np.uint16)
+    out = host(d_out).view(np.uint16)
     for k, s in enumerate(frames):
         assert np.array_equal(out[k], oracle.clahe16(s, clip, tx, ty)), (cfg, "batch", k)
     # in place
-    d = torch.from_numpy(batch.view(np.int16)).to("cuda:0")
+    d = dev(batch.view(np.int16))
     ctx.clahe16_batch_dev(d, d, w, h, len(frames), clip, tx, ty)
     ctx.synchronize()
-    assert np.array_equal(d.cpu().numpy().view(np.uint16), out)
+    assert np.array_equal(host(d).view(np.uint16), out)
 
 
 def test_clahe16_batch_and_errors(ctx):
     w, h, n = 320, 180, 3
     rng = np.random.default_rng(3)
     frames = rng.integers(0, 65536, (n, h, w), dtype=np.uint16)
-    d_in = torch.from_numpy(frames.view(np.int16)).to("cuda:0")
+    d_in = dev(frames.view(np.int16))
     d_out = torch.empty_like(d_in)
     ctx.clahe16_batch_dev(d_in, d_out, w, h, n, 2.0, 8, 8)
     ctx.synchronize()
-    out = d_out.cpu().numpy().view(np.uint16)
+    out = host(d_out).view(np.uint16)
     for k in range(n):
         assert np.array_equal(out[k], oracle.clahe16(frames[k], 2.0, 8, 8)), k
     # both LUT layouts of the interpolation (value-major is an option for <= 64 tiles) and a grid too large for it
@@ -957,7 +961,7 @@ def test_more_frames_than_grid_limit(ctx):
             d_out = torch.zeros_like(d_in)
             ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 1)
             ctx.synchronize()
-            out = d_out.cpu().numpy()
+            out = host(d_out)
             for k in check:
                 assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=1, op=0)), (fused, k)
             # every frame: compare against a vectorised numpy equalize of all 70k frames
@@ -967,7 +971,7 @@ def test_more_frames_than_grid_limit(ctx):
         d_out = torch.zeros_like(d_in)
         ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 0, 2.0, 2, 2)
         ctx.synchronize()
-        out = d_out.cpu().numpy()
+        out = host(d_out)
         for k in check:
             assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=2, tiles_y=2)), k
     finally:
@@ -994,11 +998,11 @@ def test_bgr_luma_paths_agree(ctx):
                 assert np.array_equal(ctx.bgr_luma_op(a, mi_lumaeq.OP_CLAHE, clip, tx, ty), oracle.bgr_luma_op(a, 1, clip, tx, ty)), (fused, h, w, tx, ty)
             inplace = _bgr(640, 360, 42)
             want = oracle.bgr_luma_op(inplace, 1, 2.0, 4, 4)
-            d = torch.from_numpy(np.stack([inplace, _bgr(640, 360, 43)])).cuda()
+            d = dev(np.stack([inplace, _bgr(640, 360, 43)]))
             ctx.bgr_luma_op_batch_dev(d, d, 640, 360, 2, mi_lumaeq.OP_CLAHE, 2.0, 4, 4)       # batch, in place on the device
             torch.cuda.synchronize()
-            assert np.array_equal(d[0].cpu().numpy(), want), fused
-            assert np.array_equal(d[1].cpu().numpy(), oracle.bgr_luma_op(_bgr(640, 360, 43), 1, 2.0, 4, 4)), fused
+            assert np.array_equal(host(d[0]), want), fused
+            assert np.array_equal(host(d[1]), oracle.bgr_luma_op(_bgr(640, 360, 43), 1, 2.0, 4, 4)), fused
     finally:
         ctx.set_option("bgr_fused", 1)
 
@@ -1030,11 +1034,11 @@ def test_nv12_bgr_channel_equalize_batch_and_errors(ctx):
     import torch
     w, h, n = 320, 180, 5
     a = _nv12_frames(w, h, n, 5)
-    d_in = torch.from_numpy(a).cuda()
+    d_in = dev(a)
     d_out = torch.empty_like(d_in)
     ctx.nv12_bgr_equalize_batch_dev(d_in, d_out, w, h, n)
     torch.cuda.synchronize()
-    got = d_out.cpu().numpy()
+    got = host(d_out)
     for k in range(n):
         assert np.array_equal(got[k], oracle.nv12_bgr_equalize(a[k], w, h)), k
     # unaligned frame base (vector path must not be taken): frames start 1 byte into the buffer
@@ -1042,22 +1046,22 @@ def test_nv12_bgr_channel_equalize_batch_and_errors(ctx):
     fb = w2 * h2 * 3 // 2
     a2 = _nv12_frames(w2, h2, 3, 6)
     raw = torch.zeros(3 * fb + 1, dtype=torch.uint8, device="cuda")
-    raw[1:] = torch.from_numpy(a2.reshape(-1)).cuda()
+    raw[1:] = dev(a2.reshape(-1))
     out2 = torch.zeros_like(raw)
     torch.cuda.synchronize()
     ctx.nv12_bgr_equalize_batch_dev(raw.data_ptr() + 1, out2.data_ptr() + 1, w2, h2, 3)
     torch.cuda.synchronize()
-    got2 = out2[1:].cpu().numpy().reshape(3, fb)
+    got2 = host(out2[1:]).reshape(3, fb)
     for k in range(3):
         assert np.array_equal(got2[k], oracle.nv12_bgr_equalize(a2[k], w2, h2)), k
     assert int(out2[0]) == 0
     # full-size frame: every channel of the decoded output is an equalized plane -> idempotence is not exact in 4:2:0,
     # so check against the oracle on one 4K frame
     a4 = _nv12_frames(3840, 2160, 1, 8, True)
-    d4 = torch.from_numpy(a4).cuda()
+    d4 = dev(a4)
     ctx.nv12_bgr_equalize_batch_dev(d4, d4, 3840, 2160, 1)
     torch.cuda.synchronize()
-    assert np.array_equal(d4.cpu().numpy()[0], oracle.nv12_bgr_equalize(a4[0], 3840, 2160))
+    assert np.array_equal(host(d4)[0], oracle.nv12_bgr_equalize(a4[0], 3840, 2160))
     # errors: odd sizes, null pointers; empty is a no-op
     with pytest.raises(mi_lumaeq.MiError):
         ctx.nv12_bgr_equalize(np.zeros(3 * 2 * 3 // 2, np.uint8), 3, 2)
@@ -1085,16 +1089,16 @@ def test_cvt_color_420_codes(ctx, size):
     assert np.array_equal(outbig[1:h * 3 // 2 + 1, 3:w + 3], want_i420) and outbig[0].sum() == 0 and outbig[:, :3].sum() == 0
     # device batch
     n = 3
-    d_bgr = torch.from_numpy(np.stack([_bgr(w, h, 80 + k) for k in range(n)])).cuda()
+    d_bgr = dev(np.stack([_bgr(w, h, 80 + k) for k in range(n)]))
     d_pl = torch.empty((n, h * 3 // 2, w), dtype=torch.uint8, device="cuda")
     ctx.cvt_color_420_batch_dev(d_bgr, d_pl, w, h, n, mi_lumaeq.COLOR_BGR2YUV_I420)
-    d_nv = torch.from_numpy(_nv12_frames(w, h, n, 90)).cuda()
+    d_nv = dev(_nv12_frames(w, h, n, 90))
     d_out = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
     ctx.cvt_color_420_batch_dev(d_nv, d_out, w, h, n, mi_lumaeq.COLOR_YUV2BGR_NV12)
     torch.cuda.synchronize()
     for k in range(n):
-        assert np.array_equal(d_pl[k].cpu().numpy(), oracle.bgr_to_i420(d_bgr[k].cpu().numpy())), k
-        assert np.array_equal(d_out[k].cpu().numpy(), oracle.nv12_to_bgr(d_nv[k].cpu().numpy(), w, h)), k
+        assert np.array_equal(host(d_pl[k]), oracle.bgr_to_i420(host(d_bgr[k]))), k
+        assert np.array_equal(host(d_out[k]), oracle.nv12_to_bgr(host(d_nv[k]), w, h)), k
 
 
 def test_cvt_color_420_errors(ctx):
@@ -1125,25 +1129,25 @@ def test_photo_like_scene(ctx):
     for k in range(n):
         frames[k, : w * h] = big[37 * k: 37 * k + h, 91 * k: 91 * k + w].reshape(-1)
         frames[k, w * h:] = np.random.default_rng(k).integers(0, 256, w * h // 2, dtype=np.uint8)
-    d_in = torch.from_numpy(frames).cuda()
+    d_in = dev(frames)
     d_out = torch.empty_like(d_in)
     ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.UV_COPY)
     ctx.synchronize()
-    got = d_out.cpu().numpy()
+    got = host(d_out)
     for k in range(n):
         yk = frames[k, : w * h].reshape(h, w)
         assert np.array_equal(got[k, : w * h].reshape(h, w), oracle.equalize_hist(yk)), k
         assert np.array_equal(got[k, w * h:], frames[k, w * h:]), k
     ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, mi_lumaeq.UV_FILL128, 2.0, 8, 8)
     ctx.synchronize()
-    got = d_out.cpu().numpy()
+    got = host(d_out)
     for k in range(n):
         yk = frames[k, : w * h].reshape(h, w)
         assert np.array_equal(got[k, : w * h].reshape(h, w), oracle.clahe(yk, 2.0, 8, 8)), k
         assert (got[k, w * h:] == 128).all()
     ctx.nv12_bgr_equalize_batch_dev(d_in, d_out, w, h, 1)
     torch.cuda.synchronize()
-    assert np.array_equal(d_out[0].cpu().numpy(), oracle.nv12_bgr_equalize(frames[0], w, h))
+    assert np.array_equal(host(d_out[0]), oracle.nv12_bgr_equalize(frames[0], w, h))
 
 
 def test_host_forms_unpinned_and_pinned_memory_agree(ctx):
@@ -1215,12 +1219,12 @@ def test_clahe_fp_contract_mode(ctx):
         bgr = _bgr(640, 360, 12)
         assert np.array_equal(ctx.bgr_luma_op(bgr, mi_lumaeq.OP_CLAHE, 2.0, 8, 8), oracle.bgr_luma_op(bgr, 1, 2.0, 8, 8))
         import torch
-        nv = torch.from_numpy(np.stack([synth.nv12_frame(1920, 1080, "D2", 13 + k) for k in range(3)])).cuda()
+        nv = dev(np.stack([synth.nv12_frame(1920, 1080, "D2", 13 + k) for k in range(3)]))
         out = torch.empty_like(nv)
         ctx.clahe_nv12_batch_dev(nv, out, 1920, 1080, 3, mi_lumaeq.UV_COPY, 2.0, 8, 8)
         ctx.synchronize()
         for k in range(3):
-            assert np.array_equal(out[k].cpu().numpy(), oracle.nv12_frame(nv[k].cpu().numpy(), 1920, 1080, uv_mode=1, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8)), k
+            assert np.array_equal(host(out[k]), oracle.nv12_frame(host(nv[k]), 1920, 1080, uv_mode=1, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8)), k
     finally:
         oracle.set_fp_contract(old)
         ctx.set_option("clahe_fp_contract", 0)
@@ -1357,7 +1361,7 @@ def test_clahe_tuning_options_do_not_change_bytes(ctx):
                     d_out = torch.zeros_like(d_in)
                     ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, 1, *cfg)
                     ctx.synchronize()
-                    out = d_out.cpu().numpy()
+                    out = host(d_out)
                     for k in range(n):
                         assert np.array_equal(out[k], want[k]), (w, h, xcd, threads, k)
         with pytest.raises(mi_lumaeq.MiError):
@@ -1385,7 +1389,7 @@ def test_clahe_small_tiles_in_large_batches(ctx, case):
         d_out = torch.zeros_like(d_in)
         ctx.clahe_batch_dev(d_in, d_out, w, h, n, *cfg)
         ctx.synchronize()
-        out = d_out.cpu().numpy()
+        out = host(d_out)
         for i in range(n):
             key = (i % 7, i % 11)
             if key not in want:

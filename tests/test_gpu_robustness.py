@@ -10,7 +10,7 @@ import pytest
 
 import mi_lumaeq
 import oracle
-from mi_lumaeq import synth
+from mi_lumaeq import synth, xfer
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,11 @@ torch = pytest.importorskip("torch")
 
 
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    """host array -> device tensor WITHOUT handing pageable memory to the runtime (mi_lumaeq.xfer says why)"""
+    return xfer.to_device(a)
+
+
+host = xfer.to_host                                     # device tensor -> numpy, likewise through pinned staging
 
 
 def hooks_ctx():
@@ -62,7 +66,7 @@ def test_fused_path_is_demoted_after_repeated_repairs_and_probed_again():
         c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, 3, 0)
         c.synchronize()
         assert c.get_stat("fused_fallbacks") == 3
-        assert np.array_equal(d_out[2].cpu().numpy(), oracle.nv12_frame(d_in[2].cpu().numpy(), w, h, uv_mode=0, op=0))
+        assert np.array_equal(host(d_out[2]), oracle.nv12_frame(host(d_in[2]), w, h, uv_mode=0, op=0))
         # after the period: one probe (repaired: the fault is still injected) -> demoted again, for twice as long
         time.sleep(0.45)
         assert np.array_equal(c.equalize_hist(ys[0]), want[0])
@@ -232,7 +236,7 @@ def test_pipe_and_context_busy_rules():
                 assert pipe.submit(f, o2, 7 + rep)
                 assert pipe.wait()[0] == 7 + rep and np.array_equal(o2, want)
                 torch.cuda.synchronize()
-                got = d_out.cpu().numpy()
+                got = host(d_out)
                 for k in (0, 1, 2, 3, n - 1):
                     assert np.array_equal(got[k], oracle.nv12_frame(batch[k % 4], w, h, uv_mode=1, op=0)), (rep, k)
             assert c.get_stat("fused_fallbacks") == 0
@@ -278,11 +282,11 @@ def test_ticket_stamps_share_the_lifetime_of_their_hand_off_block():
             g.replay()
             torch.cuda.synchronize()
             c.synchronize()
-            got = e_out.cpu().numpy()
+            got = host(e_out)
             for k in range(m if m == n else 8):
                 assert np.array_equal(got[k], e_want[k % 4]), ("eager", rep, k)
             assert np.array_equal(got[m - 1], e_want[(m - 1) % 4]), ("eager", rep, m - 1)
-            src, out = d_in.cpu().numpy(), d_out.cpu().numpy()
+            src, out = host(d_in), host(d_out)
             for k in range(n):
                 assert np.array_equal(out[k], oracle.nv12_frame(src[k], w, h, uv_mode=0, op=0)), ("replay", rep, k)
         assert c.get_stat("fused_fallbacks") >= 6 and c.get_stat("fused_hard_errors") == 0

@@ -19,20 +19,21 @@ def timeit(fn, n=40):
     ts.sort()
     return ts[len(ts) // 2], ts[len(ts) // 10], ts[-len(ts) // 10 - 1]
 
-for rnd in range(2):
-    for threads in (1, 2):
+for streams, threads in ((1, 1), (1, 2), (2, 1), (2, 2), (1, 1), (2, 2)):
+    if True:
         ctx.set_option("host_copy_threads", threads)
+        ctx.set_option("host_copy_streams", streams)
         s0 = ctx.get_stat("host_copies_shared")
         p50, p10, p90 = timeit(lambda: ctx.equalize_hist(y, dst))
-        print(f"unpinned {w}x{h} equalizeHist, host_copy_threads={threads}: p50 {p50:.3f} ms (p10 {p10:.3f}, p90 {p90:.3f}); "
+        print(f"unpinned {w}x{h} equalizeHist, copy streams={streams} threads={threads}: p50 {p50:.3f} ms (p10 {p10:.3f}, p90 {p90:.3f}); "
               f"copies shared with the helper: {ctx.get_stat('host_copies_shared') - s0}", flush=True)
         p50, p10, p90 = timeit(lambda: ctx.clahe(y, 2.0, 8, 8, dst))
-        print(f"unpinned {w}x{h} CLAHE 8x8,    host_copy_threads={threads}: p50 {p50:.3f} ms (p10 {p10:.3f}, p90 {p90:.3f})", flush=True)
+        print(f"unpinned {w}x{h} CLAHE 8x8,    copy streams={streams} threads={threads}: p50 {p50:.3f} ms (p10 {p10:.3f}, p90 {p90:.3f})", flush=True)
 py, pd = torch.from_numpy(y.copy()).pin_memory(), torch.empty((h, w), dtype=torch.uint8).pin_memory()
 p50, p10, p90 = timeit(lambda: ctx.equalize_hist(py.numpy(), pd.numpy()))
 print(f"pinned   {w}x{h} equalizeHist: p50 {p50:.3f} ms (p10 {p10:.3f}, p90 {p90:.3f})")
 # a caller that works at 60 fps: one call every 16.7 ms (the helper sleeps in between and is woken per call)
-ctx.set_option("host_copy_threads", 2)
+ctx.set_option("host_copy_threads", 2); ctx.set_option("host_copy_streams", 2)
 ts = []
 for k in range(60):
     time.sleep(1 / 60)

@@ -6,11 +6,12 @@ import sys, time
 sys.path.insert(0, "opencv-opencl_amd/python"); sys.path.insert(0, ".")
 import numpy as np, torch
 import mi_lumaeq, oracle
+from mi_lumaeq import xfer
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = mi_lumaeq.Context(0)
 t0 = last = time.time(); n = {"roi": 0, "grid": 0, "small": 0, "c16": 0, "420": 0, "nv12": 0}
-def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+def dev(a): return xfer.to_device(np.ascontiguousarray(a))
 def fail(what, *info):
     print("MISMATCH", what, info, flush=True); sys.exit(1)
 while time.time() - t0 < budget:
@@ -24,7 +25,7 @@ while time.time() - t0 < budget:
         d_src, d_dst = dev(src), torch.zeros((nf, h + 4, dp), dtype=torch.uint8, device="cuda")
         ctx.equalize_hist_batch_dev(d_src.data_ptr() + 2 * sp + sx, d_dst.data_ptr() + dp + dx, w, h, nf, src_step=sp, src_frame=(h + 4) * sp,
                                     dst_step=dp, dst_frame=(h + 4) * dp)
-        ctx.synchronize(); out = d_dst.cpu().numpy()
+        ctx.synchronize(); out = xfer.to_host(d_dst)
         for f in range(nf):
             if not np.array_equal(out[f, 1:1 + h, dx:dx + w], oracle.equalize_hist(src[f, 2:2 + h, sx:sx + w])): fail("roi", w, h, nf, sp, dp, sx, dx, f)
         if out[:, 0].sum() or out[:, 1 + h:].sum(): fail("roi wrote outside", w, h, sp, dp)
@@ -42,7 +43,7 @@ while time.time() - t0 < budget:
         ys = rng.integers(0, 256, (min(nf, 9), h, w), dtype=np.uint8)
         batch = np.ascontiguousarray(ys[np.arange(nf) % ys.shape[0]])
         d_in = dev(batch); d_out = torch.zeros_like(d_in)
-        ctx.clahe_batch_dev(d_in, d_out, w, h, nf, 2.0, tx, ty); ctx.synchronize(); out = d_out.cpu().numpy()
+        ctx.clahe_batch_dev(d_in, d_out, w, h, nf, 2.0, tx, ty); ctx.synchronize(); out = xfer.to_host(d_out)
         want = [oracle.clahe(ys[i], 2.0, tx, ty) for i in range(ys.shape[0])]
         for f in range(nf):
             if not np.array_equal(out[f], want[f % ys.shape[0]]): fail("small tiles", w, h, tx, ty, nf, f)
@@ -61,7 +62,7 @@ while time.time() - t0 < budget:
         d_in = dev(fr); inplace = bool(rng.integers(0, 2)); d_out = d_in if inplace else torch.zeros_like(d_in)
         if op == 0: ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, nf, uv)
         else: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, nf, uv, 2.0, 4, 4)
-        ctx.synchronize(); out = d_out.cpu().numpy()
+        ctx.synchronize(); out = xfer.to_host(d_out)
         for f in range(nf):
             if not np.array_equal(out[f], oracle.nv12_frame(fr[f], w, h, uv_mode=uv, op=op, clip_limit=2.0, tiles_x=4, tiles_y=4)): fail("nv12", w, h, nf, uv, op, inplace, f)
         n["nv12"] += 1
