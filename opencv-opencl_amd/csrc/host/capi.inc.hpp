@@ -130,6 +130,7 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
     }
     // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist12_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHist12Words * (int)sizeof(uint32_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16Entries * (int)sizeof(uint2));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16Entries * (int)sizeof(uint2));
     hipDeviceProp_t prop;
@@ -277,6 +278,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "clahe_seg_pairs")) { if (value < 4 || value > 15) return fail(c, MI_ERR_BAD_ARG, "clahe_seg_pairs must be 4..15"); c->clahe_seg_pairs = value; return MI_OK; }
     if (!strcmp(name, "clahe_xcd_map")) { c->clahe_xcd_map = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
+    if (!strcmp(name, "clahe16_fast12")) { c->clahe16_fast12 = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe16_transposed")) { c->clahe16_transposed = value != 0; return MI_OK; }
     if (!strcmp(name, "pipe_private_streams")) { c->pipe_private_streams = value != 0; return MI_OK; }
     if (!strcmp(name, "pipe_copy_streams")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "pipe_copy_streams must be 1 or 2"); c->pipe_copy_streams = value; return MI_OK; }

@@ -33,8 +33,13 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         uint16_t* luts = reinterpret_cast<uint16_t*>(c->d_c16 + (size_t)nf * tiles * kHist16 * sizeof(uint32_t));
         Range16* ranges = reinterpret_cast<Range16*>(c->d_c16 + (size_t)nf * tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t)));
         Range16* franges = ranges + (size_t)nf * tiles;
-        LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
-               src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, vec);
+        // 12-bit bet (kernels/clahe16.hip.h): vector geometry only; a tile that loses it is redone the careful way in the same workgroup
+        if (vec && c->clahe16_fast12)
+            LAUNCH(c, s, MI_K_TILE_HIST, tile_hist12_kernel, dim3(tiles, nf), dim3(1024), kHist12Words * sizeof(uint32_t),
+                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts);
+        else
+            LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
+                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, vec);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, (const Range16*)ranges, g,
                lut_scale16, clip16, luts, franges);
         if (tiles <= 64 && c->clahe16_transposed) {

@@ -137,6 +137,7 @@ struct mi_ctx {
     int fused_timeout_ms = 50;                                   // option "fused_timeout_ms": bound of every inter-workgroup wait
     int bgr_fused = 1;                                           // option "bgr_fused": 9 B/px two-pass BGR luma equalization / CLAHE
     int clahe_fp_contract = 0;                                   // option "clahe_fp_contract": CLAHE interpolation with GCC's FMA contraction (aarch64 OpenCV builds)
+    int clahe16_fast12 = 1;                                      // option "clahe16_fast12": 4096-bin x 8-copy tile histograms with the LUT folded in (12-bit bet)
     int clahe16_transposed = 0;                                  // option "clahe16_transposed": value-major LUTs for 16-bit interpolation (tiles <= 64)
     int clahe_hist_threads = 512;                                // option "clahe_hist_threads": 256 or 512 threads per tile-histogram workgroup
     int clahe_tiles_per_wg = 0;                                  // option "clahe_tiles_per_wg": tiles a tile-histogram workgroup walks in batches (0 = by tile size, 1, 2, 4, 8)

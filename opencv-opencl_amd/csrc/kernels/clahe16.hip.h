@@ -36,18 +36,20 @@ __device__ __forceinline__ void lds_add(uint32_t* h, uint32_t idx, uint32_t n)
     __hip_atomic_fetch_add(h + idx, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32
 }
 
+template <int kWinBits>
 __device__ __forceinline__ void hist16_add_dword(uint32_t* h16, uint32_t w, int half, uint32_t& lmin, uint32_t& lmax)
 {
     const uint32_t a = w & 0xffffu, b = w >> 16;
     lmin = min(lmin, min(a, b)); lmax = max(lmax, max(a, b));
-    if (a == b) { if ((int)(a >> 15) == half) lds_add(h16, a & (kHalf16 - 1), 2u); return; }
-    if ((int)(a >> 15) == half) lds_inc(h16, a & (kHalf16 - 1));
-    if ((int)(b >> 15) == half) lds_inc(h16, b & (kHalf16 - 1));
+    if (a == b) { if ((int)(a   >> kWinBits) == half) lds_add(h16, a & ((1u << kWinBits) - 1), 2u); return; }
+    if ((int)(a   >> kWinBits) == half) lds_inc(h16, a & ((1u << kWinBits) - 1));
+    if ((int)(b   >> kWinBits) == half) lds_inc(h16, b & ((1u << kWinBits) - 1));
 }
 
 // Eight pixels of one 16-byte load.  There is no room to replicate 32 768 counters per LDS bank, so equal values meeting in one
 // ds_add serialise; flat image regions (borders, saturated areas) are the bad case and are caught before they reach the LDS:
 // all eight pixels equal -> one add of 8; the same value in every active lane of the wave -> one lane adds for the whole wave.
+template <int kWinBits>
 __device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, int half, uint32_t& lmin, uint32_t& lmax)
 {
     const uint32_t v0 = q.x & 0xffffu;
@@ -57,15 +59,15 @@ __device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, in
         const unsigned long long active = __ballot(1);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
         if (__ballot(v0 == first) == active) {                      // wave-uniform value (only lanes with flat vectors are here)
-            if ((int)(v0 >> 15) == half && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(active))
-                lds_add(h16, v0 & (kHalf16 - 1), 8u * (uint32_t)__builtin_popcountll(active));
-        } else if ((int)(v0 >> 15) == half) {
-            lds_add(h16, v0 & (kHalf16 - 1), 8u);
+            if ((int)(v0   >> kWinBits) == half && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(active))
+                lds_add(h16, v0 & ((1u << kWinBits) - 1), 8u * (uint32_t)__builtin_popcountll(active));
+        } else if ((int)(v0   >> kWinBits) == half) {
+            lds_add(h16, v0 & ((1u << kWinBits) - 1), 8u);
         }
         return;
     }
-    hist16_add_dword(h16, q.x, half, lmin, lmax); hist16_add_dword(h16, q.y, half, lmin, lmax);
-    hist16_add_dword(h16, q.z, half, lmin, lmax); hist16_add_dword(h16, q.w, half, lmin, lmax);
+    hist16_add_dword<kWinBits>(h16, q.x, half, lmin, lmax); hist16_add_dword<kWinBits>(h16, q.y, half, lmin, lmax);
+    hist16_add_dword<kWinBits>(h16, q.z, half, lmin, lmax); hist16_add_dword<kWinBits>(h16, q.w, half, lmin, lmax);
 }
 
 // OPTIMISTIC sweep (vector path): count every pixel at (value & 32767) without asking which half it belongs to, and track the range
@@ -73,13 +75,15 @@ __device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, in
 // counters have aliased and the careful two-sweep code below starts over; for everything up to 15 bits -- all video -- this sweep is
 // the whole job at ~4 VALU instructions per pixel instead of ~14 (no per-pixel half test, no divergent branch around the ds_add).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <int kWinBits>
 __device__ __forceinline__ void hist16_fast_dword(uint32_t* h16, uint32_t w, u16x2& pmin, u16x2& pmax)
 {
     const u16x2 v = __builtin_bit_cast(u16x2, w);
     pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
-    lds_inc(h16, w & (kHalf16 - 1));
-    lds_inc(h16, (w >> 16) & (kHalf16 - 1));
+    lds_inc(h16, w & ((1u << kWinBits) - 1));
+    lds_inc(h16, (w >> 16) & ((1u << kWinBits) - 1));
 }
+template <int kWinBits>
 __device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u16x2& pmin, u16x2& pmax)
 {
     const uint32_t v0 = q.x & 0xffffu;
@@ -90,24 +94,25 @@ __device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u
         const unsigned long long active = __ballot(1);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
         if (__ballot(v0 == first) == active) {
-            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(active)) lds_add(h16, v0 & (kHalf16 - 1), 8u * (uint32_t)__builtin_popcountll(active));
+            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(active)) lds_add(h16, v0 & ((1u << kWinBits) - 1), 8u * (uint32_t)__builtin_popcountll(active));
         } else {
-            lds_add(h16, v0 & (kHalf16 - 1), 8u);
+            lds_add(h16, v0 & ((1u << kWinBits) - 1), 8u);
         }
         return;
     }
-    hist16_fast_dword(h16, q.x, pmin, pmax); hist16_fast_dword(h16, q.y, pmin, pmax);
-    hist16_fast_dword(h16, q.z, pmin, pmax); hist16_fast_dword(h16, q.w, pmin, pmax);
+    hist16_fast_dword<kWinBits>(h16, q.x, pmin, pmax); hist16_fast_dword<kWinBits>(h16, q.y, pmin, pmax);
+    hist16_fast_dword<kWinBits>(h16, q.z, pmin, pmax); hist16_fast_dword<kWinBits>(h16, q.w, pmin, pmax);
 }
 
 // grid = (tiles, frames), 1024 threads, 128 KiB dynamic LDS.  steps in BYTES.
 // `vec` (host: no REFLECT_101 padding, tile_w % 8 == 0, 16-B aligned rows): a lane takes 8 pixels per 16-byte load with
 // four loads in flight; otherwise one pixel per lane per step with index reflection.
-__global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                          ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
+template <int kWinBits>
+__device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinBits] LDS */, uint32_t& s_lo, uint32_t& s_hi,
+                                                    const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                    const ClaheGeom& g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
 {
-    extern __shared__ uint32_t h16[];                            // [32768]
-    __shared__ uint32_t s_lo, s_hi;
+    constexpr int kWin = 1 << kWinBits;
     const int t = threadIdx.x;
     const int tile = blockIdx.x, f = blockIdx.y;
     const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
@@ -124,12 +129,12 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
         return *reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
     };
     uint32_t lmin = 0xffffu, lmax = 0;
-    auto vadd = [&](const u32x4& q, int half) { hist16_add_vec(h16, q, half, lmin, lmax); };
+    auto vadd = [&](const u32x4& q, int half) { hist16_add_vec<kWinBits>(h16, q, half, lmin, lmax); };
     if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
     uint32_t lo = 0, hi = 0;
     bool range_known = false;
     if (vec) {                                                    // optimistic sweep, see hist16_fast_vec
-        for (int i = t; i < kHalf16 / 4; i += 1024) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
+        for (int i = t; i < kWin / 4; i += 1024) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
         u16x2 pmin = {0xffff, 0xffff}, pmax = {0, 0};
         int row = t / slots, slot = t - row * slots;
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
                 if (slot >= slots) { slot -= slots; ++row; }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (qv[k]) hist16_fast_vec(h16, q[k], pmin, pmax);
+            for (int k = 0; k < 4; ++k) if (qv[k]) hist16_fast_vec<kWinBits>(h16, q[k], pmin, pmax);
         }
         lmin = min((uint32_t)pmin.x, (uint32_t)pmin.y); lmax = max((uint32_t)pmax.x, (uint32_t)pmax.y);
 #pragma unroll
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
         }
         __syncthreads();
         lo = s_lo; hi = s_hi;
-        if (hi < kHalf16) {                                       // nothing aliased: the counters are the histogram
+        if (hi < (uint32_t)kWin) {                                // nothing aliased: the counters are the histogram
             for (uint32_t i = (lo & ~3u) + (uint32_t)t; i <= hi; i += 1024) out[i] = h16[i];
             if (t == 0) { Range16 r; r.lo = lo; r.hi = hi; ranges[tile_id] = r; }
             return;
@@ -165,8 +170,8 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
         range_known = true;                                       // a value >= 32768: start over, one half of the value range per sweep
         __syncthreads();
     }
-    for (int half = 0; half < 2; ++half) {
-        for (int i = t; i < kHalf16; i += 1024) h16[i] = 0;
+    for (int half = 0; half < (kHist16 >> kWinBits); ++half) {    // one window of the value range per sweep
+        for (int i = t; i < kWin; i += 1024) h16[i] = 0;
         __syncthreads();
         if (vec) {
             int it = t;
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
                 const int x = reflect101(tx * g.tile_w + col, g.width);
                 const uint32_t v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
                 lmin = min(lmin, v); lmax = max(lmax, v);
-                if ((int)(v >> 15) == half) lds_inc(h16, v & (kHalf16 - 1));
+                if ((int)(v   >> kWinBits) == half) lds_inc(h16, v & ((1u << kWinBits) - 1));
                 row += drow; col += dcol;
                 if (col >= g.tile_w) { col -= g.tile_w; ++row; }
             }
@@ -198,14 +203,210 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
         __syncthreads();
         lo = s_lo; hi = s_hi;
         // store the populated bins of this half only: [max(lo, base), min(hi, base + 32767)]
-        const uint32_t base = (uint32_t)half * kHalf16;
-        const uint32_t b0 = max(lo, base), b1 = min(hi, base + kHalf16 - 1);
+        const uint32_t base = (uint32_t)half * (uint32_t)kWin;
+        const uint32_t b0 = max(lo, base), b1 = min(hi, base + (uint32_t)kWin - 1);
         if (b0 <= b1)
-            for (uint32_t i = (b0 & ~3u) + (uint32_t)t; i <= b1; i += 1024) out[i] = h16[i & (kHalf16 - 1)];   // from a 4-aligned start: the LUT kernel loads 16 B
-        if (hi < kHalf16) break;                                  // nothing in the upper half: one pass was the whole job
+            for (uint32_t i = (b0 & ~3u) + (uint32_t)t; i <= b1; i += 1024) out[i] = h16[i & ((1u << kWinBits) - 1)];   // from a 4-aligned start: the LUT kernel loads 16 B
+        if (hi < base + (uint32_t)kWin) break;                    // nothing above this window: done
         __syncthreads();
     }
     if (t == 0) { Range16 r; r.lo = lo; r.hi = hi; ranges[tile_id] = r; }
+}
+
+__global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                          ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
+{
+    extern __shared__ uint32_t h16[];                            // [32768]
+    __shared__ uint32_t s_lo, s_hi;
+    tile_hist16_careful<15>(h16, s_lo, s_hi, src_base, step, frame_stride, g, hist, ranges, vec);
+}
+
+// ---- 12-bit fast path -----------------------------------------------------------------------------------------------------
+// What 16-bit video actually carries is 10 or 12 bits.  tile_hist12_kernel BETS on that: 4096 bins x 4 copies take 64 KiB of LDS
+// (two workgroups per CU instead of one), a lane counts at (value & 4095) * 4 + (lane & 3), and the packed min / max it tracks anyway tells at the end whether the
+// bet held (max < 4096).  Against the 32 768-counter sweep above:
+//   * the sweep is bound by the loads a CU keeps in flight (a constant frame takes as long as noise): two workgroups per CU double
+//     them -- the 32 768-counter kernel fills the LDS with one;
+//   * equal values meeting in one ds_add serialise, and neighbouring pixels of a real image ARE equal or close: with four copies
+//     at most the 16 lanes that share a copy can meet, not 64;
+//   * the loads of the next four vectors are in flight while the current four are counted (two register sets): with one
+//     workgroup of 16 waves per CU the ~2 us of HBM latency per iteration was otherwise exposed;
+//   * the whole LUT stage is done right here, from the counters in LDS (clip, redistribute, prefix sum over bins 0..4095 -- the same
+//     arithmetic as tile_lut16_kernel, which then returns at once for such a tile as long as the WHOLE frame stayed below 4096).
+// A tile that loses the bet -- some value >= 4096, noticed after the first four vectors per lane or at the end -- is redone by
+// tile_hist16_careful<14> (16 384 counters per sweep, up to four sweeps) in the same workgroup, same LDS.  ranges[tile].hi carries bit 31 when the tile's LUT was written here.
+constexpr uint32_t kLutDone = 0x80000000u;
+constexpr int kBins12 = 4096;
+constexpr int kCopies12 = 4;                        // 4096 bins x 4 copies x 4 B = 64 KiB: TWO workgroups per CU (the sweep is bound by the
+                                                    // loads a CU keeps in flight, not by the LDS: a constant frame takes as long as noise)
+constexpr int kCopyShift12 = 2;
+constexpr int kHist12Words = kBins12 * kCopies12;
+
+__device__ __forceinline__ void hist12_dword(uint32_t* h, uint32_t w, uint32_t cp, u16x2& pmin, u16x2& pmax)
+{
+    const u16x2 v = __builtin_bit_cast(u16x2, w);
+    pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
+    lds_inc(h, ((w & (kBins12 - 1)) << kCopyShift12) | cp);
+    lds_inc(h, (((w >> 16) & (kBins12 - 1)) << kCopyShift12) | cp);
+}
+__device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t cp, u16x2& pmin, u16x2& pmax)
+{
+    const uint32_t v0 = q.x & 0xffffu;
+    const bool flat = q.x == q.y && q.y == q.z && q.z == q.w && v0 == (q.x >> 16);
+    if (__builtin_expect(flat, 0)) {                                // flat regions never reach the LDS pixel by pixel (as hist16_fast_vec)
+        const u16x2 v = __builtin_bit_cast(u16x2, q.x);
+        pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
+        const unsigned long long active = __ballot(1);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
+        const uint32_t idx = ((v0 & (kBins12 - 1)) << kCopyShift12) | cp;
+        if (__ballot(v0 == first) == active) {
+            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(active)) lds_add(h, idx, 8u * (uint32_t)__builtin_popcountll(active));
+        } else {
+            lds_add(h, idx, 8u);
+        }
+        return;
+    }
+    hist12_dword(h, q.x, cp, pmin, pmax); hist12_dword(h, q.y, cp, pmin, pmax);
+    hist12_dword(h, q.z, cp, pmin, pmax); hist12_dword(h, q.w, cp, pmin, pmax);
+}
+
+// grid = (tiles, frames), 1024 threads, 128 KiB dynamic LDS; vector geometry only (the host checks: no padding, tile_w % 8 == 0,
+// 16-B aligned rows).
+__global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                          ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
+                                                          float lut_scale16, int clip16, uint16_t* __restrict__ luts)
+{
+    extern __shared__ uint32_t h16[];                            // [4096][4] = 64 KiB, or [16384] for the careful path
+    __shared__ uint32_t s_lo, s_hi;
+    __shared__ uint32_t s_w[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int tile = blockIdx.x, f = blockIdx.y;
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+    const size_t tile_id = (size_t)f * gridDim.x + tile;
+    const uint8_t* src = src_base + (long long)f * frame_stride;
+    const int slots = g.tile_w >> 3;
+    const int vitems = g.tile_h * slots;
+    const uint8_t* tbase = src + (long long)ty * g.tile_h * step + (long long)tx * g.tile_w * 2;
+    const uint32_t cp = (uint32_t)t & (uint32_t)(kCopies12 - 1);
+    if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
+    for (int i = t; i < kHist12Words / 4; i += 1024) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
+    // (row, slot) items walked incrementally, four predicated loads per set
+    int row = t / slots, slot = t - row * slots;
+    const int vdrow = 1024 / slots, vdslot = 1024 - vdrow * slots;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    auto load_set = [&](int it, u32x4* q, bool* qv) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            qv[k] = it + k * 1024 < vitems;
+            const u32x4* ptr = reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
+            q[k] = qv[k] ? *ptr : zero;
+            row += vdrow; slot += vdslot;
+            if (slot >= slots) { slot -= slots; ++row; }
+        }
+    };
+    u32x4 cur[4], nxt[4]; bool cv[4], nv[4];
+    load_set(t, cur, cv);
+    // the first set decides early: a frame with more than 12 bits shows it in (almost) any 32 pixels per lane
+    uint32_t m0 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m0 |= cur[k].x | cur[k].y | cur[k].z | cur[k].w;      // OR of the packed pixels: bit 12..15 of either half set?
+    const bool early_lost = __syncthreads_or((m0 & 0xf000f000u) != 0u) != 0;             // (also orders the zeroing above)
+    bool lost = early_lost;
+    u16x2 pmin = {0xffff, 0xffff}, pmax = {0, 0};
+    if (!lost) {
+        for (int it = t; it < vitems; it += 4 * 1024) {
+            const bool more = it + 4 * 1024 < vitems;                // uniform per lane only; the loads are predicated anyway
+            if (more) load_set(it + 4 * 1024, nxt, nv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (cv[k]) hist12_vec(h16, cur[k], cp, pmin, pmax);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { cur[k] = nxt[k]; cv[k] = nv[k]; }
+            }
+        }
+        uint32_t lmin = min((uint32_t)pmin.x, (uint32_t)pmin.y), lmax = max((uint32_t)pmax.x, (uint32_t)pmax.y);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64)); }
+        if (lane == 0) {
+            __hip_atomic_fetch_min(&s_lo, lmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&s_hi, lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        lost = s_hi >= (uint32_t)kBins12;
+    }
+    if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
+        __syncthreads();
+        if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
+        __syncthreads();
+        tile_hist16_careful<14>(h16, s_lo, s_hi, src_base, step, frame_stride, g, hist, ranges, 1);   // 16 384 counters per sweep fit the 64 KiB
+        return;
+    }
+    const uint32_t lo = s_lo, hi = s_hi;
+    // ---- the tile's 4096 counts: thread t owns bins 4t .. 4t+3 (sum of the eight copies)
+    // Read out conflict-free: consecutive lanes read consecutive 16 bytes (the four copies of one bin), the 4096 sums are compacted
+    // to the head of the LDS array, and each thread then picks up its four consecutive bins.
+    int v[4];
+    {
+        const u32x4* hp = reinterpret_cast<const u32x4*>(h16);
+        uint32_t part[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const u32x4 a = hp[t + 1024 * j]; part[j] = a.x + a.y + a.z + a.w; }     // bin t + 1024 j
+        __syncthreads();                                            // every copy has been read: the head of the array may be overwritten
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h16[t + 1024 * j] = part[j];
+        __syncthreads();
+        const u32x4 q = hp[t];
+        v[0] = (int)q.x; v[1] = (int)q.y; v[2] = (int)q.z; v[3] = (int)q.w;
+    }
+    const uint32_t b0 = (uint32_t)t * 4;
+    // the histogram itself, for tile_lut16_kernel should the FRAME turn out wider than 4096 values (another tile lost its bet)
+    if (b0 + 3 >= (lo & ~3u) && b0 <= hi)
+        *reinterpret_cast<u32x4*>(hist + tile_id * kHist16 + b0) = u32x4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+    auto block_scan = [&](uint32_t x, uint32_t& total) -> uint32_t {  // inclusive prefix of x over the 1024 threads
+        const uint32_t incl = wave_incl_scan(x);
+        __syncthreads();
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { const uint32_t y = s_w[k]; if (k < wv) off += y; tot += y; }
+        total = tot;
+        return off + incl;
+    };
+    // ---- clip, redistribute, prefix sum, scale: clahe.cpp for histSize 65536, exactly as tile_lut16_kernel does it from bin 0
+    int batch = 0, residual = 0, rstep = 1;
+    if (clip16 > 0) {
+        uint32_t excess = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (v[k] > clip16) excess += (uint32_t)(v[k] - clip16);
+        uint32_t clipped;
+        (void)block_scan(excess, clipped);
+        batch = (int)clipped / kHist16;
+        residual = (int)clipped - batch * kHist16;
+        if (residual != 0) { rstep = kHist16 / residual; if (rstep < 1) rstep = 1; }
+    }
+    uint32_t local = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (clip16 > 0) {
+            if (v[k] > clip16) v[k] = clip16;
+            v[k] += batch;
+            const int b = (int)b0 + k;
+            if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++v[k];
+        }
+        local += (uint32_t)v[k];
+        v[k] = (int)local;
+    }
+    uint32_t total;
+    const uint32_t before = block_scan(local, total) - local;
+    uint32_t packed[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int r = __float2int_rn(__fmul_rn((float)(int)(before + (uint32_t)v[k]), lut_scale16));
+        r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
+        if (k & 1) packed[k >> 1] |= (uint32_t)r << 16; else packed[k >> 1] = (uint32_t)r;
+    }
+    *reinterpret_cast<uint2*>(luts + tile_id * kHist16 + b0) = make_uint2(packed[0], packed[1]);
+    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | kLutDone; ranges[tile_id] = r; }
 }
 
 // grid = (tiles, frames), 1024 threads.  Bins are walked in chunks of 4096, four consecutive bins per thread (one 16-byte load,
@@ -237,7 +438,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     {
         uint32_t l = 0xffffu, u = 0;
         const Range16* fr = ranges + (size_t)blockIdx.y * tiles;
-        for (int i = t; i < tiles; i += 1024) { const Range16 r = fr[i]; l = min(l, r.lo); u = max(u, r.hi); }
+        for (int i = t; i < tiles; i += 1024) { const Range16 r = fr[i]; l = min(l, r.lo); u = max(u, r.hi & ~kLutDone); }
         if (t < tiles) {
             __hip_atomic_fetch_min(&s_flo, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_max(&s_fhi, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -245,8 +446,11 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     }
     __syncthreads();
     const uint32_t flo = s_flo, fhi = s_fhi;
-    const Range16 own = ranges[tile_id];
+    Range16 own = ranges[tile_id];
     if (blockIdx.x == 0 && t == 0) { Range16 r; r.lo = flo; r.hi = fhi; frame_ranges[blockIdx.y] = r; }
+    // tile_hist12_kernel has already written this tile's LUT for bins 0..4095: that is all anybody reads if the whole frame stayed below
+    if ((own.hi & kLutDone) && fhi < (uint32_t)kBins12) return;
+    own.hi &= ~kLutDone;
     auto load4 = [&](uint32_t b0, int* v) {                       // bins b0..b0+3 of this tile, zero outside its stored range
         if (b0 + 3 < own.lo || b0 > own.hi) { v[0] = v[1] = v[2] = v[3] = 0; return; }
         const u32x4 q = *reinterpret_cast<const u32x4*>(h + b0);

@@ -6,6 +6,8 @@ ctx = mi_lumaeq.Context(0)
 w, h = 3840, 2160
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 only = sys.argv[2] if len(sys.argv) > 2 else ""            # "12bit": just the 12-bit case (profiling runs)
+for kv in sys.argv[3:]:                                      # name=value options, e.g. clahe16_fast12=0
+    k, v = kv.split("="); ctx.set_option(k, int(v)); print("option", k, "=", v)
 def u16(lo, hi): return torch.randint(lo, hi, (n, h, w), dtype=torch.int32, device="cuda").to(torch.int16)   # bit pattern of the ushort
 cases = (("12-bit 0..4095", u16(0, 4096)), ("10-bit 0..1023", u16(0, 1024)), ("narrow 1000..1399", u16(1000, 1400)), ("13-bit 0..8191", u16(0, 8192)),
          ("15-bit 0..32767", u16(0, 32768)), ("16-bit full", u16(0, 65536)), ("const 777", torch.full((n, h, w), 777, dtype=torch.int16, device="cuda")),
