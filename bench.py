@@ -643,6 +643,18 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
+    def median_ms(fn, n):
+        """synchronous calls: per-call wall time, median (one descheduled call must not move a latency figure)"""
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        return ts[len(ts) // 2]
+
     res["single_frame_dev_equalize_ms"] = round(timeit(
         lambda: ctx.equalize_hist_nv12_batch_dev(frame, outb, w, h, 1, mi_lumaeq.UV_FILL128, stream=stream), 200), 4)
     res["single_frame_dev_clahe8x8_ms"] = round(timeit(
@@ -674,12 +686,13 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
             gctx.close()
     y = xfer.to_host(frame[0, : w * h]).reshape(h, w)
     dst = np.empty_like(y)
-    res["host_mat_equalize_ms_pcie_inclusive"] = round(timeit(lambda: ctx.equalize_hist(y, dst), 20), 3)
-    res["host_mat_clahe8x8_ms_pcie_inclusive"] = round(timeit(lambda: ctx.clahe(y, 2.0, 8, 8, dst), 20), 3)
+    res["host_mat_equalize_ms_pcie_inclusive"] = round(median_ms(lambda: ctx.equalize_hist(y, dst), 40), 3)
+    res["host_mat_clahe8x8_ms_pcie_inclusive"] = round(median_ms(lambda: ctx.clahe(y, 2.0, 8, 8, dst), 40), 3)
     # the two figures above are for ordinary (unpinned) Mats, which the library packs through its own pinned staging; planes in
     # memory the caller pinned (a registered frame pool) are DMA'd as they are
     py, pd = torch.from_numpy(y.copy()).pin_memory(), torch.empty((h, w), dtype=torch.uint8).pin_memory()
-    res["host_mat_equalize_ms_pcie_inclusive_pinned_mats"] = round(timeit(lambda: ctx.equalize_hist(py.numpy(), pd.numpy()), 20), 3)
+    pyn, pdn = py.numpy(), pd.numpy()
+    res["host_mat_equalize_ms_pcie_inclusive_pinned_mats"] = round(median_ms(lambda: ctx.equalize_hist(pyn, pdn), 40), 3)
     del py, pd
     B = args.batch
     d_in = synth.nv12_batch_torch(w, h, B, args.dist, "cuda", seed=5)
