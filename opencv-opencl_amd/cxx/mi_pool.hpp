@@ -136,7 +136,12 @@ private:
         mi_pipe* pipe = nullptr;
         std::string pipe_error;
         try {                                                   // context + pipe: allocations and warm-up for this frame size happen here,
-            c = detail::thread_ctx();                           // not under the first real frame (~100 ms would blow a 16.7 ms budget)
+            // not under the first real frame (~100 ms would blow a 16.7 ms budget).  The context is the WORKER'S OWN, not the thread's
+            // default one (detail::thread_ctx()): while frames are pending in a context's pipe its other entry points answer
+            // MI_ERR_BUSY, and a sink that calls micv::equalizeHist / CLAHE on this thread must keep working.
+            const mi_status cst = mi_ctx_create(device, &c);
+            if (cst != MI_OK) MI_CV_ERROR(cst == MI_ERR_NO_DEVICE ? GpuNotSupported : GpuApiCallError,
+                                          std::string("mi_ctx_create(device=") + std::to_string(device) + ") failed: " + mi_status_str(cst));
             mi_pipe_config cfg{};
             cfg.width = width_; cfg.height = height_;
             cfg.op = op_ == EQUALIZE ? MI_OP_EQUALIZE : (op_ == CLAHE_OP ? MI_OP_CLAHE : MI_OP_CHANNELS);
@@ -198,6 +203,7 @@ private:
             stats_.ns_deliver.fetch_add(since(t_del), std::memory_order_relaxed);
         }
         if (pipe) mi_pipe_destroy(pipe);
+        if (c) mi_ctx_destroy(c);
     }
 
     // re-sequencer: hold completed frames until all earlier ones have been delivered

@@ -263,6 +263,32 @@ int main()
         orc_nv12_frame(in[5].data(), ref.data(), W, H, 0, 0, 0.0, 0, 0);
         EXPECT(memcmp(out[5].data(), ref.data(), ysz + uvsz) == 0);
     }
+    // --- a sink that runs the adapter ITSELF on the pool thread (the reference's appsink callback chain does more OpenCV work on
+    //     delivered frames): the worker's pipe has frames pending at that moment, and a context with pending pipe frames answers
+    //     MI_ERR_BUSY -- so the pool worker must own a private context and leave the thread's default one to the sink
+    {
+        const int N = 10;
+        std::vector<std::vector<uint8_t>> in(N, std::vector<uint8_t>(ysz + uvsz)), out(N, std::vector<uint8_t>(ysz + uvsz));
+        for (int k = 0; k < N; ++k) fill(in[k], 500 + k);
+        int sink_bad = 0, sink_calls = 0;
+        std::vector<uint8_t> want_twice(ysz), once(ysz);
+        {
+            FramePool pool(1, W, H, FramePool::EQUALIZE, UV_FILL128, [&](const FrameJob& j) {
+                EXPECT(j.ok);
+                try {
+                    Mat y(H, W, CV_8UC1, j.out), again;               // equalize the delivered Y plane once more, on this very thread
+                    equalizeHist(y, again);
+                    orc_equalize_hist_u8(j.out, W, want_twice.data(), W, W, H);
+                    if (memcmp(again.data, want_twice.data(), ysz) != 0) ++sink_bad;
+                    ++sink_calls;
+                } catch (const std::exception& e) { printf("sink: %s\n", e.what()); ++sink_bad; }
+            }, 2.0, Size(8, 8), 16, 4);
+            for (int k = 0; k < N; ++k) pool.submit(in[k].data(), out[k].data());
+            pool.finish();
+            EXPECT(pool.stats().processing_errors.load() == 0);
+        }
+        EXPECT(sink_calls == N && sink_bad == 0);
+    }
     // --- the reference's worker pattern without the pool (OpenCVequalHist.cpp:397-402: 1..8 threads, each calling cv::equalizeHist on
     //     its own Mats; clahevideo.cpp: one CLAHE object per thread): equalizeHist is re-entrant across threads, distinct CLAHE objects
     //     are independent.  Eight threads -> eight per-thread contexts on one device (four get the fused kernel, four the three-kernel

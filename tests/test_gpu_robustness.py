@@ -294,3 +294,71 @@ def test_ticket_stamps_share_the_lifetime_of_their_hand_off_block():
         torch.cuda.synchronize()
     finally:
         c.close()
+
+
+def test_numa_placement_entry_points():
+    """mi_device_pci_bus_id / mi_thread_bind_near_device (what every per-GPU worker calls before it creates its context): the PCI address
+    has sysfs shape, binding reports the node and never fails hard, the thread ends up on a subset of the CPUs it had, and
+    MI_LUMAEQ_NUMA_BIND=0 turns it into a report."""
+    import os
+    import re
+    import subprocess
+    import sys
+    bdf = mi_lumaeq.device_pci_bus_id(0)
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", bdf), bdf
+    with pytest.raises(mi_lumaeq.MiError):
+        mi_lumaeq.device_pci_bus_id(99)
+    # in a child process: the binding is per thread and would otherwise stick to the test session's main thread
+    code = ("import os, sys, json\n"
+            "sys.path.insert(0, 'opencv-opencl_amd/python')\n"
+            "import mi_lumaeq\n"
+            "before = sorted(os.sched_getaffinity(0))\n"
+            "b = mi_lumaeq.bind_thread_near_device(0)\n"
+            "after = sorted(os.sched_getaffinity(0))\n"
+            "print(json.dumps({'b': b, 'before': len(before), 'after': len(after), 'subset': set(after) <= set(before)}))\n")
+    import json
+    root = str(__import__("pathlib").Path(__file__).resolve().parents[1])
+    for env_off in (False, True):
+        env = dict(os.environ)
+        if env_off:
+            env["MI_LUMAEQ_NUMA_BIND"] = "0"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["subset"] and d["after"] >= 1
+        if env_off:
+            assert d["b"]["cpus"] == 0 and d["after"] == d["before"] and "not applied" in d["b"]["why"]
+        elif d["b"]["node"] >= 0 and d["b"]["cpus"] > 0:
+            assert d["after"] == d["b"]["cpus"] <= d["before"] and "NUMA node" in d["b"]["why"]
+        else:
+            assert d["after"] == d["before"] and "not bound" in d["b"]["why"]
+
+
+def test_pool_starts_at_most_two_workers_per_gpu_and_prints_its_placement():
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parents[1] / "opencv-opencl_amd" / "lib" / "nv12_stream"
+    r = subprocess.run([str(exe), "--width", "1280", "--height", "720", "--frames", "200", "--workers", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    n_gpu = mi_lumaeq.device_count()
+    started = min(5, 2 * n_gpu)
+    if started < 5:
+        assert f"workers: 5 requested, {started} started" in r.stdout
+    assert r.stdout.count("placement: worker ") == started and "placement: submitting thread" in r.stdout
+    assert "done: 200 frames" in r.stdout and "errors=0" in r.stdout
+    r = subprocess.run([str(exe), "--width", "1280", "--height", "720", "--frames", "100", "--workers", "3", "--max-workers-per-gpu", "0", "--no-numa-bind"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("placement: worker ") == 3 and "NUMA binding off" in r.stdout and "errors=0" in r.stdout
+
+
+def test_pinned_staged_transfer_helpers_round_trip():
+    """mi_lumaeq.xfer: what tests, bench.py and smoke() move data with instead of torch's pageable .to() / .cpu()."""
+    rng = np.random.default_rng(3)
+    for shape, dt in (((3, 1080 * 1920 * 3 // 2), np.uint8), ((2, 64, 48), np.int16), ((7,), np.int32), ((0,), np.uint8)):
+        a = rng.integers(0, 200, shape).astype(dt)
+        d = xfer.to_device(a)
+        assert d.is_cuda and tuple(d.shape) == a.shape
+        back = xfer.to_host(d)
+        assert back.dtype == a.dtype and np.array_equal(back, a) and back.flags.writeable
+    v = xfer.to_device(np.arange(100, dtype=np.uint8).reshape(10, 10))[::2, 1:5]      # a non-contiguous device view
+    assert np.array_equal(xfer.to_host(v), np.arange(100, dtype=np.uint8).reshape(10, 10)[::2, 1:5])
