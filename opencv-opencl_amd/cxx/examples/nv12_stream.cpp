@@ -15,6 +15,8 @@
 // (write only every K-th delivered frame to --output), --no-numa-bind (do not bind each worker to the CPUs of its GPU's NUMA node;
 // the binding is printed in the banner), --max-workers-per-gpu K (default 2; 0 = no cap).  --workers may exceed the GPU count
 // (worker w -> GPU w mod N), up to 64; at most K of them are started per GPU.
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -76,7 +78,25 @@ int main(int argc, char** argv)
         mi_numa_binding nb{};
         main_placement = std::string("submitting thread + frame ring: ") + (mi_thread_bind_near_device(0, &nb) == MI_OK ? nb.why : "not bound");
     }
-    std::vector<std::vector<unsigned char>> in(ring, std::vector<unsigned char>(fb)), out(ring, std::vector<unsigned char>(fb));
+    // Workers on SEVERAL GPUs in this one process: frame k goes to worker k mod N and lives in ring slot k mod 32, so when N divides 32
+    // slot s always feeds the same worker -- its two frames are first-touched from a thread bound next to that worker's GPU.
+    const int ndev = std::max(1, getDeviceCount());
+    const int eff_workers = per_gpu >= 1 ? std::min(workers, ndev * per_gpu) : workers;
+    std::vector<std::vector<unsigned char>> in(ring), out(ring);
+    if (numa_bind && eff_workers > 1 && ndev > 1 && ring % eff_workers == 0) {
+        cpu_set_t all;
+        CPU_ZERO(&all);
+        const bool have_all = sched_getaffinity(0, sizeof all, &all) == 0;
+        for (int s = 0; s < ring; ++s) {
+            mi_numa_binding nb{};
+            (void)mi_thread_bind_near_device((s % eff_workers) % ndev, &nb);
+            in[s].assign(fb, 0); out[s].assign(fb, 0);                                   // value-initialisation = first touch
+            if (have_all) (void)sched_setaffinity(0, sizeof all, &all);
+        }
+        main_placement = "submitting thread: not bound; frame ring: each slot first-touched next to the GPU of the worker it feeds";
+    } else {
+        for (int s = 0; s < ring; ++s) { in[s].assign(fb, 0); out[s].assign(fb, 0); }
+    }
     FILE* fin = input.empty() ? nullptr : fopen(input.c_str(), "rb");
     FILE* fout = output.empty() ? nullptr : fopen(output.c_str(), "wb");
     if (!input.empty() && !fin) { fprintf(stderr, "cannot open %s\n", input.c_str()); return 1; }
