@@ -34,3 +34,14 @@ def test_copy_crew_under_thread_sanitizer():
     r = subprocess.run([str(CXX / "test_host_helpers_tsan")], capture_output=True, text=True, timeout=600)
     assert "ThreadSanitizer" not in r.stderr, r.stderr
     assert r.returncode == 0 and "host helpers ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not shutil.which("g++"), reason="no g++")
+def test_host_helpers_under_address_and_ub_sanitizers():
+    r = subprocess.run(["make", "-C", str(CXX), "test_host_helpers_asan"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no AddressSanitizer runtime for g++ here: " + r.stderr[-200:])
+    r = subprocess.run([str(CXX / "test_host_helpers_asan")], capture_output=True, text=True, timeout=600,
+                       env={"ASAN_OPTIONS": "detect_leaks=1", "PATH": "/usr/bin:/bin"})
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "host helpers ok" in r.stdout, r.stdout + r.stderr
