@@ -212,8 +212,9 @@ mi_status mi_host_unregister(void* ptr);
  * The reference's worker maps a frame, runs the op, rebuilds the NV12 frame and pushes it downstream, one frame at
  * a time (OpenCVequalHist.cpp:102-196); its accelerator variant blocks on each of write, write, task, read
  * (OpenCLequalHist.cpp:356-365).  A pipe is that worker's device side with up to `depth` frames in flight: the upload
- * of frame k+2, the kernels of frame k+1 and the download of frame k run concurrently (three HIP streams, both DMA
- * directions busy), so ONE host thread per GPU keeps the link full.  Frames are tightly packed NV12 in host memory
+ * of frame k+2, the kernels of frame k+1 and the download of frame k run concurrently (two upload lanes, one compute
+ * stream, two download lanes per device, shared by all pipes of the process; both DMA directions busy), so ONE host
+ * thread per GPU keeps the link full.  Frames are tightly packed NV12 in host memory
  * (W*H + W*H/2 bytes), caller-owned from mi_pipe_submit until the mi_pipe_wait that returns them; completion is in
  * submission order.  Register recycled frame buffers once with mi_host_register (a GstBufferPool's memory): their
  * copies are then fully asynchronous.  Unpinned (pageable) memory is accepted -- the calling thread copies it into / out of

@@ -919,6 +919,43 @@ def test_clahe16_value_ranges(ctx, cfg):
     assert np.array_equal(host(d).view(np.uint16), out)
 
 
+def test_clahe16_twelve_bit_bet_mixed_outcomes(ctx):
+    """The 12-bit fast path of the 16-bit tile histograms (4096 bins x 4 LDS copies, LUT folded in) bets per TILE that every value is
+    < 4096.  Frames where the bet holds everywhere, where ONE tile loses it late (a single bright pixel in its last row), where one
+    loses it at once (bright pixels in the first vectors), where a whole frame is wide -- in one batch, so that tiles whose LUT was
+    written by the fast path sit in frames whose range exceeds 4096 and must be redone by the LUT kernel -- and with the option off."""
+    w, h = 640, 368                                                # 8x8 tiles of 80 x 46: vector geometry (80 % 8 == 0, no padding)
+    rng = np.random.default_rng(12)
+    base = rng.integers(0, 4096, (h, w), dtype=np.uint16)
+    f_all12 = base.copy()
+    f_late = base.copy(); f_late[45, 79] = 60000                  # last pixel of tile (0, 0)
+    f_early = base.copy(); f_early[46:48, 80:160] = 9000          # first rows of tile (1, 1)
+    f_one_high = base.copy(); f_one_high[200, 300] = 4096         # the smallest value that loses the bet
+    f_max12 = base.copy(); f_max12[100, 100] = 4095; f_max12[0, 0] = 0
+    f_wide = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+    f_const = np.full((h, w), 4095, np.uint16)
+    frames = [f_all12, f_late, f_early, f_one_high, f_max12, f_wide, f_const]
+    for cfg in ((2.0, 8, 8), (0.0, 8, 8), (40.0, 4, 8)):
+        want = [oracle.clahe16(f, *cfg) for f in frames]
+        try:
+            for fast in (1, 0):
+                ctx.set_option("clahe16_fast12", fast)
+                for k, f in enumerate(frames):
+                    assert np.array_equal(ctx.clahe16(f, *cfg), want[k]), (cfg, fast, "single", k)
+                d_in = dev(np.stack(frames).view(np.int16))
+                d_out = torch.empty_like(d_in)
+                ctx.clahe16_batch_dev(d_in, d_out, w, h, len(frames), *cfg)
+                ctx.synchronize()
+                out = host(d_out).view(np.uint16)
+                for k in range(len(frames)):
+                    assert np.array_equal(out[k], want[k]), (cfg, fast, "batch", k)
+                ctx.clahe16_batch_dev(d_in, d_in, w, h, len(frames), *cfg)            # in place
+                ctx.synchronize()
+                assert np.array_equal(host(d_in).view(np.uint16), out), (cfg, fast, "in place")
+        finally:
+            ctx.set_option("clahe16_fast12", 1)
+
+
 def test_clahe16_batch_and_errors(ctx):
     w, h, n = 320, 180, 3
     rng = np.random.default_rng(3)
