@@ -389,7 +389,8 @@ def main():
                       "p50_ms_max": red(mine.get("p50_ms", -1.0), "max"), "p99_ms_max": red(mine.get("p99_ms", -1.0), "max"),
                       "max_ms_max": red(mine.get("max_ms", -1.0), "max"), "late_total": int(red(mine.get("late", 0), "sum")),
                       "errors_total": int(red(mine.get("errors", 0), "sum")),
-                      "unpaced_frames_per_s_total": round(red(mine.get("unpaced_frames_per_s", 0.0), "sum"), 1)}
+                      "unpaced_frames_per_s_total": round(red(mine.get("unpaced_frames_per_s", 0.0), "sum"), 1),
+                      "placement_rank0": mine.get("placement")}          # NUMA binding of rank 0's streamer (every rank prints its own)
     # ---- kernel timing of THIS rank, then the figures every rank contributes to (before anybody leaves) ----------------
     # Algorithmic bytes per frame (SURVEY.md 8d / DESIGN.md): equalizeHist on Y = 3*W*H (histogram read +
     # apply read + apply write); + UV fill W*H/2 (write) or UV copy 2*(W*H/2).  The fused kernel performs
