@@ -206,6 +206,15 @@ inline void check(mi_ctx* c, mi_status st, const char* what)
 inline void setDevice(int device) { detail::tls_device() = device; }
 inline int getDevice() { return detail::tls_device(); }
 inline int getDeviceCount() { return mi_device_count(); }
+// Bind the CALLING thread to the CPUs next to `device` (its NUMA node) -- call it at the top of a worker, before the first
+// micv:: call of that thread creates its context (mi_thread_bind_near_device; the reference's workers are not placed at all,
+// OpenCVequalHist.cpp:397-402).  Returns the one-line description for a log; never throws for a platform without NUMA information.
+inline std::string bindThreadNearDevice(int device)
+{
+    mi_numa_binding nb{};
+    const mi_status st = mi_thread_bind_near_device(device, &nb);
+    return st == MI_OK ? std::string(nb.why) : std::string("not bound: ") + mi_status_str(st);
+}
 // Library option of the calling thread's context on its current device (mi_ctx_set_option), e.g.
 //   setOption("clahe_fp_contract", 1)  -- CLAHE interpolation with the fused multiply-adds a GCC build of OpenCV uses on
 //   FMA targets (the reference's aarch64 board) instead of the separately rounded x86-64 baseline arithmetic.
