@@ -98,6 +98,8 @@ struct mi_ctx {
     uint32_t* h_mirror = nullptr;                                // pinned, device-written: [g % 16] repaired launches, [16 + g % 16] unrecoverable
                                                                  // frames of hand-off block generation g
     uint64_t fused_repaired_base = 0, fused_hard_base = 0;       // ... of blocks since replaced
+    uint32_t* fused_hard_word = nullptr;                         // set by a pipe around its launch: pinned word of the frame's slot that receives
+                                                                 // the block's "frames refused" count if this launch refuses any (instead of the mirror)
     uint64_t fused_window_start_repaired = 0;                    // repaired launches seen when the current observation window began
     uint32_t fused_window_launches = 0;                          // fused launches issued in the window
     uint64_t fused_demotions = 0;                                // statistic "fused_demotions"

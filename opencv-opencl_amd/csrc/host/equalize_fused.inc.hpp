@@ -182,7 +182,7 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     j.lutpub = j.ghist + cap * 256;
     j.sflag = j.lutpub + cap * kLutPubWords;
     j.host_repaired = c->h_mirror + (c->fused_generation % kMirrorWords);
-    j.host_hard = j.host_repaired + kMirrorWords;
+    j.host_hard = c->fused_hard_word ? c->fused_hard_word : j.host_repaired + kMirrorWords;
     const long long grid = std::min<long long>(tickets, (long long)c->cu_count * c->fused_wgs_per_cu);
     if (!c->capturing) c->fused_pair_open = true;
     switch (vpt) {

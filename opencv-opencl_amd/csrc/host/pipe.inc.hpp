@@ -83,7 +83,15 @@ mi_status pipe_run_op(mi_pipe* p, PipeSlot& sl)
     UVJob uv{};
     const UVJob* puv = nullptr;
     if (p->uv_dev) { uv = nv12_uv(sl.d_in, sl.d_out, g.width, g.height, g.uv_mode); puv = &uv; }
-    return g.op == MI_OP_CLAHE ? clahe_dev(c, p->s_k, a, g.clip_limit, g.tiles_x, g.tiles_y, puv) : equalize_dev(c, p->s_k, a, puv);
+    if (g.op == MI_OP_CLAHE) return clahe_dev(c, p->s_k, a, g.clip_limit, g.tiles_x, g.tiles_y, puv);
+    // "frames the repair refused" of THIS launch goes straight into the slot's word of pinned host memory (written by the finish
+    // kernel, read by mi_pipe_wait after the frame's download): exact per frame, and no 4-byte copy behind every download
+    uint32_t* word = p->h_hard + (&sl - p->slots.data());
+    *word = 0;
+    c->fused_hard_word = word;
+    const mi_status st = equalize_dev(c, p->s_k, a, puv);
+    c->fused_hard_word = nullptr;
+    return st;
 }
 
 // The runtime multiplexes HIP streams onto a few hardware queues (4 per priority level), and a hardware queue executes its
@@ -305,8 +313,6 @@ mi_status mi_pipe_submit(mi_pipe* p, const uint8_t* in, uint8_t* out, uint64_t t
     HIPCHK(c, hipEventRecord(sl.ev_k, p->s_k));
     HIPCHK(c, hipStreamWaitEvent(s_d2h, sl.ev_k, 0));
     HIPCHK(c, hipMemcpyAsync(sl.out_staged ? sl.h_out : out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, s_d2h));
-    if (c->d_fused && p->cfg.op == MI_OP_EQUALIZE)
-        HIPCHK(c, hipMemcpyAsync(p->h_hard + (&sl - p->slots.data()), c->d_fused + kFusedStats + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s_d2h));
     HIPCHK(c, hipEventRecord(sl.ev_done, s_d2h));
     drain.done();                                                 // success: the frame stays in flight, that is the point of a pipe
     ++p->count; ++p->submitted; ++c->pipe_pending;
