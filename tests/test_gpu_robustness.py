@@ -362,3 +362,107 @@ def test_pinned_staged_transfer_helpers_round_trip():
         assert back.dtype == a.dtype and np.array_equal(back, a) and back.flags.writeable
     v = xfer.to_device(np.arange(100, dtype=np.uint8).reshape(10, 10))[::2, 1:5]      # a non-contiguous device view
     assert np.array_equal(xfer.to_host(v), np.arange(100, dtype=np.uint8).reshape(10, 10)[::2, 1:5])
+
+
+def test_host_forms_randomized_memory_kinds_pitches_and_options():
+    """Differential run over the host-pointer forms' staging machinery: random sizes (below and above the helper thread's and the
+    chunking's thresholds), row pitches, pinned / unpinned / registered planes in every combination, in place, one or two copy streams,
+    one or two copying threads -- every result against the oracle."""
+    rng = np.random.default_rng(2026)
+    sizes = [(1, 1), (17, 3), (640, 360), (1279, 719), (1920, 1080), (2048, 1024), (4096, 8), (8, 4096), (3840, 2160)]
+    with mi_lumaeq.Context(0) as c:
+        for case in range(48):
+            w, h = sizes[case % len(sizes)] if case < 2 * len(sizes) else (int(rng.integers(1, 2500)), int(rng.integers(1, 1500)))
+            pad_s, pad_d = int(rng.integers(0, 3)) * 16 + int(rng.integers(0, 2)) * 5, int(rng.integers(0, 3)) * 32
+            kind_s, kind_d = rng.integers(0, 3, 2)                # 0 ordinary numpy, 1 pinned torch memory, 2 registered numpy
+            if (w + max(pad_s, pad_d)) * h > 12_000_000:
+                pad_s = pad_d = 0
+
+            def plane(kind, pad, fill):
+                shape = (h, w + pad)
+                if kind == 1:
+                    t = torch.empty(shape, dtype=torch.uint8).pin_memory()
+                    a = t.numpy()
+                    keep = t
+                else:
+                    a = np.empty(shape, np.uint8)
+                    keep = a
+                    if kind == 2 and a.nbytes >= (1 << 20):        # (small arrays share heap pages with their neighbours: leave them alone)
+                        mi_lumaeq.host_register(a)
+                        registered.append(a)
+                a[:] = fill
+                return a, keep
+            registered = []
+            src_full, keep_s = plane(kind_s, pad_s, 0)
+            dst_full, keep_d = plane(kind_d, pad_d, 0xEE)
+            try:
+                y = rng.integers(0, 256, (h, w), dtype=np.uint8) if case % 3 else synth.y_plane(w, h, synth.DISTS[case % 5], case)
+                src_full[:, :w] = y
+                src, dst = src_full[:, :w], dst_full[:, :w]
+                c.set_option("host_copy_streams", int(rng.integers(1, 3)))
+                c.set_option("host_copy_threads", int(rng.integers(1, 3)))
+                op = case % 4
+                if op == 0:
+                    got, want = c.equalize_hist(src, dst), oracle.equalize_hist(y)
+                elif op == 1:
+                    cfg = (float(rng.choice([0.0, 2.0, 40.0])), int(rng.integers(1, 9)), int(rng.integers(1, 9)))
+                    got, want = c.clahe(src, *cfg, dst=dst), oracle.clahe(y, *cfg)
+                elif op == 2:                                      # in place on the source view
+                    want = oracle.equalize_hist(y)
+                    got = c.equalize_hist(src, src)
+                else:                                              # whole NV12 frame (tight), UV copy or fill
+                    w2, h2 = max(2, w & ~1), max(2, h & ~1)
+                    f = synth.nv12_frame(w2, h2, synth.DISTS[case % 5], case)
+                    uv = int(rng.integers(0, 2))
+                    got, want = c.equalize_hist_nv12(f, w2, h2, uv), oracle.nv12_frame(f, w2, h2, uv_mode=uv, op=0)
+                assert np.array_equal(got, want), (case, w, h, op, int(kind_s), int(kind_d), pad_s, pad_d)
+                if op in (0, 1) and pad_d:
+                    assert (dst_full[:, w:] == 0xEE).all(), (case, "bytes beyond the view were written")
+            finally:
+                for a in registered:
+                    mi_lumaeq.host_unregister(a)
+        assert c.get_stat("error_drains") == 0 and c.get_stat("fused_hard_errors") == 0
+
+
+def test_pipe_randomized_sessions():
+    """Random pipe sessions: op, UV mode and policy, depth, pinned / unpinned / mixed frame memory, random interleaving of submit and
+    wait (including BUSY answers when the pipe is full) -- every frame comes back under its own tag, in order, with the oracle's bytes."""
+    rng = np.random.default_rng(77)
+    for session in range(10):
+        w, h = [(640, 360), (1280, 720), (322, 182), (1920, 1080)][session % 4]
+        op = [mi_lumaeq.OP_EQUALIZE, mi_lumaeq.OP_CLAHE, mi_lumaeq.OP_EQUALIZE, mi_lumaeq.OP_CHANNELS][session % 4]
+        uv = int(rng.integers(0, 2))
+        policy = [mi_lumaeq.PIPE_UV_AUTO, mi_lumaeq.PIPE_UV_HOST, mi_lumaeq.PIPE_UV_DEVICE][session % 3]
+        depth = int(rng.integers(2, 7))
+        n = 14
+        frames = [synth.nv12_frame(w, h, synth.DISTS[k % 5], 1000 * session + k) for k in range(n)]
+        if op == mi_lumaeq.OP_CHANNELS:
+            want = [oracle.nv12_bgr_equalize(f, w, h) for f in frames]
+        else:
+            want = [oracle.nv12_frame(f, w, h, uv_mode=uv, op=1 if op == mi_lumaeq.OP_CLAHE else 0, clip_limit=2.0, tiles_x=4, tiles_y=2) for f in frames]
+        outs = [np.zeros_like(f) for f in frames]
+        registered = []
+        for k in range(n):                                         # a random subset of the buffers is registered (pinned)
+            for a in (frames[k], outs[k]):
+                if a.nbytes >= (1 << 19) and rng.integers(0, 2):
+                    mi_lumaeq.host_register(a)
+                    registered.append(a)
+        c = mi_lumaeq.Context(0)
+        try:
+            with mi_lumaeq.Pipe(c, w, h, op=op, uv_mode=uv, clip_limit=2.0, tiles_x=4, tiles_y=2, depth=depth, uv_policy=policy) as pipe:
+                nxt, done = 0, 0
+                while done < n:
+                    if nxt < n and (pipe.pending == 0 or rng.integers(0, 3)):
+                        if pipe.submit(frames[nxt], outs[nxt], 5000 + nxt):
+                            nxt += 1
+                            continue
+                        assert pipe.pending == pipe.depth          # BUSY only when full
+                    tag, out = pipe.wait()
+                    assert tag == 5000 + done and out is outs[done]
+                    assert np.array_equal(out, want[done]), (session, done, op, uv, policy, depth)
+                    done += 1
+                assert pipe.pending == 0
+        finally:
+            c.close()
+            for a in registered:
+                mi_lumaeq.host_unregister(a)
