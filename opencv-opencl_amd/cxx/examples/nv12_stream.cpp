@@ -128,7 +128,7 @@ int main(int argc, char** argv)
         printf("nv12_stream: %dx%d %s uv=%s (uv-policy %s) workers=%d depth=%d gpus=%d frames=%d%s%s\n", width, height, op.c_str(), uv.c_str(),
                uv_policy.c_str(), pool.workers(), depth, getDeviceCount(), frames, paced ? " paced" : "", pin ? " pinned-ring" : " pageable-ring");
         if (pool.workers() != pool.requested())
-            printf("workers: %d requested, %d started (at most %d per GPU: more only add contention on the copy engines)\n", pool.requested(), pool.workers(), per_gpu);
+            printf("workers: %d requested, %d started (at most %d per GPU: one keeps the link busy, more never help)\n", pool.requested(), pool.workers(), per_gpu);
         printf("placement: %s\n", main_placement.c_str());
         for (const std::string& line : pool.placement()) printf("placement: %s\n", line.c_str());
         // synthetic source: the ring's frames exist before the clock starts (a camera / decoder hands over finished frames;

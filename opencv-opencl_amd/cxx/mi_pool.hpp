@@ -66,10 +66,9 @@ public:
         const int ndev = getDeviceCount();
         if (ndev <= 0) MI_CV_ERROR(GpuNotSupported, "no HIP device (this backend has no CPU fallback)");
         // The reference's --workers N buys CPU parallelism (OpenCVequalHist.cpp:397-402).  Here a worker only feeds a GPU, and ONE
-        // worker already keeps a GPU's copy engines ~95 % busy (5.4 k 4K frames/s); two are no slower; four on one GPU were measured
-        // at 2.4 k frames/s -- sixteen frames in flight make the runtime spread the copies over more DMA engines, and single
-        // transfers then take 4x as long (profiles/r03_c_nv12_stream_workers.txt).  So at most `max_workers_per_gpu` workers are
-        // started per GPU; requested() still reports what was asked for.
+        // worker already keeps a GPU's download engine ~95 % busy (5.4 k 4K frames/s); two are no slower; three to eight on one GPU
+        // run at 4.9-5.05 k (profiles/r03_c_nv12_stream_crowd.txt).  So at most `max_workers_per_gpu` workers are started per GPU;
+        // requested() still reports what was asked for.
         requested_ = workers;
         if (max_workers_per_gpu >= 1 && workers > ndev * max_workers_per_gpu) workers = ndev * max_workers_per_gpu;
         queues_.resize(workers);
