@@ -572,6 +572,24 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
                 "lut_apply_kernel": {"avg_ms": round(a_ms, 5), "alg_GBs": round((2 * ysz + uvb) * Bq / (a_ms * 1e-3) / 1e9, 1),
                                      "frac_of_8TBs": round((2 * ysz + uvb) * Bq / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "hist_partial_kernel": {"avg_ms": round(h_ms, 5), "alg_GBs": round(ysz * Bq / (h_ms * 1e-3) / 1e9, 1)}}
+            # ... and the histogram stage on its own (mi_hist_u8_batch_dev in a loop): inside the three-kernel sequence it runs behind the
+            # previous call's 0.8 GB write drain, which is charged to whoever runs next; alone it shows what the kernel itself does
+            d_hist = torch.empty((Bq, 256), dtype=torch.int32, device="cuda")
+            fs = w * h * 3 // 2
+            for _ in range(3):
+                ctx.hist_batch_dev(q_in, w, h, Bq, d_hist, src_frame=fs)
+            ctx.synchronize()
+            ctx.profile_read(reset=True)
+            ctx.set_profiling(True)
+            for _ in range(20):
+                ctx.hist_batch_dev(q_in, w, h, Bq, d_hist, src_frame=fs)
+            ctx.set_profiling(False)
+            pr2 = ctx.profile_read(reset=True)["hist_partial_kernel"]
+            if pr2["launches"]:
+                i_ms = pr2["total_ms"] / pr2["launches"]
+                res["three_kernel_path"]["hist_partial_kernel_alone"] = {"avg_ms": round(i_ms, 5), "alg_GBs": round(ysz * Bq / (i_ms * 1e-3) / 1e9, 1),
+                                                                         "frac_of_8TBs": round(ysz * Bq / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del d_hist
         del q_in, q_out
     # north star: throughput on 1920x1080 as well as 3840x2160 (same path, 256-frame batches = the same bytes per step)
     if (w, h) == (3840, 2160) and args.op == "equalize":
