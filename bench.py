@@ -720,6 +720,24 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
         ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream)
     ms = timeit(lambda: ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, B, mi_lumaeq.UV_FILL128, 2.0, 8, 8, stream=stream), 100)
     res["clahe8x8_batch_frames_per_s"] = round(B / (ms * 1e-3), 1)
+    # the tile-histogram (+ clip + LUT) pass on its own: inside the CLAHE sequence it runs behind the interpolation's 0.8 GB write drain
+    d_luts = torch.empty((B, 64, 256), dtype=torch.uint8, device="cuda")
+    fs = w * h * 3 // 2
+    for _ in range(3):
+        ctx.clahe_tile_luts_batch_dev(d_in, w, h, B, 2.0, 8, 8, d_luts, src_frame=fs, stream=stream)
+    torch.cuda.synchronize()
+    ctx.profile_read(reset=True)
+    ctx.set_profiling(True)
+    for _ in range(20):
+        ctx.clahe_tile_luts_batch_dev(d_in, w, h, B, 2.0, 8, 8, d_luts, src_frame=fs, stream=stream)
+    ctx.set_profiling(False)
+    torch.cuda.synchronize()
+    th = ctx.profile_read(reset=True)["tile_hist_kernel"]
+    if th["launches"]:
+        t_ms = th["total_ms"] / th["launches"]
+        res["clahe_tile_hist_kernel_alone"] = {"avg_ms": round(t_ms, 5), "alg_GBs": round(w * h * B / (t_ms * 1e-3) / 1e9, 1),
+                                               "frac_of_8TBs": round(w * h * B / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del d_luts
     res["clahe8x8_batch_whole_path_frac_of_8TBs"] = round((3 * w * h + w * h // 2) * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     del d_in, d_out
     # BASELINE.json configs[4] taken literally (parity unpinned): BGR -> YUV -> equalize Y -> BGR on
