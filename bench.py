@@ -192,7 +192,15 @@ def cpu_baseline(args, w, h):
         oracle.nv12_frame(f1080[d2 % 4], 1920, 1080, uv_mode=uv_mode, op=op)
         d2 += 1
     fps1080 = d2 / (time.perf_counter() - t2)
-    return {"value": round(multi, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(multi, 2), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": cpu_model,
             "sample": f"{done} x {w}x{h} NV12 frames ({args.dist}, {args.op}, uv={args.uv}) in {el:.1f} s, "
                       f"OpenMP row/tile-striped CPU restatement of OpenCV 4.4 (oracle/lumaeq_oracle.c), "
                       f"host has {os.cpu_count()} logical CPUs",
