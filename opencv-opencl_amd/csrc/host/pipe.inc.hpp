@@ -49,6 +49,7 @@ struct PipeStreams {
 static std::mutex g_pipe_streams_mu;
 static PipeStreams g_pipe_streams[kMaxDevices];
 static std::atomic<uint32_t> g_pipe_lane[kMaxDevices];          // frames submitted on the device by ALL pipes: picks the copy lane
+static std::atomic<int> g_pipe_users[kMaxDevices];               // pipes sharing the device's streams (PipeStreams::users, readable without its lock)
 // One frame's enqueue sequence (H2D, event, wait, kernels, event, wait, D2H, event) is issued under this per-device lock.  The
 // runtime dispatches directly from the calling thread and some of these calls block for tens of microseconds while holding the
 // stream's lock; two workers interleaving their calls on the shared streams call by call made EACH sequence slower (2 workers
@@ -128,6 +129,7 @@ void pipe_free(mi_pipe* p)
     } else if (p->s_k) {
         std::lock_guard<std::mutex> lk(g_pipe_streams_mu);
         PipeStreams& ps = g_pipe_streams[p->c->device];
+        g_pipe_users[p->c->device].fetch_sub(1, std::memory_order_relaxed);
         if (--ps.users == 0) {
             for (int i = 0; i < 5; ++i) if (*ps.all(i)) (void)hipStreamDestroy(*ps.all(i));
             ps = PipeStreams{};
@@ -192,6 +194,7 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
             }
         }
         ++ps.users;
+        g_pipe_users[c->device].fetch_add(1, std::memory_order_relaxed);
         p->s_h2d[0] = ps.h2d[0]; p->s_h2d[1] = ps.h2d[1]; p->s_k = ps.k; p->s_d2h[0] = ps.d2h[0]; p->s_d2h[1] = ps.d2h[1];
         p->n_copy = c->pipe_copy_streams > 1 ? 2 : 1;
     }
@@ -302,7 +305,7 @@ mi_status mi_pipe_submit(mi_pipe* p, const uint8_t* in, uint8_t* out, uint64_t t
     // consecutive frames ON THE DEVICE (whichever pipe they come from) travel on alternate copy streams
     // (with more than two pipes feeding one device both lanes of a direction end up with deep queues and single transfers were
     // measured 4x slower -- 2.4 k frames/s for four workers against 4.7 k on one lane: such a crowd shares lane 0)
-    const bool crowd = !p->private_streams && g_pipe_streams[c->device].users > 2;
+    const bool crowd = !p->private_streams && g_pipe_users[c->device].load(std::memory_order_relaxed) > 2;
     sl.lane = (p->n_copy > 1 && !crowd) ? (int)(g_pipe_lane[c->device].fetch_add(1, std::memory_order_relaxed) & 1) : 0;
     hipStream_t s_h2d = p->s_h2d[sl.lane], s_d2h = p->s_d2h[sl.lane];
     StreamDrain drain(HipStreamSync{}, drain_counter(c));
