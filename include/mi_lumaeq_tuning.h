@@ -18,6 +18,11 @@
                                                            * registers between the histogram and the apply pass (slice = 256 x VPT x 16 B) */
 #define MI_OPT_FUSED_ACQUIRE       "fused_acquire"       /* 1/0, default 1: agent-scope acquire before a consumer reads the LUT       */
 
+/* equalizeHist on few frames */
+#define MI_OPT_TWO_KERNEL_MAX      "two_kernel_max_frames" /* 0..64, default 2: calls of up to this many frames (twice as many when a frame is
+                                                           * 1080p-sized or smaller) run as histogram + LUT in one launch (the last workgroup
+                                                           * writes the LUT) followed by the apply kernel, instead of the fused pair; 0 = never */
+
 /* CLAHE (8-bit) */
 #define MI_OPT_CLAHE_XCD_MAP       "clahe_xcd_map"       /* 1/0, default 1: XCD-aware tile order of the tile-histogram pass           */
 #define MI_OPT_CLAHE_HIST_THREADS  "clahe_hist_threads"  /* 256 / 512, default 512: threads per tile-histogram workgroup              */

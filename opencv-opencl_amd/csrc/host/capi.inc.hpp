@@ -163,6 +163,7 @@ void mi_ctx_destroy(mi_ctx* c)
     for (auto e : c->chunk_events) (void)hipEventDestroy(e);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_luts) (void)hipFree(c->d_luts);
+    if (c->d_ghist) (void)hipFree(c->d_ghist);
     if (c->d_fused) (void)hipFree(c->d_fused);
     for (void* q : c->retired) (void)hipFree(q);
     if (c->d_planes) (void)hipFree(c->d_planes);
@@ -268,6 +269,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "fused_reprobe_ms")) { c->fused_reprobe_ms = c->fused_reprobe_ms_now = std::max(1, value); return MI_OK; }
     if (!strcmp(name, "clahe_fp_contract")) { c->clahe_fp_contract = value != 0; return MI_OK; }
     // ---- speed only (mi_lumaeq_tuning.h)
+    if (!strcmp(name, "two_kernel_max_frames")) { if (value < 0 || value > 64) return fail(c, MI_ERR_BAD_ARG, "two_kernel_max_frames must be 0..64"); c->two_kernel_max_frames = value; return MI_OK; }
     if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }
     if (!strcmp(name, "fused_vpt") && value == 0) { c->fused_vpt = kVPT; return MI_OK; }
     if (!strcmp(name, "fused_vpt")) { if (value != 8 && value != 16 && value != 20 && value != 24) return fail(c, MI_ERR_BAD_ARG, "fused_vpt must be 0 (default), 8, 16, 20 or 24"); c->fused_vpt = value; return MI_OK; }

@@ -199,8 +199,36 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     return MI_OK;
 }
 
+// One or two frames (a stream's frame, a cv::Mat call; up to four of 1080p or less): histogram + LUT in one launch whose last
+// workgroup writes the LUT, then the apply kernel.  No inter-workgroup waits, so no finish kernel and nothing to repair: 18 us per
+// 4K frame against 23 us for the fused pair, whose single read cannot pay for its hand-off latency on so little data.
+mi_status equalize_two_kernel_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
+{
+    const size_t need = (size_t)a.n_frames * (256 + 1) * sizeof(uint32_t);
+    if (need > c->ghist_bytes) {
+        mi_status st = grow_dev(c, &c->d_ghist, &c->ghist_bytes, std::max<size_t>(need, 64 * 257 * sizeof(uint32_t)));
+        if (st) return st;
+        HIPCHK(c, hipMemsetAsync(c->d_ghist, 0, c->ghist_bytes, s));      // once: every launch leaves the scratch zeroed
+    }
+    mi_status st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)a.n_frames * 256);
+    if (st) return st;
+    PlaneArgs b = a;
+    b.dst = nullptr;
+    const PlaneBatch p = make_plane(b);
+    const int B = blocks_per_frame(c, (long long)a.width * a.height, p.rows, a.n_frames, 256);
+    uint32_t* cnt = c->d_ghist + (size_t)a.n_frames * 256;
+    LAUNCH(c, s, MI_K_HIST, hist_lut_kernel, dim3(B, a.n_frames), dim3(kHistThreads), 0, p, c->d_ghist, cnt,
+           (int)((long long)a.width * a.height), c->d_luts);
+    return launch_apply(c, s, a, 0, a.n_frames, c->d_luts, uv);
+}
+
 mi_status equalize_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
+    // measured (profiles/r03_l_single_frame.txt, us per call, two-kernel / fused pair / three-kernel): 4K 1 frame 18.0 / 22.9 / 24.3,
+    // 2 frames 24.2 / 27.9 / 29.6, 3 frames 34.9 / 32.3 / 34.2; 1080p 4 frames 18.9 / 22.3 / 20.0, 8 frames 31.4 / 28.2 / 25.4
+    const long long px = (long long)a.width * a.height;
+    const int k2 = c->two_kernel_max_frames;
+    if (k2 > 0 && (a.n_frames <= k2 || (a.n_frames <= 2 * k2 && px <= 1920LL * 1088))) return equalize_two_kernel_dev(c, s, a, uv);
     if (fused_applicable(c, a, uv) && fused_admit(c)) return equalize_fused_dev(c, s, a, uv);
     for (int f0 = 0; f0 < a.n_frames; f0 += kMaxGridY) {
         const int nf = std::min(kMaxGridY, a.n_frames - f0);

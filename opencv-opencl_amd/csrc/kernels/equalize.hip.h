@@ -64,9 +64,9 @@ __device__ __forceinline__ void hist_rows(uint32_t* h, const uint8_t* row0, long
     }
 }
 
-__global__ __launch_bounds__(kHistThreads) void hist_partial_kernel(PlaneBatch p, uint32_t* __restrict__ partial)
+// this workgroup's share (blockIdx.x of gridDim.x) of frame blockIdx.y, counted into the LDS histogram h (zeroed here)
+__device__ __forceinline__ void hist_block(uint32_t* h, const PlaneBatch& p)
 {
-    __shared__ uint32_t h[256 * kCopies];
     const int t = threadIdx.x;
     for (int i = t; i < 256 * kCopies; i += kHistThreads) h[i] = 0;
     __syncthreads();
@@ -80,6 +80,13 @@ __global__ __launch_bounds__(kHistThreads) void hist_partial_kernel(PlaneBatch p
         for (int r = blockIdx.x; r < p.rows; r += gridDim.x) hist_flat<kHistThreads>(h, base + (long long)r * p.src_step, p.row_bytes, 0, 1);
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(kHistThreads) void hist_partial_kernel(PlaneBatch p, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[256 * kCopies];
+    hist_block(h, p);
+    const int t = threadIdx.x;
     if (t < 256) partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + t] = lds_hist_bin(h, t);
 }
 
@@ -127,6 +134,35 @@ __global__ __launch_bounds__(kThreads) void equalize_lut_kernel(const uint32_t* 
     for (; b < nparts; ++b) c += pp[(size_t)b * 256];
     if (hist_out) hist_out[(size_t)f * 256 + t] = (int32_t)c;
     if (!lut_out) return;
+    lut_out[(size_t)f * 256 + t] = equalize_lut_value(c, total, &sh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1+K2 in one launch for FEW frames (a single frame of a stream, a cv::Mat call): every workgroup adds its non-zero bins to the
+// frame's global histogram with agent-scope atomics and takes an arrival number; the LAST one to arrive exchanges the 256 counts
+// out (leaving the scratch zeroed for the next launch) and writes the LUT.  Nobody waits for anybody -- the "last block" pattern
+// has no inter-workgroup dependency, so unlike the fused kernel it needs neither bounded waits nor a finish kernel -- and one
+// launch (plus its gap) is gone against K1 -> K2.  With lut_apply_kernel behind it a single 4K frame costs two launches.
+// grid = (B, n_frames), 256 threads.  ghist[f][256] and cnt[f] must be zero on entry (they are zero again on exit).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kHistThreads) void hist_lut_kernel(PlaneBatch p, uint32_t* __restrict__ ghist, uint32_t* __restrict__ cnt,
+                                                                int total, uint8_t* __restrict__ lut_out)
+{
+    __shared__ uint32_t h[256 * kCopies];
+    __shared__ EqLutShared sh;
+    __shared__ int s_last;
+    hist_block(h, p);
+    const int t = threadIdx.x, f = blockIdx.y;
+    uint32_t* gh = ghist + (size_t)f * 256;
+    const uint32_t mine = lds_hist_bin(h, t);
+    if (mine) __hip_atomic_fetch_add(gh + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's atomics have been performed at the L2
+    __syncthreads();
+    if (t == 0) s_last = __hip_atomic_fetch_add(cnt + f, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;                                            // uniform over the workgroup
+    const uint32_t c = __hip_atomic_exchange(gh + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // RMW at the L2: coherent by construction
+    if (t == 0) __hip_atomic_store(cnt + f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lut_out[(size_t)f * 256 + t] = equalize_lut_value(c, total, &sh);
 }
 

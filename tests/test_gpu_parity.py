@@ -25,7 +25,9 @@ host = xfer.to_host                                     # device tensor -> numpy
 def hooks_ctx():
     """A context of libmi_lumaeq_test.so: the product sources built with -DMI_TEST_HOOKS (fault injection into the fused kernel's
     hand-off, microsecond wait bounds, forced failures of checked HIP calls).  The product library knows none of these options."""
-    return mi_lumaeq.Context(0, lib=mi_lumaeq.test_lib())
+    c = mi_lumaeq.Context(0, lib=mi_lumaeq.test_lib())
+    c.set_option("two_kernel_max_frames", 0)      # these tests are about the fused kernel's hand-off: one- and two-frame calls must take it too
+    return c
 
 
 @pytest.mark.parametrize("shape", SMALL, ids=str)
@@ -351,6 +353,7 @@ def test_profiling_counters(ctx):
     d_in = dev(np.stack([synth.nv12_frame(w, h, "D1", k) for k in range(n)]))
     d_out = torch.empty_like(d_in)
     try:
+        ctx.set_option("two_kernel_max_frames", 0)                  # (a two-frame call would otherwise take the two-kernel path, checked last)
         for fused, names in ((1, ["equalize_fused_kernel", "fused_finish_kernel"]), (0, ["hist_partial_kernel", "equalize_lut_kernel", "lut_apply_kernel"])):
             ctx.set_option("fused", fused)
             ctx.profile_read(reset=True)
@@ -371,13 +374,26 @@ def test_profiling_counters(ctx):
         assert 0 < v["min_ms"] <= v["p10_ms"] <= v["p50_ms"] <= v["p90_ms"] <= v["max_ms"]
         assert v["min_ms"] <= v["total_ms"] / 12 <= v["max_ms"]
         assert ctx.profile_read(reset=True)["equalize_fused_kernel"]["max_ms"] == 0          # reset clears the samples
+        # default routing of a one- or two-frame call: histogram + LUT in ONE launch (its last workgroup writes the LUT), then the apply kernel
+        ctx.set_option("two_kernel_max_frames", 2)
+        ctx.set_profiling(True)
+        ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
+        p = ctx.profile_read(reset=True)
+        ctx.set_profiling(False)
+        assert {k for k, v in p.items() if v["launches"]} == {"hist_partial_kernel", "lut_apply_kernel"}
+        assert p["hist_partial_kernel"]["launches"] == 1 and p["lut_apply_kernel"]["launches"] == 1
+        src, out = host(d_in), host(d_out)
+        for k in range(n):
+            assert np.array_equal(out[k], oracle.nv12_frame(src[k], w, h, uv_mode=0, op=0))
     finally:
         ctx.set_option("fused", 1)
+        ctx.set_option("two_kernel_max_frames", 2)
         ctx.set_profiling(False)
 
 
 @pytest.mark.parametrize("opts", [dict(fused=0), dict(fused_vpt=8), dict(fused_vpt=16), dict(fused_vpt=20, fused_wgs_per_cu=2),
-                                  dict(fused_vpt=24, fused_acquire=0), dict(fused_wgs_per_cu=1)], ids=str)
+                                  dict(fused_vpt=24, fused_acquire=0), dict(fused_wgs_per_cu=1), dict(two_kernel_max_frames=64),
+                                  dict(two_kernel_max_frames=0), dict(two_kernel_max_frames=0, fused=0)], ids=str)
 def test_equalize_paths_agree(ctx, opts):
     """Three-kernel path and every fused-kernel configuration give the oracle's bytes (4K, 1080p, tiny, UV modes)."""
     try:
@@ -394,7 +410,7 @@ def test_equalize_paths_agree(ctx, opts):
                 for k in range(n):
                     assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), (w, h, k, uv_mode)
     finally:
-        for k, v in dict(fused=1, fused_vpt=20, fused_wgs_per_cu=4, fused_acquire=1).items():
+        for k, v in dict(fused=1, fused_vpt=20, fused_wgs_per_cu=4, fused_acquire=1, two_kernel_max_frames=2).items():
             ctx.set_option(k, v)
 
 

@@ -26,7 +26,9 @@ host = xfer.to_host                                     # device tensor -> numpy
 
 
 def hooks_ctx():
-    return mi_lumaeq.Context(0, lib=mi_lumaeq.test_lib())
+    c = mi_lumaeq.Context(0, lib=mi_lumaeq.test_lib())
+    c.set_option("two_kernel_max_frames", 0)      # these tests are about the fused kernel's hand-off: one- and two-frame calls must take it too
+    return c
 
 
 def test_product_library_knows_no_test_hook():
