@@ -12,6 +12,7 @@ TL = mi_lumaeq.test_lib()
 fused_a, fused_b, ref = mi_lumaeq.Context(0, lib=TL), mi_lumaeq.Context(0, lib=TL), mi_lumaeq.Context(0, lib=TL)
 for c_ in (fused_a, fused_b):
     c_.set_option("fused_demote_after", 0)                # the soak wants every launch on the fused path, however often it is repaired
+    c_.set_option("two_kernel_max_frames", 0)             # ... one- and two-frame batches included
 ref.set_option("fused", 0)
 shapes = [(3840, 2160), (1920, 1080), (1280, 720), (640, 360), (256, 64), (3840, 1088), (2560, 1440)]
 t0 = time.time(); launches = frames = mismatches = errors = 0
