@@ -199,8 +199,8 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     return MI_OK;
 }
 
-// One or two frames (a stream's frame, a cv::Mat call; up to four of 1080p or less): histogram + LUT in one launch whose last
-// workgroup writes the LUT, then the apply kernel.  No inter-workgroup waits, so no finish kernel and nothing to repair: 18 us per
+// Up to four frames (a stream's frame, a cv::Mat call; up to eight of 1080p or less): histogram + LUT in one launch whose last
+// workgroup writes the LUT, then the apply kernel.  No inter-workgroup waits, so no finish kernel and nothing to repair: 16.5 us per
 // 4K frame against 23 us for the fused pair, whose single read cannot pay for its hand-off latency on so little data.
 mi_status equalize_two_kernel_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
@@ -224,8 +224,9 @@ mi_status equalize_two_kernel_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, 
 
 mi_status equalize_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
-    // measured (profiles/r03_l_single_frame.txt, us per call, two-kernel / fused pair / three-kernel): 4K 1 frame 18.0 / 22.9 / 24.3,
-    // 2 frames 24.2 / 27.9 / 29.6, 3 frames 34.9 / 32.3 / 34.2; 1080p 4 frames 18.9 / 22.3 / 20.0, 8 frames 31.4 / 28.2 / 25.4
+    // measured (profiles/r03_l_single_frame.txt, us per call, two-kernel / fused pair / three-kernel): 4K 1 frame 16.5 / 22.8 / 24.5,
+    // 2 frames 21.9 / 27.8 / 29.9, 4 frames 34.6 / 38.5 / 36.8, 8 frames 57.8 / 52.3 / 53.2; 1080p 4 frames 17.3 / 22.1 / 19.9,
+    // 8 frames 27.1 / 28.3 / 25.1, 16 frames 45.0 / 39.1 / 35.4
     const long long px = (long long)a.width * a.height;
     const int k2 = c->two_kernel_max_frames;
     if (k2 > 0 && (a.n_frames <= k2 || (a.n_frames <= 2 * k2 && px <= 1920LL * 1088))) return equalize_two_kernel_dev(c, s, a, uv);

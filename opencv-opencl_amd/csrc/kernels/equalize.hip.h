@@ -158,7 +158,10 @@ __global__ __launch_bounds__(kHistThreads) void hist_lut_kernel(PlaneBatch p, ui
     if (mine) __hip_atomic_fetch_add(gh + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's atomics have been performed at the L2
     __syncthreads();
-    if (t == 0) s_last = __hip_atomic_fetch_add(cnt + f, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    // relaxed on purpose: everything the last workgroup reads arrives through atomics performed at the device's point of coherence
+    // (drained above by vmcnt(0)); an agent-scope acquire / release here would write back and invalidate this XCD's L2 once per
+    // workgroup (measured: 8 x 4K frames 88 us against 53 us for the three-kernel path)
+    if (t == 0) s_last = __hip_atomic_fetch_add(cnt + f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;                                            // uniform over the workgroup
     const uint32_t c = __hip_atomic_exchange(gh + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // RMW at the L2: coherent by construction

@@ -375,7 +375,7 @@ def test_profiling_counters(ctx):
         assert v["min_ms"] <= v["total_ms"] / 12 <= v["max_ms"]
         assert ctx.profile_read(reset=True)["equalize_fused_kernel"]["max_ms"] == 0          # reset clears the samples
         # default routing of a one- or two-frame call: histogram + LUT in ONE launch (its last workgroup writes the LUT), then the apply kernel
-        ctx.set_option("two_kernel_max_frames", 2)
+        ctx.set_option("two_kernel_max_frames", 4)
         ctx.set_profiling(True)
         ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
         p = ctx.profile_read(reset=True)
@@ -387,7 +387,7 @@ def test_profiling_counters(ctx):
             assert np.array_equal(out[k], oracle.nv12_frame(src[k], w, h, uv_mode=0, op=0))
     finally:
         ctx.set_option("fused", 1)
-        ctx.set_option("two_kernel_max_frames", 2)
+        ctx.set_option("two_kernel_max_frames", 4)
         ctx.set_profiling(False)
 
 
@@ -397,6 +397,8 @@ def test_profiling_counters(ctx):
 def test_equalize_paths_agree(ctx, opts):
     """Three-kernel path and every fused-kernel configuration give the oracle's bytes (4K, 1080p, tiny, UV modes)."""
     try:
+        if "two_kernel_max_frames" not in opts:
+            ctx.set_option("two_kernel_max_frames", 0)              # these configurations are about the fused / three-kernel paths: keep small batches on them
         for k, v in opts.items():
             ctx.set_option(k, v)
         for (w, h, n) in [(3840, 2160, 3), (1920, 1080, 5), (64, 36, 7), (16, 1, 2)]:
@@ -410,7 +412,7 @@ def test_equalize_paths_agree(ctx, opts):
                 for k in range(n):
                     assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), (w, h, k, uv_mode)
     finally:
-        for k, v in dict(fused=1, fused_vpt=20, fused_wgs_per_cu=4, fused_acquire=1, two_kernel_max_frames=2).items():
+        for k, v in dict(fused=1, fused_vpt=20, fused_wgs_per_cu=4, fused_acquire=1, two_kernel_max_frames=4).items():
             ctx.set_option(k, v)
 
 
@@ -625,6 +627,8 @@ def test_many_contexts_share_one_gpu():
     want = [oracle.nv12_frame(frames[k], w, h, uv_mode=0, op=0) for k in range(n)]
     ctxs = [mi_lumaeq.Context(0) for _ in range(7)]
     try:
+        for c in ctxs:
+            c.set_option("two_kernel_max_frames", 0)               # four 1080p frames would take the two-kernel path: this test is about the fused slots
         outs = [torch.zeros_like(d_in) for _ in ctxs]
         for c, o in zip(ctxs, outs):
             c.equalize_hist_nv12_batch_dev(d_in, o, w, h, n, 0, stream=mi_lumaeq.STREAM_CTX)   # 7 private streams, concurrently
@@ -672,6 +676,7 @@ def test_hip_graph_capture_and_replay():
     w, h, n = 1920, 1080, 6
     c = mi_lumaeq.Context(0)
     try:
+        c.set_option("two_kernel_max_frames", 0)                    # capture the FUSED pair (six 1080p frames would otherwise be routed to the two-kernel path, captured below)
         d_in = synth.nv12_batch_torch(w, h, n, "D2", "cuda:0", seed=11)
         d_out = torch.zeros_like(d_in)
         c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 1)            # warm-up: allocations happen here, not in the capture
@@ -698,8 +703,22 @@ def test_hip_graph_capture_and_replay():
         g2.replay()
         torch.cuda.synchronize()
         assert np.array_equal(host(d_out[1]), oracle.nv12_frame(host(d_in[1]), w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
+        # the default routing of few frames (histogram + LUT in one launch, then apply) is capturable as well
+        c.set_option("two_kernel_max_frames", 4)
+        c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, 2, 1)            # sizes its scratch eagerly
+        c.synchronize()
+        g4 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g4):
+            c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, 2, 1, stream=torch.cuda.current_stream().cuda_stream)
+        for rep in range(2):
+            d_in.copy_(synth.nv12_batch_torch(w, h, n, synth.DISTS[3 + rep], "cuda:0", seed=900 + rep))
+            d_out.zero_()
+            g4.replay()
+            torch.cuda.synchronize()
+            for k in range(2):
+                assert np.array_equal(host(d_out[k]), oracle.nv12_frame(host(d_in[k]), w, h, uv_mode=1, op=0)), (rep, k)
         # destroy the graphs while the context (whose scratch their kernel nodes point at) is still alive
-        del g, g2
+        del g, g2, g4
         torch.cuda.synchronize()
     finally:
         c.close()
