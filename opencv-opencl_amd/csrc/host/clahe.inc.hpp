@@ -40,8 +40,12 @@ int clahe_auto_tiles_per_wg(const ClaheGeom& g)
 mi_status launch_tile_luts(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const ClaheGeom& g, int f0, int nf, uint8_t* d_luts_out)
 {
     const int tiles = g.tiles_x * g.tiles_y;
-    // splits per tile: enough workgroups to fill the chip, at least ~8 rows of work each
-    long long want = ((long long)c->cu_count * 8 + (long long)tiles * nf - 1) / ((long long)tiles * nf);
+    // Splits per tile.  Splitting costs a third launch (partials -> tile_lut_kernel) and pays only for LARGE tiles on few frames, and then
+    // only up to about one workgroup per CU: one 4K frame 8x8 takes 29.8 us with 32 splits (the round-2 rule: ~8 workgroups per CU),
+    // 21.9 us with none (64 workgroups on 256 CUs!) and 20.5 us with 4; 1080p 8x8 (tiles of 32 K pixels) is fastest unsplit at every
+    // batch size (four frames: 18.7 us against 27.1) -- profiles/r03_m_clahe_splits.txt.
+    const long long tile_px = (long long)g.tile_w * g.tile_h;
+    const long long want = tile_px >= 65536 ? (long long)c->cu_count / ((long long)tiles * nf) : 1;
     int S = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 8), 64LL}));
     mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * tiles * S * 256 * sizeof(uint32_t));
     if (st) return st;
