@@ -19,7 +19,7 @@
 #define MI_OPT_FUSED_ACQUIRE       "fused_acquire"       /* 1/0, default 1: agent-scope acquire before a consumer reads the LUT       */
 
 /* equalizeHist on few frames */
-#define MI_OPT_TWO_KERNEL_MAX      "two_kernel_max_frames" /* 0..64, default 4: calls of up to this many frames (twice as many when a frame is
+#define MI_OPT_TWO_KERNEL_MAX      "two_kernel_max_frames" /* 0..64, default 8: calls of up to this many frames (twice as many when a frame is
                                                            * 1080p-sized or smaller) run as histogram + LUT in one launch (the last workgroup
                                                            * writes the LUT) followed by the apply kernel, instead of the fused pair; 0 = never */
 

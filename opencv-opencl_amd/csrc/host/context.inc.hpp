@@ -83,7 +83,7 @@ struct mi_ctx {
     uint32_t* d_partial = nullptr; size_t partial_bytes = 0;     // histogram partials
     uint8_t*  d_luts = nullptr;    size_t luts_bytes = 0;        // per-frame / per-tile LUTs
     uint32_t* d_ghist = nullptr;   size_t ghist_bytes = 0;       // global histograms + arrival counters of hist_lut_kernel (zero between launches)
-    int two_kernel_max_frames = 4;                               // option "two_kernel_max_frames": batches up to this size take hist_lut_kernel + lut_apply_kernel
+    int two_kernel_max_frames = 8;                               // option "two_kernel_max_frames": batches up to this size take hist_lut_kernel + lut_apply_kernel
     uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (self-cleaning; all per-launch
                                                                  // state lives in it, so captured launches replay unchanged).  The
                                                                  // ticket stamps are PART of the block: stamps, epochs and checksums

@@ -199,9 +199,9 @@ mi_status equalize_fused_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const
     return MI_OK;
 }
 
-// Up to four frames (a stream's frame, a cv::Mat call; up to eight of 1080p or less): histogram + LUT in one launch whose last
-// workgroup writes the LUT, then the apply kernel.  No inter-workgroup waits, so no finish kernel and nothing to repair: 16.5 us per
-// 4K frame against 23 us for the fused pair, whose single read cannot pay for its hand-off latency on so little data.
+// Up to eight frames (a stream's frame, a cv::Mat call; up to sixteen of 1080p or less): histogram + LUT in one launch whose last
+// workgroup writes the LUT, then the apply kernel.  No inter-workgroup waits, so no finish kernel and nothing to repair: 17 us per
+// 4K frame against 22.5 us for the fused pair, whose single read cannot pay for its hand-off latency on so little data.
 mi_status equalize_two_kernel_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
     const size_t need = (size_t)a.n_frames * (256 + 1) * sizeof(uint32_t);
@@ -215,7 +215,13 @@ mi_status equalize_two_kernel_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, 
     PlaneArgs b = a;
     b.dst = nullptr;
     const PlaneBatch p = make_plane(b);
-    const int B = blocks_per_frame(c, (long long)a.width * a.height, p.rows, a.n_frames, 256);
+    // workgroups per frame: every one of them ends in up to 256 global atomics on the frame's histogram, so FEWER than the
+    // streaming kernels' ~8 per CU: about two per CU in all, at least 32 KiB each, at most 128 per frame (probe of round 3: four 4K
+    // frames 34.5 us with 256 per frame, 28.6 with 128; four 1080p frames 17.3 us with 126, 14.5 with 64)
+    const long long px = (long long)a.width * a.height;
+    long long Bq = std::min<long long>({(long long)c->cu_count * 2 / a.n_frames, 128LL, std::max<long long>(1, px / 32768)});
+    if (p.rows > 1) Bq = std::min<long long>(Bq, p.rows);
+    const int B = (int)std::max<long long>(1, Bq);
     uint32_t* cnt = c->d_ghist + (size_t)a.n_frames * 256;
     LAUNCH(c, s, MI_K_HIST, hist_lut_kernel, dim3(B, a.n_frames), dim3(kHistThreads), 0, p, c->d_ghist, cnt,
            (int)((long long)a.width * a.height), c->d_luts);
@@ -224,9 +230,9 @@ mi_status equalize_two_kernel_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, 
 
 mi_status equalize_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const UVJob* uv)
 {
-    // measured (profiles/r03_l_single_frame.txt, us per call, two-kernel / fused pair / three-kernel): 4K 1 frame 16.5 / 22.8 / 24.5,
-    // 2 frames 21.9 / 27.8 / 29.9, 4 frames 34.6 / 38.5 / 36.8, 8 frames 57.8 / 52.3 / 53.2; 1080p 4 frames 17.3 / 22.1 / 19.9,
-    // 8 frames 27.1 / 28.3 / 25.1, 16 frames 45.0 / 39.1 / 35.4
+    // measured (profiles/r03_l_single_frame.txt, us per call, two-kernel / fused pair / three-kernel): 4K 1 frame 17.0 / 22.5 / 24.5,
+    // 2 frames 20.6 / 28.2 / 29.5, 4 frames 29.3 / 38.9 / 37.1, 8 frames 45.5 / 52.2 / 53.2, 16 frames 87.2 / 87.0 / 90.5;
+    // 1080p 4 frames 15.3 / 22.5 / 19.7, 8 frames 21.6 / 28.2 / 25.1, 16 frames 29.5 / 39.3 / 35.7
     const long long px = (long long)a.width * a.height;
     const int k2 = c->two_kernel_max_frames;
     if (k2 > 0 && (a.n_frames <= k2 || (a.n_frames <= 2 * k2 && px <= 1920LL * 1088))) return equalize_two_kernel_dev(c, s, a, uv);

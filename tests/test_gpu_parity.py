@@ -375,7 +375,7 @@ def test_profiling_counters(ctx):
         assert v["min_ms"] <= v["total_ms"] / 12 <= v["max_ms"]
         assert ctx.profile_read(reset=True)["equalize_fused_kernel"]["max_ms"] == 0          # reset clears the samples
         # default routing of a one- or two-frame call: histogram + LUT in ONE launch (its last workgroup writes the LUT), then the apply kernel
-        ctx.set_option("two_kernel_max_frames", 4)
+        ctx.set_option("two_kernel_max_frames", 8)
         ctx.set_profiling(True)
         ctx.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, n, 0)
         p = ctx.profile_read(reset=True)
@@ -387,7 +387,7 @@ def test_profiling_counters(ctx):
             assert np.array_equal(out[k], oracle.nv12_frame(src[k], w, h, uv_mode=0, op=0))
     finally:
         ctx.set_option("fused", 1)
-        ctx.set_option("two_kernel_max_frames", 4)
+        ctx.set_option("two_kernel_max_frames", 8)
         ctx.set_profiling(False)
 
 
@@ -412,7 +412,7 @@ def test_equalize_paths_agree(ctx, opts):
                 for k in range(n):
                     assert np.array_equal(out[k], oracle.nv12_frame(frames[k], w, h, uv_mode=uv_mode, op=0)), (w, h, k, uv_mode)
     finally:
-        for k, v in dict(fused=1, fused_vpt=20, fused_wgs_per_cu=4, fused_acquire=1, two_kernel_max_frames=4).items():
+        for k, v in dict(fused=1, fused_vpt=20, fused_wgs_per_cu=4, fused_acquire=1, two_kernel_max_frames=8).items():
             ctx.set_option(k, v)
 
 
@@ -704,7 +704,7 @@ def test_hip_graph_capture_and_replay():
         torch.cuda.synchronize()
         assert np.array_equal(host(d_out[1]), oracle.nv12_frame(host(d_in[1]), w, h, uv_mode=0, op=1, clip_limit=2.0, tiles_x=8, tiles_y=8))
         # the default routing of few frames (histogram + LUT in one launch, then apply) is capturable as well
-        c.set_option("two_kernel_max_frames", 4)
+        c.set_option("two_kernel_max_frames", 8)
         c.equalize_hist_nv12_batch_dev(d_in, d_out, w, h, 2, 1)            # sizes its scratch eagerly
         c.synchronize()
         g4 = torch.cuda.CUDAGraph()

@@ -22,4 +22,4 @@ for (w, h) in ((3840, 2160), (1920, 1080), (1280, 720)):
             res[name] = rate(lambda: ctx.equalize_hist_nv12_batch_dev(nv, out, w, h, n, mi_lumaeq.UV_FILL128))
         print(f"{w}x{h} frames={n:2d}: " + "  ".join(f"{k} {v:7.1f} us/call" for k, v in res.items()), flush=True)
         del nv, out
-ctx.set_option("two_kernel_max_frames", 4); ctx.set_option("fused", 1)
+ctx.set_option("two_kernel_max_frames", 8); ctx.set_option("fused", 1)
