@@ -164,6 +164,7 @@ void mi_ctx_destroy(mi_ctx* c)
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_luts) (void)hipFree(c->d_luts);
     if (c->d_ghist) (void)hipFree(c->d_ghist);
+    if (c->d_sync16) (void)hipFree(c->d_sync16);
     if (c->d_fused) (void)hipFree(c->d_fused);
     for (void* q : c->retired) (void)hipFree(q);
     if (c->d_planes) (void)hipFree(c->d_planes);

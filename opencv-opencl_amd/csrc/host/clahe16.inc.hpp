@@ -19,10 +19,17 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
     // scratch per frame: tile histograms (u32) + ushort LUTs + the tiles' populated ranges + the frame's range; frames are
     // processed in chunks that keep it <= ~2 GiB (address space, not traffic: 288 GB of HBM) (the value-major copy of the LUTs reuses the histogram area, which is
     // dead once the LUTs exist).  Only the bins a frame populates are ever written or read (kernels/clahe16.hip.h).
-    const size_t per_frame = (size_t)tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t)) + ((size_t)tiles + 1) * sizeof(Range16);
+    const size_t per_frame = (size_t)tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t)) + ((size_t)tiles + 1) * sizeof(Range16) + sizeof(uint32_t);
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)2 << 30) / per_frame));
     st = grow_dev(c, &c->d_c16, &c->c16_bytes, per_frame * (size_t)chunk);
     if (st) return st;
+    // per-frame arrival words of tile_hist12_kernel: zero between launches (its last workgroup per frame leaves them so)
+    const size_t sync_need = (size_t)chunk * 4 * sizeof(uint32_t);
+    if (sync_need > c->sync16_bytes) {
+        st = grow_dev(c, &c->d_sync16, &c->sync16_bytes, std::max<size_t>(sync_need, 64 * 4 * sizeof(uint32_t)));
+        if (st) return st;
+        HIPCHK(c, hipMemsetAsync(c->d_sync16, 0, c->sync16_bytes, s));
+    }
     // vector path of the tile histogram: no REFLECT_101 padding, 8-pixel groups inside one tile, 16-B aligned rows
     const int vec = width % tiles_x == 0 && height % tiles_y == 0 && g.tile_w % 8 == 0 &&
                     (((uintptr_t)src | src_step | src_frame) & 15) == 0;
@@ -33,15 +40,18 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         uint16_t* luts = reinterpret_cast<uint16_t*>(c->d_c16 + (size_t)nf * tiles * kHist16 * sizeof(uint32_t));
         Range16* ranges = reinterpret_cast<Range16*>(c->d_c16 + (size_t)nf * tiles * kHist16 * (sizeof(uint32_t) + sizeof(uint16_t)));
         Range16* franges = ranges + (size_t)nf * tiles;
+        uint32_t* fdone = reinterpret_cast<uint32_t*>(franges + nf);
+        const bool bet12 = vec && c->clahe16_fast12;
         // 12-bit bet (kernels/clahe16.hip.h): vector geometry only; a tile that loses it is redone the careful way in the same workgroup
-        if (vec && c->clahe16_fast12)
+        if (bet12)
             LAUNCH(c, s, MI_K_TILE_HIST, tile_hist12_kernel, dim3(tiles, nf), dim3(1024), kHist12Words * sizeof(uint32_t),
-                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts);
+                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
+                   c->d_sync16, franges, fdone);
         else
             LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, vec);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, (const Range16*)ranges, g,
-               lut_scale16, clip16, luts, franges);
+               lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr));
         if (tiles <= 64 && c->clahe16_transposed) {
             // value-major LUTs (one cache line per pixel value): transposed into the histogram area, which is dead by now
             uint16_t* lutT = reinterpret_cast<uint16_t*>(hist);
@@ -51,20 +61,28 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
                    dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)lutT);
         } else {
-            // one workgroup per (tile pair, band, sub-band); enough sub-bands to fill the chip, never less than ~16 rows each
-            long long want = ((long long)c->cu_count * 4 + (long long)npairs * bands * nf - 1) / ((long long)npairs * bands * nf);
-            const int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 16), 16LL}));
-            if ((long long)npairs * bands * subs > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "16-bit CLAHE: tile grid too large");
+            // one workgroup per (tile pair, band, sub-band).  Few frames: enough sub-bands to fill the chip (four workgroups per CU), never
+            // less than ~16 rows each.  Many frames: still TWO sub-bands per band while they keep 64 rows -- 2 workgroups are resident per
+            // CU and a band-high workgroup lives ~50 us, so the last round of a launch is long and half empty (16 4K frames: 1296 unequal
+            // workgroups on 512 slots); three or more cost more in table staging (64 KiB per workgroup) than they gain
+            // (profiles/r03_n_clahe16_interp_subs.txt).
+            const long long per_sub = (long long)npairs * bands * nf;
+            const long long want = ((long long)c->cu_count * 4 + per_sub - 1) / per_sub;
+            int subs = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 16), 16LL}));
+            if (subs < 2 && g.tile_h >= 128) subs = 2;
+            const long long rows = (long long)bands * subs * nf;
+            const long long grid = (rows + 7) / 8 * 8 * npairs;           // rows are dealt to the 8 XCDs whole (kernels/clahe16.hip.h)
+            if (grid > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "16-bit CLAHE: tile grid too large");
             const uint8_t* sp = src + (size_t)f0 * src_frame;
             uint8_t* dp = dst + (size_t)f0 * dst_frame;
             if (g.contract)
-                LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<true>, dim3((unsigned)(npairs * bands * subs), nf), dim3(kInterp16Threads),
+                LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<true>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs);
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf);
             else
-                LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<false>, dim3((unsigned)(npairs * bands * subs), nf), dim3(kInterp16Threads),
+                LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<false>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs);
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf);
             // IN-PLACE frames whose range does not fit the LDS table (their workgroups above returned at once); the launch is a no-op for
             // every other frame, and is left out altogether when the call is not in place (it cost 8 us per call)
             if (sp == dp) {

@@ -82,6 +82,7 @@ struct mi_ctx {
     // device scratch, grown lazily ("allocate once per size", OpenCLequalHist.cpp:175-186)
     uint32_t* d_partial = nullptr; size_t partial_bytes = 0;     // histogram partials
     uint8_t*  d_luts = nullptr;    size_t luts_bytes = 0;        // per-frame / per-tile LUTs
+    uint32_t* d_sync16 = nullptr;  size_t sync16_bytes = 0;      // per-frame arrival words of tile_hist12_kernel (zero between launches)
     uint32_t* d_ghist = nullptr;   size_t ghist_bytes = 0;       // global histograms + arrival counters of hist_lut_kernel (zero between launches)
     int two_kernel_max_frames = 8;                               // option "two_kernel_max_frames": batches up to this size take hist_lut_kernel + lut_apply_kernel
     uint32_t* d_fused = nullptr;   size_t fused_bytes = 0;       // hand-off block of the fused kernel (self-cleaning; all per-launch

@@ -274,7 +274,8 @@ __device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t
 // 16-B aligned rows).
 __global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
                                                           ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
-                                                          float lut_scale16, int clip16, uint16_t* __restrict__ luts)
+                                                          float lut_scale16, int clip16, uint16_t* __restrict__ luts,
+                                                          uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done)
 {
     extern __shared__ uint32_t h16[];                            // [4096][4] = 64 KiB, or [16384] for the careful path
     __shared__ uint32_t s_lo, s_hi;
@@ -333,6 +334,33 @@ __global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __rest
         }
         __syncthreads();
         lost = s_hi >= (uint32_t)kBins12;
+    }
+    // The frame's range and "every tile wrote its LUT here" are settled by the LAST workgroup of the frame to get here, so that
+    // tile_lut16_kernel can leave at once on one scalar load (launched only to leave, it still cost 26 us per 16 frames in the sequence:
+    // every workgroup re-derived the frame's range from the tiles' ranges first).  sync[f] = {arrivals, max(0xffff - lo), max(hi),
+    // -}: zero between launches, touched with relaxed agent-scope atomics only -- performed at the L2, coherent by construction,
+    // no write-back / invalidate of this XCD's L2 (see hist_lut_kernel).
+    // Arrival comes EARLY -- as soon as the tile knows whether its bet held, before its LUT is computed and stored: the flag is read by
+    // the next kernel, and thread 0 must not sit on its own stores' completion (arriving after them made every workgroup ~5 us longer).
+    // A tile that lost its bet contributes nothing: the frame is then not "done" and tile_lut16_kernel derives the range itself.
+    // word 0 = arrivals (low half) + LUTs done (high half).
+    if (t == 0) {
+        uint32_t* sy = sync + 4 * (size_t)f;
+        if (!lost) {
+            __hip_atomic_fetch_max(sy + 1, 0xffffu - s_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(sy + 2, s_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const uint32_t before = __hip_atomic_fetch_add(sy, lost ? 1u : 0x10001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((before & 0xffffu) == gridDim.x - 1) {                 // the last workgroup of the frame
+            const uint32_t nd = (before >> 16) + (lost ? 0u : 1u);
+            const uint32_t nlo = __hip_atomic_exchange(sy + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t fhi = __hip_atomic_exchange(sy + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Range16 r; r.lo = 0xffffu - nlo; r.hi = fhi;
+            frame_ranges[f] = r;
+            frame_done[f] = (nd == gridDim.x && fhi < (uint32_t)kBins12) ? 1u : 0u;
+        }
     }
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
         __syncthreads();
@@ -413,8 +441,11 @@ __global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __rest
 // one 8-byte store), over [frame lo & ~3, frame hi] only.  Semantics of clahe.cpp for histSize 65536: clip at clip16, excess / 65536
 // added to every bin, the residual spread with stride max(65536 / residual, 1); then the prefix sum scaled by lut_scale16.
 __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, const Range16* __restrict__ ranges, ClaheGeom g,
-                                                         float lut_scale16, int clip16, uint16_t* __restrict__ luts, Range16* __restrict__ frame_ranges)
+                                                         float lut_scale16, int clip16, uint16_t* __restrict__ luts, Range16* __restrict__ frame_ranges,
+                                                         const uint32_t* __restrict__ frame_done)
 {
+    // tile_hist12_kernel has written every LUT of this frame (bins 0..4095: all anybody reads) and the frame's range: one scalar load
+    if (frame_done && frame_done[blockIdx.y]) return;
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_flo, s_fhi;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -524,14 +555,22 @@ template <bool FMA>
 __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                          uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                          ClaheGeom g, const uint16_t* __restrict__ luts,
-                                                                         const Range16* __restrict__ frame_ranges, int subs)
+                                                                         const Range16* __restrict__ frame_ranges, int subs, int n_frames)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 tab[];      // [kInterp16Entries] {a | b << 16, c | d << 16}
-    const int t = threadIdx.x, f = blockIdx.y;
-    const int npairs = g.tiles_x + 1;
-    int id = blockIdx.x;
-    const int sub = id % subs; id /= subs;
-    const int pr = id % npairs, band = id / npairs;
+    const int t = threadIdx.x;
+    const int npairs = g.tiles_x + 1, bands = g.tiles_y + 1;
+    // Workgroups reach the 8 XCDs round-robin in launch order.  A ROW of workgroups -- the tiles_x + 1 pairs of one (frame, band,
+    // sub-band) -- is given to ONE XCD, its pairs one after the other: the rectangles of neighbouring pairs meet in the middle of a
+    // 128-byte line (a 4K pair is 960 bytes wide and starts at byte 480), and only an L2 that sees both halves writes whole lines
+    // back.  grid = 8 * ceil(rows / 8) * (tiles_x + 1) workgroups, one dimension; rows beyond the last return at once.
+    const long long id = blockIdx.x;
+    const int xcd = (int)(id & 7);
+    const long long k = id >> 3;
+    const int pr = (int)(k % npairs);
+    const long long row = (k / npairs) * 8 + xcd;
+    if (row >= (long long)bands * subs * n_frames) return;
+    const int sub = (int)(row % subs), band = (int)((row / subs) % bands), f = (int)(row / ((long long)subs * bands));
     const int ty1u = band - 1;
     const int ty1 = max(ty1u, 0), ty2 = min(ty1u + 1, g.tiles_y - 1);
     const int tx1 = max(pr - 1, 0), tx2 = min(pr, g.tiles_x - 1);
@@ -603,33 +642,52 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     }
     const uint32_t windows = multi ? s_windows : 1u;
 
+    // One window and one pass -- every call on 10/12/13-bit content: a lane's first four rows are requested BEFORE the table is staged
+    // (the staging is ~4 us of L2 reads and LDS writes during which the workgroup had nothing in flight), and inside the row loop the
+    // next four are requested before the current four are blended.  The kernel runs at 4 waves per SIMD (64 KiB of LDS per workgroup):
+    // without the second register set every iteration exposed the full HBM latency (measured alone, 16 4K frames: 142 us, see
+    // profiles/r03_n_*).
+    constexpr int kRows = 4;
+    const bool aligned = ((((uintptr_t)src | (uintptr_t)dst | (unsigned long long)src_step | (unsigned long long)dst_step) & 15) == 0);
+    u32x4 q[kRows];
+    bool pre_valid = false;
+    if (!multi && passes == 1 && aligned) {
+        const int gi = t % ngroups, phase = t / ngroups;
+        const int x0 = (g_lo + gi) << 3, y = y_lo + phase;
+        if (phase < phases && x0 + 8 <= g.width && y + (kRows - 1) * phases < y_hi) {
+#pragma unroll
+            for (int k = 0; k < kRows; ++k) q[k] = *reinterpret_cast<const u32x4*>(src + (long long)(y + k * phases) * src_step + 2 * (long long)x0);
+            pre_valid = true;
+        }
+    }
+
     for (uint32_t w0 = start, wi = 0; w0 <= fr.hi; w0 += (uint32_t)kInterp16Entries, ++wi) {
         if (!((windows >> wi) & 1u)) continue;                      // uniform: nothing of this rectangle lives in that window
         __syncthreads();                                            // the previous window's table is no longer read
         {
             const uint32_t w1 = min(fr.hi, w0 + (uint32_t)kInterp16Entries - 1);
-            const uint32_t n4 = (w1 - w0) / 4 + 1;                   // groups of four consecutive values
-            for (uint32_t i = t; i < n4; i += kInterp16Threads) {
-                const uint32_t v = w0 + 4 * i;
-                const uint2 qa = *reinterpret_cast<const uint2*>(la + v), qb = *reinterpret_cast<const uint2*>(lb + v);
-                const uint2 qc = *reinterpret_cast<const uint2*>(lc + v), qd = *reinterpret_cast<const uint2*>(ld + v);
-                if (f32tab) {
-                    const uint32_t wa[2] = {qa.x, qa.y}, wb[2] = {qb.x, qb.y}, wc[2] = {qc.x, qc.y}, wd[2] = {qd.x, qd.y};
+            // One table entry per lane and step, consecutive lanes -> consecutive entries: conflict-free LDS writes; the sixteen 2-byte
+            // loads of four steps are in flight together.
+            const uint32_t n = w1 - w0 + 1;
+            for (uint32_t i0 = 0; i0 < n; i0 += 4 * kInterp16Threads) {
+                uint32_t va[4], vb[4], vc[4], vd[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int sh = 16 * (k & 1);
-                        const f32x4 e = {(float)((wa[k >> 1] >> sh) & 0xffffu), (float)((wc[k >> 1] >> sh) & 0xffffu),
-                                         (float)((wb[k >> 1] >> sh) & 0xffffu), (float)((wd[k >> 1] >> sh) & 0xffffu)};      // {a, c, b, d}
-                        tabf[4 * i + k] = e;
-                    }
-                    continue;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t v = min(w0 + i0 + (uint32_t)(k * kInterp16Threads + t), w1);
+                    va[k] = la[v]; vb[k] = lb[v]; vc[k] = lc[v]; vd[k] = ld[v];
                 }
-                uint2 e0, e1, e2, e3;
-                e0.x = (qa.x & 0xffffu) | (qb.x << 16);        e0.y = (qc.x & 0xffffu) | (qd.x << 16);
-                e1.x = (qa.x >> 16) | (qb.x & 0xffff0000u);    e1.y = (qc.x >> 16) | (qd.x & 0xffff0000u);
-                e2.x = (qa.y & 0xffffu) | (qb.y << 16);        e2.y = (qc.y & 0xffffu) | (qd.y << 16);
-                e3.x = (qa.y >> 16) | (qb.y & 0xffff0000u);    e3.y = (qc.y >> 16) | (qd.y & 0xffff0000u);
-                tab[4 * i] = e0; tab[4 * i + 1] = e1; tab[4 * i + 2] = e2; tab[4 * i + 3] = e3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t i = i0 + (uint32_t)(k * kInterp16Threads + t);
+                    if (i >= n) continue;
+                    if (f32tab) {
+                        const f32x4 e = {(float)va[k], (float)vc[k], (float)vb[k], (float)vd[k]};      // {a, c, b, d}
+                        tabf[i] = e;
+                    } else {
+                        uint2 e; e.x = va[k] | (vb[k] << 16); e.y = vc[k] | (vd[k] << 16);
+                        tab[i] = e;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -650,7 +708,6 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                 if (q == pr && x0 + j < g.width) own |= 1u << j;
             }
             if (!own) continue;
-            const bool aligned = ((((uintptr_t)src | (uintptr_t)dst | (unsigned long long)src_step | (unsigned long long)dst_step) & 15) == 0);
             const bool vec_ok = own == 0xffu && aligned && !multi;
             auto blend_row = [&](int y, const uint32_t* px, uint32_t* res) {
                 const float tyf = tile_coord<FMA>(y, g.inv_th);
@@ -687,23 +744,37 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
             };
             int y = y_lo + phase;
             if (vec_ok) {
-                // four rows are loaded before the first is blended: 64 B in flight per lane instead of 16 (the kernel runs at two
-                // workgroups per CU, too few waves to hide the HBM latency otherwise)
-                constexpr int kRows = 4;
-                auto do_vec_row = [&](int yy, const u32x4& q) {
-                    const uint32_t px[8] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, q.z & 0xffffu, q.z >> 16, q.w & 0xffffu, q.w >> 16};
+                // four rows per set, two sets: the next set is in flight while the current one is blended (128 B per lane)
+                auto do_vec_row = [&](int yy, const u32x4& qq) {
+                    const uint32_t px[8] = {qq.x & 0xffffu, qq.x >> 16, qq.y & 0xffffu, qq.y >> 16, qq.z & 0xffffu, qq.z >> 16, qq.w & 0xffffu, qq.w >> 16};
                     uint32_t res[8];
                     blend_row(yy, px, res);
                     u32x4 o;
                     o.x = res[0] | (res[1] << 16); o.y = res[2] | (res[3] << 16); o.z = res[4] | (res[5] << 16); o.w = res[6] | (res[7] << 16);
                     *reinterpret_cast<u32x4*>(dst + (long long)yy * dst_step + 2 * (long long)x0) = o;
                 };
-                for (; y + (kRows - 1) * phases < y_hi; y += kRows * phases) {
-                    u32x4 q[kRows];
+                auto ld_row = [&](int yy) { return *reinterpret_cast<const u32x4*>(src + (long long)yy * src_step + 2 * (long long)x0); };
+                bool have = y + (kRows - 1) * phases < y_hi;
+                if (have && !pre_valid) {
 #pragma unroll
-                    for (int k = 0; k < kRows; ++k) q[k] = *reinterpret_cast<const u32x4*>(src + (long long)(y + k * phases) * src_step + 2 * (long long)x0);
+                    for (int k = 0; k < kRows; ++k) q[k] = ld_row(y + k * phases);
+                }
+                pre_valid = false;
+                while (have) {
+                    const int y2 = y + kRows * phases;
+                    const bool more = y2 + (kRows - 1) * phases < y_hi;
+                    u32x4 nq[kRows];
+                    if (more) {
+#pragma unroll
+                        for (int k = 0; k < kRows; ++k) nq[k] = ld_row(y2 + k * phases);
+                    }
 #pragma unroll
                     for (int k = 0; k < kRows; ++k) { do_vec_row(y + k * phases, q[k]); __builtin_amdgcn_sched_barrier(0); }
+                    if (more) {
+#pragma unroll
+                        for (int k = 0; k < kRows; ++k) q[k] = nq[k];
+                    }
+                    y = y2; have = more;
                 }
                 for (; y < y_hi; y += phases) do_vec_row(y, *reinterpret_cast<const u32x4*>(src + (long long)y * src_step + 2 * (long long)x0));
             } else {
