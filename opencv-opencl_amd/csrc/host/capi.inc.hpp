@@ -130,7 +130,7 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
     }
     // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist12_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHist12Words * (int)sizeof(uint32_t));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist12_kernel<kHist12Threads, kCopies12>), hipFuncAttributeMaxDynamicSharedMemorySize, kHist12Words * (int)sizeof(uint32_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16Entries * (int)sizeof(uint2));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16Entries * (int)sizeof(uint2));
     hipDeviceProp_t prop;

@@ -44,7 +44,7 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         const bool bet12 = vec && c->clahe16_fast12;
         // 12-bit bet (kernels/clahe16.hip.h): vector geometry only; a tile that loses it is redone the careful way in the same workgroup
         if (bet12)
-            LAUNCH(c, s, MI_K_TILE_HIST, tile_hist12_kernel, dim3(tiles, nf), dim3(1024), kHist12Words * sizeof(uint32_t),
+            LAUNCH(c, s, MI_K_TILE_HIST, (tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
                    c->d_sync16, franges, fdone);
         else

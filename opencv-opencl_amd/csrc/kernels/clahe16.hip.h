@@ -104,10 +104,10 @@ __device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u
     hist16_fast_dword<kWinBits>(h16, q.z, pmin, pmax); hist16_fast_dword<kWinBits>(h16, q.w, pmin, pmax);
 }
 
-// grid = (tiles, frames), 1024 threads, 128 KiB dynamic LDS.  steps in BYTES.
+// grid = (tiles, frames), NT threads (1024 in tile_hist16_kernel), (4 << kWinBits) bytes of dynamic LDS.  steps in BYTES.
 // `vec` (host: no REFLECT_101 padding, tile_w % 8 == 0, 16-B aligned rows): a lane takes 8 pixels per 16-byte load with
 // four loads in flight; otherwise one pixel per lane per step with index reflection.
-template <int kWinBits>
+template <int kWinBits, int NT = 1024>
 __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinBits] LDS */, uint32_t& s_lo, uint32_t& s_hi,
                                                     const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
                                                     const ClaheGeom& g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
@@ -120,7 +120,7 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
     const size_t tile_id = (size_t)f * gridDim.x + tile;
     uint32_t* out = hist + tile_id * kHist16;
     const long long items = (long long)g.tile_h * g.tile_w;
-    const int drow = 1024 / g.tile_w, dcol = 1024 - drow * g.tile_w;
+    const int drow = NT / g.tile_w, dcol = NT - drow * g.tile_w;
     const int slots = g.tile_w >> 3;                              // 8-pixel groups per tile row (vector path)
     const int vitems = g.tile_h * slots;
     const uint8_t* tbase = src + (long long)ty * g.tile_h * step + (long long)tx * g.tile_w * 2;
@@ -134,17 +134,17 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
     uint32_t lo = 0, hi = 0;
     bool range_known = false;
     if (vec) {                                                    // optimistic sweep, see hist16_fast_vec
-        for (int i = t; i < kWin / 4; i += 1024) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
+        for (int i = t; i < kWin / 4; i += NT) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
         u16x2 pmin = {0xffff, 0xffff}, pmax = {0, 0};
         int row = t / slots, slot = t - row * slots;
-        const int vdrow = 1024 / slots, vdslot = 1024 - vdrow * slots;
+        const int vdrow = NT / slots, vdslot = NT - vdrow * slots;
         const u32x4 zero = {0u, 0u, 0u, 0u};
-        for (int it = t; it < vitems; it += 4 * 1024) {           // (row, slot) items walked incrementally, four predicated loads in flight
+        for (int it = t; it < vitems; it += 4 * NT) {           // (row, slot) items walked incrementally, four predicated loads in flight
             u32x4 q[4]; bool qv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                qv[k] = it + k * 1024 < vitems;
+                qv[k] = it + k * NT < vitems;
                 const u32x4* ptr = reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
                 q[k] = qv[k] ? *ptr : zero;
                 row += vdrow; slot += vdslot;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
         __syncthreads();
         lo = s_lo; hi = s_hi;
         if (hi < (uint32_t)kWin) {                                // nothing aliased: the counters are the histogram
-            for (uint32_t i = (lo & ~3u) + (uint32_t)t; i <= hi; i += 1024) out[i] = h16[i];
+            for (uint32_t i = (lo & ~3u) + (uint32_t)t; i <= hi; i += NT) out[i] = h16[i];
             if (t == 0) { Range16 r; r.lo = lo; r.hi = hi; ranges[tile_id] = r; }
             return;
         }
@@ -171,18 +171,18 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
         __syncthreads();
     }
     for (int half = 0; half < (kHist16 >> kWinBits); ++half) {    // one window of the value range per sweep
-        for (int i = t; i < kWin; i += 1024) h16[i] = 0;
+        for (int i = t; i < kWin; i += NT) h16[i] = 0;
         __syncthreads();
         if (vec) {
             int it = t;
-            for (; it + 3 * 1024 < vitems; it += 4 * 1024) {
-                const u32x4 a = vload(it), b = vload(it + 1024), c = vload(it + 2048), d = vload(it + 3072);
+            for (; it + 3 * NT < vitems; it += 4 * NT) {
+                const u32x4 a = vload(it), b = vload(it + NT), c = vload(it + 2 * NT), d = vload(it + 3 * NT);
                 vadd(a, half); vadd(b, half); vadd(c, half); vadd(d, half);
             }
-            for (; it < vitems; it += 1024) vadd(vload(it), half);
+            for (; it < vitems; it += NT) vadd(vload(it), half);
         } else {
             int row = t / g.tile_w, col = t - row * g.tile_w;
-            for (long long it = t; it < items; it += 1024) {
+            for (long long it = t; it < items; it += NT) {
                 const int y = reflect101(ty * g.tile_h + row, g.height);
                 const int x = reflect101(tx * g.tile_w + col, g.width);
                 const uint32_t v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
@@ -206,7 +206,7 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
         const uint32_t base = (uint32_t)half * (uint32_t)kWin;
         const uint32_t b0 = max(lo, base), b1 = min(hi, base + (uint32_t)kWin - 1);
         if (b0 <= b1)
-            for (uint32_t i = (b0 & ~3u) + (uint32_t)t; i <= b1; i += 1024) out[i] = h16[i & ((1u << kWinBits) - 1)];   // from a 4-aligned start: the LUT kernel loads 16 B
+            for (uint32_t i = (b0 & ~3u) + (uint32_t)t; i <= b1; i += NT) out[i] = h16[i & ((1u << kWinBits) - 1)];   // from a 4-aligned start: the LUT kernel loads 16 B
         if (hi < base + (uint32_t)kWin) break;                    // nothing above this window: done
         __syncthreads();
     }
@@ -222,9 +222,9 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
 }
 
 // ---- 12-bit fast path -----------------------------------------------------------------------------------------------------
-// What 16-bit video actually carries is 10 or 12 bits.  tile_hist12_kernel BETS on that: 4096 bins x 4 copies take 64 KiB of LDS
-// (two workgroups per CU instead of one), a lane counts at (value & 4095) * 4 + (lane & 3), and the packed min / max it tracks anyway tells at the end whether the
-// bet held (max < 4096).  Against the 32 768-counter sweep above:
+// What 16-bit video actually carries is 10 or 12 bits.  tile_hist12_kernel BETS on that: 4096 bins x COPIES copies (32 KiB of LDS with
+// two: four workgroups of 512 threads per CU), a lane counts at (value & 4095) * COPIES + (lane & (COPIES - 1)), and the packed min / max it
+// tracks anyway tells at the end whether the bet held (max < 4096).  Against the 32 768-counter sweep above:
 //   * the sweep is bound by the loads a CU keeps in flight (a constant frame takes as long as noise): two workgroups per CU double
 //     them -- the 32 768-counter kernel fills the LDS with one;
 //   * equal values meeting in one ds_add serialise, and neighbouring pixels of a real image ARE equal or close: with four copies
@@ -234,21 +234,25 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
 //   * the whole LUT stage is done right here, from the counters in LDS (clip, redistribute, prefix sum over bins 0..4095 -- the same
 //     arithmetic as tile_lut16_kernel, which then returns at once for such a tile as long as the WHOLE frame stayed below 4096).
 // A tile that loses the bet -- some value >= 4096, noticed after the first four vectors per lane or at the end -- is redone by
-// tile_hist16_careful<14> (16 384 counters per sweep, up to four sweeps) in the same workgroup, same LDS.  ranges[tile].hi carries bit 31 when the tile's LUT was written here.
+// tile_hist16_careful (as many counters per sweep as fit the same LDS: 8192 with two copies, up to eight sweeps) in the same workgroup.  ranges[tile].hi carries bit 31 when the tile's LUT was written here.
 constexpr uint32_t kLutDone = 0x80000000u;
 constexpr int kBins12 = 4096;
-constexpr int kCopies12 = 4;                        // 4096 bins x 4 copies x 4 B = 64 KiB: TWO workgroups per CU (the sweep is bound by the
-                                                    // loads a CU keeps in flight, not by the LDS: a constant frame takes as long as noise)
-constexpr int kCopyShift12 = 2;
+// Shipped shape: 1024 threads, 4 copies = 64 KiB of LDS, two workgroups per CU.  512 threads x 2 copies (32 KiB, four workgroups per
+// CU) measured the same on 12-bit content (16 4K frames: 59.6 us alone either way; the sweep on its own 45 us either way,
+// tools/hist12_probe.hip) and leaves the careful path half the counters per sweep, so the larger shape stays.
+constexpr int kHist12Threads = 1024;
+constexpr int kCopies12 = 4;
 constexpr int kHist12Words = kBins12 * kCopies12;
 
+template <int COPIES>
 __device__ __forceinline__ void hist12_dword(uint32_t* h, uint32_t w, uint32_t cp, u16x2& pmin, u16x2& pmax)
 {
     const u16x2 v = __builtin_bit_cast(u16x2, w);
     pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
-    lds_inc(h, ((w & (kBins12 - 1)) << kCopyShift12) | cp);
-    lds_inc(h, (((w >> 16) & (kBins12 - 1)) << kCopyShift12) | cp);
+    lds_inc(h, ((w & (kBins12 - 1)) * COPIES) | cp);
+    lds_inc(h, (((w >> 16) & (kBins12 - 1)) * COPIES) | cp);
 }
+template <int COPIES>
 __device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t cp, u16x2& pmin, u16x2& pmax)
 {
     const uint32_t v0 = q.x & 0xffffu;
@@ -258,7 +262,7 @@ __device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t
         pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
         const unsigned long long active = __ballot(1);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
-        const uint32_t idx = ((v0 & (kBins12 - 1)) << kCopyShift12) | cp;
+        const uint32_t idx = ((v0 & (kBins12 - 1)) * COPIES) | cp;
         if (__ballot(v0 == first) == active) {
             if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(active)) lds_add(h, idx, 8u * (uint32_t)__builtin_popcountll(active));
         } else {
@@ -266,39 +270,44 @@ __device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t
         }
         return;
     }
-    hist12_dword(h, q.x, cp, pmin, pmax); hist12_dword(h, q.y, cp, pmin, pmax);
-    hist12_dword(h, q.z, cp, pmin, pmax); hist12_dword(h, q.w, cp, pmin, pmax);
+    hist12_dword<COPIES>(h, q.x, cp, pmin, pmax); hist12_dword<COPIES>(h, q.y, cp, pmin, pmax);
+    hist12_dword<COPIES>(h, q.z, cp, pmin, pmax); hist12_dword<COPIES>(h, q.w, cp, pmin, pmax);
 }
 
-// grid = (tiles, frames), 1024 threads, 128 KiB dynamic LDS; vector geometry only (the host checks: no padding, tile_w % 8 == 0,
-// 16-B aligned rows).
-__global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                          ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
-                                                          float lut_scale16, int clip16, uint16_t* __restrict__ luts,
-                                                          uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done)
+// grid = (tiles, frames), NT threads, 4096 * COPIES * 4 bytes of dynamic LDS; vector geometry only (the host checks: no padding,
+// tile_w % 8 == 0, 16-B aligned rows).  A thread owns 4096 / NT consecutive bins in the LUT stage.
+template <int NT, int COPIES>
+__global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+                                                        ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
+                                                        float lut_scale16, int clip16, uint16_t* __restrict__ luts,
+                                                        uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done)
 {
-    extern __shared__ uint32_t h16[];                            // [4096][4] = 64 KiB, or [16384] for the careful path
+    static_assert(COPIES == 2 || COPIES == 4, "copies");
+    constexpr int NW = NT / 64, BPT = kBins12 / NT;                // waves; bins per thread
+    static_assert(BPT % 4 == 0 && BPT >= 4, "a thread owns whole 16-byte groups of bins");
+    constexpr int kCarefulBits = COPIES == 4 ? 14 : 13;            // the careful path's counters fill the same LDS
+    extern __shared__ uint32_t h16[];                            // [4096][COPIES], or [1 << kCarefulBits] for the careful path
     __shared__ uint32_t s_lo, s_hi;
-    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_w[NW];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int tile = blockIdx.x, f = blockIdx.y;
-    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const size_t tile_id = (size_t)f * gridDim.x + tile;
+    const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const uint8_t* src = src_base + (long long)f * frame_stride;
     const int slots = g.tile_w >> 3;
     const int vitems = g.tile_h * slots;
     const uint8_t* tbase = src + (long long)ty * g.tile_h * step + (long long)tx * g.tile_w * 2;
-    const uint32_t cp = (uint32_t)t & (uint32_t)(kCopies12 - 1);
+    const uint32_t cp = (uint32_t)t & (uint32_t)(COPIES - 1);
     if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
-    for (int i = t; i < kHist12Words / 4; i += 1024) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = t; i < kBins12 * COPIES / 4; i += NT) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
     // (row, slot) items walked incrementally, four predicated loads per set
     int row = t / slots, slot = t - row * slots;
-    const int vdrow = 1024 / slots, vdslot = 1024 - vdrow * slots;
+    const int vdrow = NT / slots, vdslot = NT - vdrow * slots;
     const u32x4 zero = {0u, 0u, 0u, 0u};
     auto load_set = [&](int it, u32x4* q, bool* qv) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            qv[k] = it + k * 1024 < vitems;
+            qv[k] = it + k * NT < vitems;
             const u32x4* ptr = reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
             q[k] = qv[k] ? *ptr : zero;
             row += vdrow; slot += vdslot;
@@ -315,11 +324,11 @@ __global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __rest
     bool lost = early_lost;
     u16x2 pmin = {0xffff, 0xffff}, pmax = {0, 0};
     if (!lost) {
-        for (int it = t; it < vitems; it += 4 * 1024) {
-            const bool more = it + 4 * 1024 < vitems;                // uniform per lane only; the loads are predicated anyway
-            if (more) load_set(it + 4 * 1024, nxt, nv);
+        for (int it = t; it < vitems; it += 4 * NT) {
+            const bool more = it + 4 * NT < vitems;                  // uniform per lane only; the loads are predicated anyway
+            if (more) load_set(it + 4 * NT, nxt, nv);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (cv[k]) hist12_vec(h16, cur[k], cp, pmin, pmax);
+            for (int k = 0; k < 4; ++k) if (cv[k]) hist12_vec<COPIES>(h16, cur[k], cp, pmin, pmax);
             if (more) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { cur[k] = nxt[k]; cv[k] = nv[k]; }
@@ -366,37 +375,46 @@ __global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __rest
         __syncthreads();
         if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
         __syncthreads();
-        tile_hist16_careful<14>(h16, s_lo, s_hi, src_base, step, frame_stride, g, hist, ranges, 1);   // 16 384 counters per sweep fit the 64 KiB
+        tile_hist16_careful<kCarefulBits, NT>(h16, s_lo, s_hi, src_base, step, frame_stride, g, hist, ranges, 1);   // its counters fill the same LDS
         return;
     }
     const uint32_t lo = s_lo, hi = s_hi;
-    // ---- the tile's 4096 counts: thread t owns bins 4t .. 4t+3 (sum of the eight copies)
-    // Read out conflict-free: consecutive lanes read consecutive 16 bytes (the four copies of one bin), the 4096 sums are compacted
-    // to the head of the LDS array, and each thread then picks up its four consecutive bins.
-    int v[4];
+    // ---- the tile's 4096 counts: thread t owns bins BPT * t .. BPT * t + BPT - 1 (sum of the copies)
+    // Read out conflict-free: consecutive lanes read the consecutive copies of consecutive bins, the 4096 sums are compacted to the head
+    // of the LDS array, and each thread then picks up its consecutive bins.
+    int v[BPT];
     {
-        const u32x4* hp = reinterpret_cast<const u32x4*>(h16);
-        uint32_t part[4];
+        uint32_t part[BPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const u32x4 a = hp[t + 1024 * j]; part[j] = a.x + a.y + a.z + a.w; }     // bin t + 1024 j
+        for (int j = 0; j < BPT; ++j) {                              // bin t + NT * j
+            if (COPIES == 4) { const u32x4 a = reinterpret_cast<const u32x4*>(h16)[t + NT * j]; part[j] = a.x + a.y + a.z + a.w; }
+            else { const uint2 a = reinterpret_cast<const uint2*>(h16)[t + NT * j]; part[j] = a.x + a.y; }
+        }
         __syncthreads();                                            // every copy has been read: the head of the array may be overwritten
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h16[t + 1024 * j] = part[j];
+        for (int j = 0; j < BPT; ++j) h16[t + NT * j] = part[j];
         __syncthreads();
-        const u32x4 q = hp[t];
-        v[0] = (int)q.x; v[1] = (int)q.y; v[2] = (int)q.z; v[3] = (int)q.w;
+#pragma unroll
+        for (int j = 0; j < BPT / 4; ++j) {
+            const u32x4 q = reinterpret_cast<const u32x4*>(h16)[t * (BPT / 4) + j];
+            v[4 * j] = (int)q.x; v[4 * j + 1] = (int)q.y; v[4 * j + 2] = (int)q.z; v[4 * j + 3] = (int)q.w;
+        }
     }
-    const uint32_t b0 = (uint32_t)t * 4;
+    const uint32_t b0 = (uint32_t)t * BPT;
     // the histogram itself, for tile_lut16_kernel should the FRAME turn out wider than 4096 values (another tile lost its bet)
-    if (b0 + 3 >= (lo & ~3u) && b0 <= hi)
-        *reinterpret_cast<u32x4*>(hist + tile_id * kHist16 + b0) = u32x4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
-    auto block_scan = [&](uint32_t x, uint32_t& total) -> uint32_t {  // inclusive prefix of x over the 1024 threads
+#pragma unroll
+    for (int j = 0; j < BPT / 4; ++j) {
+        const uint32_t bj = b0 + 4 * j;
+        if (bj + 3 >= (lo & ~3u) && bj <= hi)
+            *reinterpret_cast<u32x4*>(hist + tile_id * kHist16 + bj) = u32x4{(uint32_t)v[4 * j], (uint32_t)v[4 * j + 1], (uint32_t)v[4 * j + 2], (uint32_t)v[4 * j + 3]};
+    }
+    auto block_scan = [&](uint32_t x, uint32_t& total) -> uint32_t {  // inclusive prefix of x over the NT threads
         const uint32_t incl = wave_incl_scan(x);
         __syncthreads();
         if (lane == 63) s_w[wv] = incl;
         __syncthreads();
         uint32_t off = 0, tot = 0;
-        for (int k = 0; k < 16; ++k) { const uint32_t y = s_w[k]; if (k < wv) off += y; tot += y; }
+        for (int k = 0; k < NW; ++k) { const uint32_t y = s_w[k]; if (k < wv) off += y; tot += y; }
         total = tot;
         return off + incl;
     };
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __rest
     if (clip16 > 0) {
         uint32_t excess = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (v[k] > clip16) excess += (uint32_t)(v[k] - clip16);
+        for (int k = 0; k < BPT; ++k) if (v[k] > clip16) excess += (uint32_t)(v[k] - clip16);
         uint32_t clipped;
         (void)block_scan(excess, clipped);
         batch = (int)clipped / kHist16;
@@ -414,7 +432,7 @@ __global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __rest
     }
     uint32_t local = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < BPT; ++k) {
         if (clip16 > 0) {
             if (v[k] > clip16) v[k] = clip16;
             v[k] += batch;
@@ -426,14 +444,16 @@ __global__ __launch_bounds__(1024) void tile_hist12_kernel(const uint8_t* __rest
     }
     uint32_t total;
     const uint32_t before = block_scan(local, total) - local;
-    uint32_t packed[2];
+    uint32_t packed[BPT / 2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < BPT; ++k) {
         int r = __float2int_rn(__fmul_rn((float)(int)(before + (uint32_t)v[k]), lut_scale16));
         r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
         if (k & 1) packed[k >> 1] |= (uint32_t)r << 16; else packed[k >> 1] = (uint32_t)r;
     }
-    *reinterpret_cast<uint2*>(luts + tile_id * kHist16 + b0) = make_uint2(packed[0], packed[1]);
+#pragma unroll
+    for (int j = 0; j < BPT / 4; ++j)
+        *reinterpret_cast<uint2*>(luts + tile_id * kHist16 + b0 + 4 * j) = make_uint2(packed[2 * j], packed[2 * j + 1]);
     if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | kLutDone; ranges[tile_id] = r; }
 }
 

@@ -991,6 +991,36 @@ def test_clahe16_twelve_bit_bet_mixed_outcomes(ctx):
             ctx.set_option("clahe16_fast12", 1)
 
 
+def test_clahe16_frame_done_flags_over_many_frames(ctx):
+    """The last tile workgroup of each FRAME settles the frame's range and whether every tile wrote its LUT in the histogram kernel
+    (the LUT kernel then leaves on one scalar load); the per-frame arrival words must come back to zero after every launch.  150
+    small frames whose outcomes alternate -- 12-bit, 10-bit, narrow, one pixel >= 4096, full range -- in calls of 150, 40 and 150
+    frames, out of place and in place: every frame against the oracle."""
+    w, h = 128, 64                                                 # 8x8 tiles of 16 x 8 pixels: vector geometry
+    rng = np.random.default_rng(77)
+    def frame(k):
+        kind = k % 5
+        if kind == 0: return rng.integers(0, 4096, (h, w), dtype=np.uint16)
+        if kind == 1: return rng.integers(0, 1024, (h, w), dtype=np.uint16)
+        if kind == 2: return rng.integers(1000 + k, 1400 + k, (h, w), dtype=np.uint16)
+        if kind == 3:
+            f = rng.integers(0, 4096, (h, w), dtype=np.uint16); f[(7 * k) % h, (13 * k) % w] = 4096 + 100 * k; return f
+        return rng.integers(0, 65536, (h, w), dtype=np.uint16)
+    frames = np.stack([frame(k) for k in range(150)])
+    want = np.stack([oracle.clahe16(f, 2.0, 8, 8) for f in frames])
+    for n in (150, 40, 150):
+        d_in = dev(frames[:n].view(np.int16))
+        d_out = torch.zeros_like(d_in)
+        ctx.clahe16_batch_dev(d_in, d_out, w, h, n, 2.0, 8, 8)
+        ctx.synchronize()
+        out = host(d_out).view(np.uint16)
+        bad = [k for k in range(n) if not np.array_equal(out[k], want[k])]
+        assert not bad, (n, bad[:10])
+        ctx.clahe16_batch_dev(d_in, d_in, w, h, n, 2.0, 8, 8)
+        ctx.synchronize()
+        assert np.array_equal(host(d_in).view(np.uint16), want[:n]), (n, "in place")
+
+
 def test_clahe16_batch_and_errors(ctx):
     w, h, n = 320, 180, 3
     rng = np.random.default_rng(3)

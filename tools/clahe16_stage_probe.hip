@@ -66,14 +66,17 @@ int main(int argc, char** argv)
             CK(hipMemcpy(src + plane * f, hb.data(), plane, hipMemcpyHostToDevice));
         }
     }
-    CK(hipFuncSetAttribute((const void*)tile_hist12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHist12Words * 4));
+    CK(hipFuncSetAttribute((const void*)tile_hist12_kernel<kHist12Threads, kCopies12>, hipFuncAttributeMaxDynamicSharedMemorySize, kHist12Words * 4));
     CK(hipFuncSetAttribute((const void*)clahe_interp16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16Entries * 8));
     const int npairs = TX + 1, bands = TY + 1;
-    long long want = ((long long)cus * 20 + (long long)npairs * bands * nf - 1) / ((long long)npairs * bands * nf);
-    const int subs = argc > 4 ? atoi(argv[4]) : (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 64), 16LL}));
+    // the library's rule (host/clahe16.inc.hpp): fill the chip when frames are few, two sub-bands per band otherwise
+    long long want = ((long long)cus * 4 + (long long)npairs * bands * nf - 1) / ((long long)npairs * bands * nf);
+    int subs_rule = (int)std::max<long long>(1, std::min<long long>({want, (long long)std::max(1, g.tile_h / 16), 16LL}));
+    if (subs_rule < 2 && g.tile_h >= 128) subs_rule = 2;
+    const int subs = argc > 4 ? atoi(argv[4]) : subs_rule;
     const long long rows = (long long)bands * subs * nf;
     const unsigned igrid = (unsigned)((rows + 7) / 8 * 8 * npairs);
-    auto k_hist = [&] { hipLaunchKernelGGL(tile_hist12_kernel, dim3(tiles, nf), dim3(1024), kHist12Words * 4, 0, (const uint8_t*)src, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone); };
+    auto k_hist = [&] { hipLaunchKernelGGL((tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * 4, 0, (const uint8_t*)src, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone); };
     auto k_lut = [&] { hipLaunchKernelGGL(tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, 0, (const uint32_t*)hist, (const Range16*)ranges, g, lut_scale16, clip16, luts, franges, (const uint32_t*)fdone); };
     auto k_int = [&] { hipLaunchKernelGGL(clahe_interp16_kernel<false>, dim3(igrid), dim3(kInterp16Threads), kInterp16Entries * 8, 0,
                                           (const uint8_t*)src, (long long)step, (long long)plane, dst, (long long)step, (long long)plane, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf); };
@@ -102,7 +105,7 @@ int main(int argc, char** argv)
         const float tc = time_us([&] {
             for (int f0 = 0; f0 < nf; f0 += chunk) {
                 const uint8_t* sp = src + plane * f0; uint8_t* dp = dst + plane * f0;
-                hipLaunchKernelGGL(tile_hist12_kernel, dim3(tiles, chunk), dim3(1024), kHist12Words * 4, 0, sp, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone);
+                hipLaunchKernelGGL((tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, chunk), dim3(kHist12Threads), kHist12Words * 4, 0, sp, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone);
                 hipLaunchKernelGGL(tile_lut16_kernel, dim3(tiles, chunk), dim3(1024), 0, 0, (const uint32_t*)hist, (const Range16*)ranges, g, lut_scale16, clip16, luts, franges, (const uint32_t*)fdone);
                 hipLaunchKernelGGL(clahe_interp16_kernel<false>, dim3(cgrid), dim3(kInterp16Threads), kInterp16Entries * 8, 0,
                                    sp, (long long)step, (long long)plane, dp, (long long)step, (long long)plane, g, (const uint16_t*)luts, (const Range16*)franges, subs, chunk);
