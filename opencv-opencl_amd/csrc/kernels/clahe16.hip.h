@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
     static_assert(BPT % 4 == 0 && BPT >= 4, "a thread owns whole 16-byte groups of bins");
     constexpr int kCarefulBits = COPIES == 4 ? 14 : 13;            // the careful path's counters fill the same LDS
     extern __shared__ uint32_t h16[];                            // [4096][COPIES], or [1 << kCarefulBits] for the careful path
-    __shared__ uint32_t s_lo, s_hi;
+    __shared__ uint32_t s_lo, s_hi, s_sum;
     __shared__ uint32_t s_w[NW];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int tile = blockIdx.x, f = blockIdx.y;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
     const int vitems = g.tile_h * slots;
     const uint8_t* tbase = src + (long long)ty * g.tile_h * step + (long long)tx * g.tile_w * 2;
     const uint32_t cp = (uint32_t)t & (uint32_t)(COPIES - 1);
-    if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
+    if (t == 0) { s_lo = 0xffffu; s_hi = 0; s_sum = 0; }
     for (int i = t; i < kBins12 * COPIES / 4; i += NT) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
     // (row, slot) items walked incrementally, four predicated loads per set
     int row = t / slots, slot = t - row * slots;
@@ -344,38 +344,44 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
         __syncthreads();
         lost = s_hi >= (uint32_t)kBins12;
     }
-    // The frame's range and "every tile wrote its LUT here" are settled by the LAST workgroup of the frame to get here, so that
+    // The frame's range and "every tile wrote its LUT here" are settled by the LAST workgroup of the frame to arrive, so that
     // tile_lut16_kernel can leave at once on one scalar load (launched only to leave, it still cost 26 us per 16 frames in the sequence:
-    // every workgroup re-derived the frame's range from the tiles' ranges first).  sync[f] = {arrivals, max(0xffff - lo), max(hi),
-    // -}: zero between launches, touched with relaxed agent-scope atomics only -- performed at the L2, coherent by construction,
-    // no write-back / invalidate of this XCD's L2 (see hist_lut_kernel).
-    // Arrival comes EARLY -- as soon as the tile knows whether its bet held, before its LUT is computed and stored: the flag is read by
-    // the next kernel, and thread 0 must not sit on its own stores' completion (arriving after them made every workgroup ~5 us longer).
-    // A tile that lost its bet contributes nothing: the frame is then not "done" and tile_lut16_kernel derives the range itself.
-    // word 0 = arrivals (low half) + LUTs done (high half).
+    // every workgroup re-derived the frame's range from the tiles' ranges first).  ONE 64-bit word per frame, zero between launches:
+    // bits 0..15 arrivals, 16..31 tiles whose bet held, 32..63 which 128-value buckets hold a tile's lowest / highest value.  A tile
+    // ORs its two bucket bits in and then adds its arrival -- two relaxed agent-scope atomics on the SAME address, so every arrival
+    // the last workgroup sees comes with its bits (performed at the L2: no write-back / invalidate of this XCD's L2, see
+    // hist_lut_kernel).  Thread 0 issues them here, as soon as the tile knows whether its bet held, and looks at the returned
+    // value only at the very end: waiting here held the whole workgroup at its next barrier (9 us per 16 frames), arriving after
+    // the LUT made thread 0 sit on its own stores.  The range so reported is rounded out to buckets, which only makes the
+    // interpolation stage a few more (existing) table entries.  A tile that lost its bet adds an arrival and nothing else: the
+    // frame is then not "done" and tile_lut16_kernel derives the exact range itself.
+    unsigned long long before64 = 0;
+    uint32_t own_bits = 0, own_add = 1u;
+    unsigned long long* const sy = reinterpret_cast<unsigned long long*>(sync) + 2 * (size_t)f;
     if (t == 0) {
-        uint32_t* sy = sync + 4 * (size_t)f;
         if (!lost) {
-            __hip_atomic_fetch_max(sy + 1, 0xffffu - s_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_max(sy + 2, s_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            own_bits = (1u << (s_lo >> 7)) | (1u << (s_hi >> 7));
+            own_add = 0x10001u;
+            __hip_atomic_fetch_or(sy, (unsigned long long)own_bits << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const uint32_t before = __hip_atomic_fetch_add(sy, lost ? 1u : 0x10001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((before & 0xffffu) == gridDim.x - 1) {                 // the last workgroup of the frame
-            const uint32_t nd = (before >> 16) + (lost ? 0u : 1u);
-            const uint32_t nlo = __hip_atomic_exchange(sy + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t fhi = __hip_atomic_exchange(sy + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            Range16 r; r.lo = 0xffffu - nlo; r.hi = fhi;
-            frame_ranges[f] = r;
-            frame_done[f] = (nd == gridDim.x && fhi < (uint32_t)kBins12) ? 1u : 0u;
-        }
+        before64 = __hip_atomic_fetch_add(sy, (unsigned long long)own_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    auto settle_frame = [&]() {                                     // thread 0, last statement of either path
+        if ((uint32_t)(before64 & 0xffffu) != gridDim.x - 1) return;
+        const uint32_t nd = (uint32_t)((before64 >> 16) & 0xffffu) + (own_add >> 16);
+        const uint32_t bits = (uint32_t)(before64 >> 32) | own_bits;
+        __hip_atomic_store(sy, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Range16 r; r.lo = 0xffffu; r.hi = 0;
+        if (bits) { r.lo = (uint32_t)__builtin_ctz(bits) << 7; r.hi = (((31u - (uint32_t)__builtin_clz(bits)) << 7) | 127u); }
+        frame_ranges[f] = r;
+        frame_done[f] = nd == gridDim.x ? 1u : 0u;
+    };
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
         __syncthreads();
         if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
         __syncthreads();
         tile_hist16_careful<kCarefulBits, NT>(h16, s_lo, s_hi, src_base, step, frame_stride, g, hist, ranges, 1);   // its counters fill the same LDS
+        if (t == 0) settle_frame();
         return;
     }
     const uint32_t lo = s_lo, hi = s_hi;
@@ -424,8 +430,12 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
         uint32_t excess = 0;
 #pragma unroll
         for (int k = 0; k < BPT; ++k) if (v[k] > clip16) excess += (uint32_t)(v[k] - clip16);
-        uint32_t clipped;
-        (void)block_scan(excess, clipped);
+        // a sum, not a scan: one LDS add per wave and one barrier
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) excess += (uint32_t)__shfl_xor((int)excess, d, 64);
+        if (lane == 0 && excess) __hip_atomic_fetch_add(&s_sum, excess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        const uint32_t clipped = s_sum;
         batch = (int)clipped / kHist16;
         residual = (int)clipped - batch * kHist16;
         if (residual != 0) { rstep = kHist16 / residual; if (rstep < 1) rstep = 1; }
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
 #pragma unroll
     for (int j = 0; j < BPT / 4; ++j)
         *reinterpret_cast<uint2*>(luts + tile_id * kHist16 + b0 + 4 * j) = make_uint2(packed[2 * j], packed[2 * j + 1]);
-    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | kLutDone; ranges[tile_id] = r; }
+    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | kLutDone; ranges[tile_id] = r; settle_frame(); }
 }
 
 // grid = (tiles, frames), 1024 threads.  Bins are walked in chunks of 4096, four consecutive bins per thread (one 16-byte load,
