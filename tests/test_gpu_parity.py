@@ -717,8 +717,29 @@ def test_hip_graph_capture_and_replay():
             torch.cuda.synchronize()
             for k in range(2):
                 assert np.array_equal(host(d_out[k]), oracle.nv12_frame(host(d_in[k]), w, h, uv_mode=1, op=0)), (rep, k)
+        # 16-bit CLAHE: its per-frame arrival words live in the context and are left zero by every launch, so a captured sequence
+        # replays on new content -- frames whose 12-bit bet holds and one that loses it
+        w16, h16, n16 = 640, 368, 4
+        rng = np.random.default_rng(61)
+        s16 = dev(rng.integers(0, 4096, (n16, h16, w16), dtype=np.uint16).view(np.int16))
+        o16 = torch.zeros_like(s16)
+        c.clahe16_batch_dev(s16, o16, w16, h16, n16, 2.0, 8, 8)            # sizes the scratch eagerly
+        c.synchronize()
+        g5 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g5):
+            c.clahe16_batch_dev(s16, o16, w16, h16, n16, 2.0, 8, 8, stream=torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):
+            fr = rng.integers(0, 4096 if rep != 1 else 1024, (n16, h16, w16), dtype=np.uint16)
+            if rep == 2: fr[2, 100, 100] = 50000
+            s16.copy_(dev(fr.view(np.int16)))
+            o16.zero_()
+            g5.replay()
+            torch.cuda.synchronize()
+            out16 = host(o16).view(np.uint16)
+            for k in range(n16):
+                assert np.array_equal(out16[k], oracle.clahe16(fr[k], 2.0, 8, 8)), ("clahe16 replay", rep, k)
         # destroy the graphs while the context (whose scratch their kernel nodes point at) is still alive
-        del g, g2, g4
+        del g, g2, g4, g5
         torch.cuda.synchronize()
     finally:
         c.close()
