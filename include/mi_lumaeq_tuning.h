@@ -34,8 +34,8 @@
                                                            * across)                                                                 */
 
 /* CLAHE (16-bit) */
-#define MI_OPT_CLAHE16_FAST12      "clahe16_fast12"      /* 1/0, default 1: tile histograms bet on values < 4096 (4096 bins x 8 LDS copies,
-                                                           * LUT folded in); a tile that loses the bet is redone with 32 768 counters   */
+#define MI_OPT_CLAHE16_FAST12      "clahe16_fast12"      /* 1/0, default 1: tile histograms bet on values < 4096 (4096 bins x 4 LDS copies,
+                                                           * LUT folded in); a tile that loses the bet is redone with 16 384 counters   */
 #define MI_OPT_CLAHE16_TRANSPOSED  "clahe16_transposed"  /* 1/0, default 0: value-major LUT layout for the 16-bit interpolation       */
 
 /* colour neighbours */

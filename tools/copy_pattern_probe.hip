@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT) void copy_rects(const uint8_t* __restrict__ src
 template <int R, int STAGE>
 __global__ __launch_bounds__(512) void copy_pairs(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, long long step, long long frame,
                                                   int width, int height, int tile_w, int tile_h, int tiles_x, int tiles_y, const uint32_t* __restrict__ table,
-                                                  int subs, int xcd_rows)
+                                                  int subs, int xcd_rows, int strip_px)
 {
     extern __shared__ uint32_t lds[];
     const int t = threadIdx.x;
@@ -109,8 +109,14 @@ __global__ __launch_bounds__(512) void copy_pairs(const uint8_t* __restrict__ sr
     }
     const int yb_lo = max(0, ((2 * band - 1) * tile_h) / 2), yb_hi = min(height, ((2 * band + 1) * tile_h + 1) / 2);
     const int y_lo = yb_lo + (yb_hi - yb_lo) * sub / subs, y_hi = yb_lo + (yb_hi - yb_lo) * (sub + 1) / subs;
-    const int x_lo = max(0, ((2 * pr - 1) * tile_w) / 2 - 4), x_hi = min(width, ((2 * pr + 1) * tile_w + 1) / 2 + 4);
-    const int own_lo = max(0, ((2 * pr - 1) * tile_w) / 2), own_hi = min(width, ((2 * pr + 1) * tile_w + 1) / 2);
+    int x_lo, x_hi, own_lo, own_hi;
+    if (strip_px > 0) {                                           // aligned strips instead of pairs: [pr * strip_px, (pr + 1) * strip_px)
+        x_lo = own_lo = pr * strip_px; x_hi = own_hi = min(width, (pr + 1) * strip_px);
+    } else {
+        x_lo = max(0, ((2 * pr - 1) * tile_w) / 2 - 4); x_hi = min(width, ((2 * pr + 1) * tile_w + 1) / 2 + 4);
+        own_lo = max(0, ((2 * pr - 1) * tile_w) / 2); own_hi = min(width, ((2 * pr + 1) * tile_w + 1) / 2);
+    }
+    if (x_lo >= x_hi) return;
     const int g_lo = x_lo >> 3, ngroups = ((x_hi + 7) >> 3) - g_lo;
     const int phases = max(1, 512 / ngroups);
     const int gi = t % ngroups, phase = t / ngroups;
@@ -157,7 +163,7 @@ static void run(const char* what, int seg_groups, int x_off, int rect_rows, int 
 }
 
 template <int R, int STAGE>
-static void run_pairs(const char* what, int subs = 1, int xcd_rows = 0)
+static void run_pairs(const char* what, int subs = 1, int xcd_rows = 0, int strip_px = 0)
 {
     auto k = copy_pairs<R, STAGE>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -167,14 +173,14 @@ static void run_pairs(const char* what, int subs = 1, int xcd_rows = 0)
     const int reps = 10;
     // with the XCD mapping the grid is padded so that 8 * ceil(rows / 8) rows of 9 workgroups exist
     const int rows = 9 * subs * 16, grid_x = xcd_rows ? ((rows + 7) / 8 * 8 * 9 + 15) / 16 : 81 * subs;
-    auto launch = [&] { hipLaunchKernelGGL(k, dim3(grid_x, 16), dim3(512), 65536, 0, g_src, g_dst, step, frame, 3840, 2160, 480, 270, 8, 8, (const uint32_t*)table, subs, xcd_rows); };
+    auto launch = [&] { hipLaunchKernelGGL(k, dim3(grid_x, 16), dim3(512), 65536, 0, g_src, g_dst, step, frame, 3840, 2160, 480, 270, 8, 8, (const uint32_t*)table, subs, xcd_rows, strip_px); };
     launch(); CK(hipDeviceSynchronize());
     CK(hipEventRecord(a, 0));
     for (int r = 0; r < reps; ++r) launch();
     CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     const double us = ms * 1e3 / reps, bytes = 2.0 * frame * 16;
-    printf("%-40s R=%d stage=%d subs=%d xcd_rows=%d wgs=%5d: %7.1f us  %5.2f TB/s\n", what, R, STAGE, subs, xcd_rows, grid_x * 16, us, bytes / us / 1e6);
+    printf("%-40s R=%d stage=%d subs=%d xcd_rows=%d strip=%4d px wgs=%5d: %7.1f us  %5.2f TB/s\n", what, R, STAGE, subs, xcd_rows, strip_px, grid_x * 16, us, bytes / us / 1e6);
     CK(hipFree(table));
 }
 
@@ -186,6 +192,9 @@ int main()
     run_pairs<4, 0>("the shipped geometry, copy only");
     run_pairs<4, 1>("the shipped geometry, staging + copy");
     run_pairs<2, 0>("the shipped geometry, copy only");
+    // 9 aligned strips of 448 pixels = 896 bytes = 7 lines (the 9th is 256 pixels wide) instead of the 9 pairs, same bands
+    for (int xr = 0; xr < 2; ++xr)
+        for (int sb = 1; sb <= 2; ++sb) { run_pairs<4, 1>("aligned 896-byte strips, bands as shipped", sb, xr, 448); run_pairs<4, 1>("pairs as shipped", sb, xr, 0); }
     for (int xr = 0; xr < 2; ++xr)
         for (int sb = 1; sb <= 8; sb *= 2) { run_pairs<4, 0>("shipped geometry", sb, xr); run_pairs<4, 1>("shipped geometry", sb, xr); }
     // linear reference: full rows, many workgroups
