@@ -151,6 +151,21 @@ def test_host_form_error_exits_drain_the_stream_and_leave_the_context_usable(pin
                 assert e.status == 3
             c.set_option("hip_fail_after", 0)
             assert np.array_equal(c.nv12_bgr_equalize(nv, w, h), want_nv), n
+        # 16-bit CLAHE: a failure reported between its launches (the tile histograms ran, the LUT kernel or the interpolation did
+        # not) must leave the per-frame arrival words of the histogram kernel at zero for the next call
+        y16 = np.random.default_rng(9).integers(0, 4096, (h, w), dtype=np.uint16)
+        want16 = oracle.clahe16(y16, 2.0, 8, 8)
+        hit = 0
+        for n in range(1, 16):
+            c.set_option("hip_fail_after", n)
+            try:
+                c.clahe16(y16, 2.0, 8, 8)
+            except mi_lumaeq.MiError as e:
+                assert e.status == 3
+                hit += 1
+            c.set_option("hip_fail_after", 0)
+            assert np.array_equal(c.clahe16(y16, 2.0, 8, 8), want16), n
+        assert hit >= 4
     finally:
         c.close()
 
