@@ -9,15 +9,20 @@ namespace mi {
 // CLAHE on CV_16UC1 (clahe.cpp CLAHE_CalcLut_Body<ushort,65536,0> / CLAHE_Interpolation_Body<ushort,0>).
 // Not on the reference's path (OpenCV surface beyond it).  Everything is RANGE-ADAPTIVE: 16-bit video carries 10 or 12 bits,
 // so the three kernels only ever touch the bins a frame populates.
+//   tile_hist12   (vector geometry, the default) one workgroup per tile BETS on values < 4096: 4096 bins x 4 LDS copies, the whole
+//                 LUT stage done from the counters in LDS; a tile that loses is redone by the careful sweeps of tile_hist16 in the
+//                 same workgroup.  The last workgroup of a frame to arrive writes the frame's range and "every LUT written".
 //   tile_hist16   one workgroup per tile; ONE pass builds the histogram of values < 32768 in 128 KiB of LDS and tracks the
 //                 tile's min / max; a second pass runs only if the tile holds values >= 32768.  Only bins [lo, hi] are stored,
 //                 with the tile's range next to them (unwritten bins are never read by anyone).
-//   tile_lut16    frame range = union of its tiles' ranges; the clip excess is summed over the tile's own bins; the scan walks
-//                 [frame lo, frame hi] only, starting from the closed-form prefix of the empty bins below it (they still
-//                 receive `batch` and their share of the residual increments, exactly as the sequential loops would give them).
-//   clahe_interp16  one workgroup per (tile pair, band, sub-band): stages {LUT[ty1][tx1][v], [ty1][tx2][v], [ty2][tx1][v],
-//                 [ty2][tx2][v]} for v in the frame range as ONE 8-byte LDS entry, so a pixel costs one ds_read_b64 instead of
-//                 four L2 gathers.  kInterp16Entries values fit at a time (every 12- and 13-bit source in one go); a wider range
+//   tile_lut16    leaves at once for a frame tile_hist12 has finished.  Otherwise: frame range = union of its tiles' ranges; the
+//                 clip excess is summed over the tile's own bins; the scan walks [frame lo, frame hi] only, starting from the
+//                 closed-form prefix of the empty bins below it (they still receive `batch` and their share of the residual
+//                 increments, exactly as the sequential loops would give them).
+//   clahe_interp16  one workgroup per (tile pair, band, sub-band), the pairs of a row on one XCD: stages {LUT[ty1][tx1][v],
+//                 [ty1][tx2][v], [ty2][tx1][v], [ty2][tx2][v]} for v in the frame range as ONE LDS entry -- four floats when the
+//                 range has at most 4096 values, else 8 bytes -- so a pixel costs one LDS read instead of four L2 gathers.
+//                 kInterp16Entries 8-byte entries fit at a time (every 13-bit source in one go); a wider range
 //                 is walked in windows of that size, each pixel finished in the window its value falls into (the workgroup's
 //                 pixels are re-read once per window, from L2; windows none of them falls into are skipped -- a locally smooth
 //                 image needs one or two of the eight).  Only in-place calls on wide-range frames still gather from L2
