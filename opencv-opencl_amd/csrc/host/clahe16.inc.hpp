@@ -59,7 +59,7 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                    (const uint16_t*)luts, lutT, tiles);
             LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16T_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
-                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)lutT);
+                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)lutT, (const Range16*)franges);
         } else {
             // one workgroup per (tile pair, band, sub-band).  Few frames: enough sub-bands to fill the chip (four workgroups per CU), never
             // less than ~16 rows each.  Many frames: still TWO sub-bands per band while they keep 64 rows -- 2 workgroups are resident per

@@ -34,7 +34,21 @@ constexpr int kInterp16F32Entries = 4096;                  // ... or 4096 entrie
 constexpr int kInterp16Entries = 8192;               // LDS pair-table entries (64 KiB): two workgroups of 512 threads per CU
 constexpr int kInterp16Threads = 512;
 
-struct Range16 { uint32_t lo, hi; };                 // populated value range of a tile (lo > hi: empty -- cannot happen, a tile has pixels)
+struct Range16 { uint32_t lo, hi; };                 // populated value range of a tile / frame (lo > hi: empty -- cannot happen, a tile has pixels)
+// hi carries more than the bound: bits 0..15 the highest value, bits 16..19 a SHIFT -- every value of the tile (frame) is a multiple
+// of 1 << shift (10- or 12-bit samples in the high bits of the word, as P010 / P016 video stores them) -- and bit 31 kLutDone.
+// A frame with a shift runs in the COMPRESSED domain j = value >> shift from the LUT kernel on: its LUTs are stored at index j and
+// the interpolation looks pixels up at (pixel >> shift), so MSB-aligned 10- and 12-bit content needs one 1024- / 4096-entry table
+// like LSB-aligned content instead of windows over the whole 16-bit range.
+constexpr uint32_t kRangeHiMask = 0xffffu;
+__device__ __forceinline__ uint32_t range_hi(uint32_t hi) { return hi & kRangeHiMask; }
+__device__ __forceinline__ uint32_t range_shift(uint32_t hi) { return (hi >> 16) & 15u; }
+// shift of a set of values from the OR of all of them (packed pairs allowed): trailing zero bits, 15 when every value is 0
+__device__ __forceinline__ uint32_t shift_of_or(uint32_t packed_or)
+{
+    const uint32_t o = (packed_or | (packed_or >> 16)) & 0xffffu;
+    return o ? (uint32_t)__builtin_ctz(o) : 15u;
+}
 
 __device__ __forceinline__ void lds_add(uint32_t* h, uint32_t idx, uint32_t n)
 {
@@ -42,10 +56,10 @@ __device__ __forceinline__ void lds_add(uint32_t* h, uint32_t idx, uint32_t n)
 }
 
 template <int kWinBits>
-__device__ __forceinline__ void hist16_add_dword(uint32_t* h16, uint32_t w, int half, uint32_t& lmin, uint32_t& lmax)
+__device__ __forceinline__ void hist16_add_dword(uint32_t* h16, uint32_t w, int half, uint32_t& lmin, uint32_t& lmax, uint32_t& lor)
 {
     const uint32_t a = w & 0xffffu, b = w >> 16;
-    lmin = min(lmin, min(a, b)); lmax = max(lmax, max(a, b));
+    lmin = min(lmin, min(a, b)); lmax = max(lmax, max(a, b)); lor |= w;
     if (a == b) { if ((int)(a   >> kWinBits) == half) lds_add(h16, a & ((1u << kWinBits) - 1), 2u); return; }
     if ((int)(a   >> kWinBits) == half) lds_inc(h16, a & ((1u << kWinBits) - 1));
     if ((int)(b   >> kWinBits) == half) lds_inc(h16, b & ((1u << kWinBits) - 1));
@@ -55,12 +69,12 @@ __device__ __forceinline__ void hist16_add_dword(uint32_t* h16, uint32_t w, int 
 // ds_add serialise; flat image regions (borders, saturated areas) are the bad case and are caught before they reach the LDS:
 // all eight pixels equal -> one add of 8; the same value in every active lane of the wave -> one lane adds for the whole wave.
 template <int kWinBits>
-__device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, int half, uint32_t& lmin, uint32_t& lmax)
+__device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, int half, uint32_t& lmin, uint32_t& lmax, uint32_t& lor)
 {
     const uint32_t v0 = q.x & 0xffffu;
     const bool flat = q.x == q.y && q.y == q.z && q.z == q.w && v0 == (q.x >> 16);
     if (__builtin_expect(flat, 0)) {
-        lmin = min(lmin, v0); lmax = max(lmax, v0);
+        lmin = min(lmin, v0); lmax = max(lmax, v0); lor |= v0;
         const unsigned long long active = __ballot(1);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
         if (__ballot(v0 == first) == active) {                      // wave-uniform value (only lanes with flat vectors are here)
@@ -71,8 +85,8 @@ __device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, in
         }
         return;
     }
-    hist16_add_dword<kWinBits>(h16, q.x, half, lmin, lmax); hist16_add_dword<kWinBits>(h16, q.y, half, lmin, lmax);
-    hist16_add_dword<kWinBits>(h16, q.z, half, lmin, lmax); hist16_add_dword<kWinBits>(h16, q.w, half, lmin, lmax);
+    hist16_add_dword<kWinBits>(h16, q.x, half, lmin, lmax, lor); hist16_add_dword<kWinBits>(h16, q.y, half, lmin, lmax, lor);
+    hist16_add_dword<kWinBits>(h16, q.z, half, lmin, lmax, lor); hist16_add_dword<kWinBits>(h16, q.w, half, lmin, lmax, lor);
 }
 
 // OPTIMISTIC sweep (vector path): count every pixel at (value & 32767) without asking which half it belongs to, and track the range
@@ -81,21 +95,21 @@ __device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, in
 // the whole job at ~4 VALU instructions per pixel instead of ~14 (no per-pixel half test, no divergent branch around the ds_add).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <int kWinBits>
-__device__ __forceinline__ void hist16_fast_dword(uint32_t* h16, uint32_t w, u16x2& pmin, u16x2& pmax)
+__device__ __forceinline__ void hist16_fast_dword(uint32_t* h16, uint32_t w, u16x2& pmin, u16x2& pmax, uint32_t& lor)
 {
     const u16x2 v = __builtin_bit_cast(u16x2, w);
-    pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
+    pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v); lor |= w;
     lds_inc(h16, w & ((1u << kWinBits) - 1));
     lds_inc(h16, (w >> 16) & ((1u << kWinBits) - 1));
 }
 template <int kWinBits>
-__device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u16x2& pmin, u16x2& pmax)
+__device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u16x2& pmin, u16x2& pmax, uint32_t& lor)
 {
     const uint32_t v0 = q.x & 0xffffu;
     const bool flat = q.x == q.y && q.y == q.z && q.z == q.w && v0 == (q.x >> 16);
     if (__builtin_expect(flat, 0)) {                                // as hist16_add_vec: flat regions never reach the LDS pixel by pixel
         const u16x2 v = __builtin_bit_cast(u16x2, q.x);
-        pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
+        pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v); lor |= q.x;
         const unsigned long long active = __ballot(1);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
         if (__ballot(v0 == first) == active) {
@@ -105,15 +119,15 @@ __device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u
         }
         return;
     }
-    hist16_fast_dword<kWinBits>(h16, q.x, pmin, pmax); hist16_fast_dword<kWinBits>(h16, q.y, pmin, pmax);
-    hist16_fast_dword<kWinBits>(h16, q.z, pmin, pmax); hist16_fast_dword<kWinBits>(h16, q.w, pmin, pmax);
+    hist16_fast_dword<kWinBits>(h16, q.x, pmin, pmax, lor); hist16_fast_dword<kWinBits>(h16, q.y, pmin, pmax, lor);
+    hist16_fast_dword<kWinBits>(h16, q.z, pmin, pmax, lor); hist16_fast_dword<kWinBits>(h16, q.w, pmin, pmax, lor);
 }
 
 // grid = (tiles, frames), NT threads (1024 in tile_hist16_kernel), (4 << kWinBits) bytes of dynamic LDS.  steps in BYTES.
 // `vec` (host: no REFLECT_101 padding, tile_w % 8 == 0, 16-B aligned rows): a lane takes 8 pixels per 16-byte load with
 // four loads in flight; otherwise one pixel per lane per step with index reflection.
 template <int kWinBits, int NT = 1024>
-__device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinBits] LDS */, uint32_t& s_lo, uint32_t& s_hi,
+__device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinBits] LDS */, uint32_t& s_lo, uint32_t& s_hi, uint32_t& s_or,
                                                     const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
                                                     const ClaheGeom& g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
 {
@@ -133,9 +147,9 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
         const int row = it / slots, slot = it - row * slots;
         return *reinterpret_cast<const u32x4*>(tbase + (long long)row * step + (slot << 4));
     };
-    uint32_t lmin = 0xffffu, lmax = 0;
-    auto vadd = [&](const u32x4& q, int half) { hist16_add_vec<kWinBits>(h16, q, half, lmin, lmax); };
-    if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
+    uint32_t lmin = 0xffffu, lmax = 0, lor = 0;
+    auto vadd = [&](const u32x4& q, int half) { hist16_add_vec<kWinBits>(h16, q, half, lmin, lmax, lor); };
+    if (t == 0) { s_lo = 0xffffu; s_hi = 0; s_or = 0; }
     uint32_t lo = 0, hi = 0;
     bool range_known = false;
     if (vec) {                                                    // optimistic sweep, see hist16_fast_vec
@@ -156,20 +170,24 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
                 if (slot >= slots) { slot -= slots; ++row; }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (qv[k]) hist16_fast_vec<kWinBits>(h16, q[k], pmin, pmax);
+            for (int k = 0; k < 4; ++k) if (qv[k]) hist16_fast_vec<kWinBits>(h16, q[k], pmin, pmax, lor);
         }
         lmin = min((uint32_t)pmin.x, (uint32_t)pmin.y); lmax = max((uint32_t)pmax.x, (uint32_t)pmax.y);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64)); }
+        for (int d = 32; d >= 1; d >>= 1) {
+            lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
+            lor |= (uint32_t)__shfl_xor((int)lor, d, 64);
+        }
         if ((t & 63) == 0) {
             __hip_atomic_fetch_min(&s_lo, lmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_max(&s_hi, lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&s_or, lor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         lo = s_lo; hi = s_hi;
         if (hi < (uint32_t)kWin) {                                // nothing aliased: the counters are the histogram
             for (uint32_t i = (lo & ~3u) + (uint32_t)t; i <= hi; i += NT) out[i] = h16[i];
-            if (t == 0) { Range16 r; r.lo = lo; r.hi = hi; ranges[tile_id] = r; }
+            if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (shift_of_or(s_or) << 16); ranges[tile_id] = r; }
             return;
         }
         range_known = true;                                       // a value >= 32768: start over, one half of the value range per sweep
@@ -191,7 +209,7 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
                 const int y = reflect101(ty * g.tile_h + row, g.height);
                 const int x = reflect101(tx * g.tile_w + col, g.width);
                 const uint32_t v = *reinterpret_cast<const uint16_t*>(src + (long long)y * step + 2 * (long long)x);
-                lmin = min(lmin, v); lmax = max(lmax, v);
+                lmin = min(lmin, v); lmax = max(lmax, v); lor |= v;
                 if ((int)(v   >> kWinBits) == half) lds_inc(h16, v & ((1u << kWinBits) - 1));
                 row += drow; col += dcol;
                 if (col >= g.tile_w) { col -= g.tile_w; ++row; }
@@ -199,10 +217,14 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
         }
         if (half == 0 && !range_known) {                          // the tile's range is known after the first sweep
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64)); }
+            for (int d = 32; d >= 1; d >>= 1) {
+                lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
+                lor |= (uint32_t)__shfl_xor((int)lor, d, 64);
+            }
             if ((t & 63) == 0) {
                 __hip_atomic_fetch_min(&s_lo, lmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_max(&s_hi, lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_or(&s_or, lor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         __syncthreads();
@@ -215,15 +237,15 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
         if (hi < base + (uint32_t)kWin) break;                    // nothing above this window: done
         __syncthreads();
     }
-    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi; ranges[tile_id] = r; }
+    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (shift_of_or(s_or) << 16); ranges[tile_id] = r; }
 }
 
 __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
                                                           ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
 {
     extern __shared__ uint32_t h16[];                            // [32768]
-    __shared__ uint32_t s_lo, s_hi;
-    tile_hist16_careful<15>(h16, s_lo, s_hi, src_base, step, frame_stride, g, hist, ranges, vec);
+    __shared__ uint32_t s_lo, s_hi, s_or;
+    tile_hist16_careful<15>(h16, s_lo, s_hi, s_or, src_base, step, frame_stride, g, hist, ranges, vec);
 }
 
 // ---- 12-bit fast path -----------------------------------------------------------------------------------------------------
@@ -292,7 +314,7 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
     static_assert(BPT % 4 == 0 && BPT >= 4, "a thread owns whole 16-byte groups of bins");
     constexpr int kCarefulBits = COPIES == 4 ? 14 : 13;            // the careful path's counters fill the same LDS
     extern __shared__ uint32_t h16[];                            // [4096][COPIES], or [1 << kCarefulBits] for the careful path
-    __shared__ uint32_t s_lo, s_hi, s_sum;
+    __shared__ uint32_t s_lo, s_hi, s_sum, s_or;
     __shared__ uint32_t s_w[NW];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int tile = blockIdx.x, f = blockIdx.y;
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
         __syncthreads();
         if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
         __syncthreads();
-        tile_hist16_careful<kCarefulBits, NT>(h16, s_lo, s_hi, src_base, step, frame_stride, g, hist, ranges, 1);   // its counters fill the same LDS
+        tile_hist16_careful<kCarefulBits, NT>(h16, s_lo, s_hi, s_or, src_base, step, frame_stride, g, hist, ranges, 1);   // its counters fill the same LDS
         if (t == 0) settle_frame();
         return;
     }
@@ -472,9 +494,13 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
     if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | kLutDone; ranges[tile_id] = r; settle_frame(); }
 }
 
-// grid = (tiles, frames), 1024 threads.  Bins are walked in chunks of 4096, four consecutive bins per thread (one 16-byte load,
-// one 8-byte store), over [frame lo & ~3, frame hi] only.  Semantics of clahe.cpp for histSize 65536: clip at clip16, excess / 65536
-// added to every bin, the residual spread with stride max(65536 / residual, 1); then the prefix sum scaled by lut_scale16.
+// grid = (tiles, frames), 1024 threads.  Works in the frame's COMPRESSED domain j = value >> shift (shift = the smallest of its tiles'
+// shifts; 0 for ordinary content, where j is the value itself): bins are walked in chunks of 4096, four consecutive j per thread, over
+// [frame lo >> shift & ~3, frame hi >> shift] only, and the LUT is stored at index j.  Semantics of clahe.cpp for histSize 65536: clip at
+// clip16, excess / 65536 added to every one of the 65 536 bins, the residual spread with stride max(65536 / residual, 1); then the
+// prefix sum scaled by lut_scale16.  Bins that cannot be populated (below the range, between multiples of 1 << shift) still receive
+// `batch` and their share of the residual increments: in closed form,
+//     sum over bins <= b  =  (clipped counts of the populated bins <= b)  +  batch * (b + 1)  +  min(residual, b / rstep + 1).
 __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, const Range16* __restrict__ ranges, ClaheGeom g,
                                                          float lut_scale16, int clip16, uint16_t* __restrict__ luts, Range16* __restrict__ frame_ranges,
                                                          const uint32_t* __restrict__ frame_done)
@@ -482,7 +508,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     // tile_hist12_kernel has written every LUT of this frame (bins 0..4095: all anybody reads) and the frame's range: one scalar load
     if (frame_done && frame_done[blockIdx.y]) return;
     __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_flo, s_fhi;
+    __shared__ uint32_t s_flo, s_fhi, s_fs;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int tiles = gridDim.x;
     const size_t tile_id = (size_t)blockIdx.y * tiles + blockIdx.x;
@@ -498,38 +524,49 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
         total = tot;
         return off + incl;
     };
-    // frame range: union of the tiles' ranges (every workgroup of the frame computes the same two numbers)
-    if (t == 0) { s_flo = 0xffffu; s_fhi = 0; }
+    // frame range and shift: union / minimum over the tiles (every workgroup of the frame computes the same three numbers)
+    if (t == 0) { s_flo = 0xffffu; s_fhi = 0; s_fs = 15u; }
     __syncthreads();
     {
-        uint32_t l = 0xffffu, u = 0;
+        uint32_t l = 0xffffu, u = 0, sh = 15u;
         const Range16* fr = ranges + (size_t)blockIdx.y * tiles;
-        for (int i = t; i < tiles; i += 1024) { const Range16 r = fr[i]; l = min(l, r.lo); u = max(u, r.hi & ~kLutDone); }
+        for (int i = t; i < tiles; i += 1024) { const Range16 r = fr[i]; l = min(l, r.lo); u = max(u, range_hi(r.hi)); sh = min(sh, range_shift(r.hi)); }
         if (t < tiles) {
             __hip_atomic_fetch_min(&s_flo, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_max(&s_fhi, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(&s_fs, sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
-    const uint32_t flo = s_flo, fhi = s_fhi;
-    Range16 own = ranges[tile_id];
-    if (blockIdx.x == 0 && t == 0) { Range16 r; r.lo = flo; r.hi = fhi; frame_ranges[blockIdx.y] = r; }
+    const uint32_t flo = s_flo, fhi = s_fhi, sft = s_fs;
+    const Range16 own_r = ranges[tile_id];
+    if (blockIdx.x == 0 && t == 0) { Range16 r; r.lo = flo; r.hi = fhi | (sft << 16); frame_ranges[blockIdx.y] = r; }
     // tile_hist12_kernel has already written this tile's LUT for bins 0..4095: that is all anybody reads if the whole frame stayed below
-    if ((own.hi & kLutDone) && fhi < (uint32_t)kBins12) return;
-    own.hi &= ~kLutDone;
-    auto load4 = [&](uint32_t b0, int* v) {                       // bins b0..b0+3 of this tile, zero outside its stored range
-        if (b0 + 3 < own.lo || b0 > own.hi) { v[0] = v[1] = v[2] = v[3] = 0; return; }
-        const u32x4 q = *reinterpret_cast<const u32x4*>(h + b0);
-        const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+    if ((own_r.hi & kLutDone) && fhi < (uint32_t)kBins12 && sft == 0) return;
+    const uint32_t own_lo = own_r.lo, own_hi = range_hi(own_r.hi);
+    // counts of the compressed bins j0 .. j0 + 3 of this tile (bin j holds value j << shift), zero outside the tile's stored range
+    auto load4 = [&](uint32_t j0, int* v) {
+        if (sft == 0) {
+            if (j0 + 3 < own_lo || j0 > own_hi) { v[0] = v[1] = v[2] = v[3] = 0; return; }
+            const u32x4 q = *reinterpret_cast<const u32x4*>(h + j0);
+            const uint32_t x[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (b0 + k >= own.lo && b0 + k <= own.hi) ? (int)x[k] : 0;
+            for (int k = 0; k < 4; ++k) v[k] = (j0 + k >= own_lo && j0 + k <= own_hi) ? (int)x[k] : 0;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t b = (j0 + k) << sft;
+            v[k] = (b >= own_lo && b <= own_hi) ? (int)h[b] : 0;
+        }
     };
+    const uint32_t jhi = fhi >> sft, own_jlo = own_lo >> sft, own_jhi = own_hi >> sft;
     int batch = 0, residual = 0, rstep = 1;
     if (clip16 > 0) {
         uint32_t excess = 0;
-        for (uint32_t b0 = (own.lo & ~3u) + (uint32_t)t * 4; b0 <= own.hi; b0 += 4096) {
+        for (uint32_t j0 = (own_jlo & ~3u) + (uint32_t)t * 4; j0 <= own_jhi; j0 += 4096) {
             int v[4];
-            load4(b0, v);
+            load4(j0, v);
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (v[k] > clip16) excess += (uint32_t)(v[k] - clip16);
         }
@@ -539,28 +576,18 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
         residual = (int)clipped - batch * kHist16;
         if (residual != 0) { rstep = kHist16 / residual; if (rstep < 1) rstep = 1; }
     }
-    // prefix of the bins below the scan start: empty bins hold `batch`, plus 1 where b % rstep == 0 and b / rstep < residual
-    const uint32_t start = flo & ~3u;
-    uint32_t running = 0;
-    if (clip16 > 0) {
-        const uint32_t ninc = residual == 0 ? 0u : min((uint32_t)residual, (start + (uint32_t)rstep - 1) / (uint32_t)rstep);
-        running = (uint32_t)batch * start + ninc;
-    }
-    for (uint32_t c0 = start; c0 <= fhi; c0 += 4096) {
-        const uint32_t b0 = c0 + (uint32_t)t * 4;
-        const bool active = b0 <= fhi;
+    const uint32_t start = (flo >> sft) & ~3u;
+    uint32_t running = 0;                                           // clipped counts of the populated bins before the chunk
+    for (uint32_t c0 = start; c0 <= jhi; c0 += 4096) {
+        const uint32_t j0 = c0 + (uint32_t)t * 4;
+        const bool active = j0 <= jhi;
         int v[4] = {0, 0, 0, 0};
         uint32_t local = 0;
         if (active) {
-            load4(b0, v);
+            load4(j0, v);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (clip16 > 0) {
-                    if (v[k] > clip16) v[k] = clip16;
-                    v[k] += batch;
-                    const int b = (int)b0 + k;
-                    if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++v[k];
-                }
+                if (clip16 > 0 && v[k] > clip16) v[k] = clip16;
                 local += (uint32_t)v[k];
                 v[k] = (int)local;                                   // inclusive prefix within the thread's four bins
             }
@@ -572,11 +599,17 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
             uint32_t packed[2];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                int r = __float2int_rn(__fmul_rn((float)(int)(before + (uint32_t)v[k]), lut_scale16));
+                uint32_t sum = before + (uint32_t)v[k];
+                if (clip16 > 0) {
+                    const uint32_t b = (j0 + (uint32_t)k) << sft;        // the value this bin stands for
+                    sum += (uint32_t)batch * (b + 1u);
+                    if (residual != 0) sum += min((uint32_t)residual, b / (uint32_t)rstep + 1u);
+                }
+                int r = __float2int_rn(__fmul_rn((float)(int)sum, lut_scale16));
                 r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
                 if (k & 1) packed[k >> 1] |= (uint32_t)r << 16; else packed[k >> 1] = (uint32_t)r;
             }
-            *reinterpret_cast<uint2*>(lut + b0) = make_uint2(packed[0], packed[1]);
+            *reinterpret_cast<uint2*>(lut + j0) = make_uint2(packed[0], packed[1]);
         }
     }
 }
@@ -614,7 +647,10 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const uint16_t* lb = lf + ((size_t)ty1 * g.tiles_x + tx2) * kHist16;
     const uint16_t* lc = lf + ((size_t)ty2 * g.tiles_x + tx1) * kHist16;
     const uint16_t* ld = lf + ((size_t)ty2 * g.tiles_x + tx2) * kHist16;
-    const Range16 fr = frame_ranges[f];
+    // everything below works in the frame's COMPRESSED domain j = value >> sft (see Range16; sft = 0 for ordinary content)
+    const Range16 fr_raw = frame_ranges[f];
+    const uint32_t sft = range_shift(fr_raw.hi);
+    Range16 fr; fr.lo = fr_raw.lo >> sft; fr.hi = range_hi(fr_raw.hi) >> sft;
     const uint32_t start = fr.lo & ~3u;
     // A range wider than the table is walked in WINDOWS of kInterp16Entries values: the table is staged once per window and a pixel is
     // finished in the window its value falls into (2-byte stores).  That re-reads the workgroup's pixels once per window, so it
@@ -659,7 +695,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
             const int phase = passes > 1 ? 0 : t / ngroups;
             if (gi >= ngroups || phase >= phases) continue;
             const int x0 = (g_lo + gi) << 3;
-            auto note = [&](uint32_t v) { seen |= 1u << ((v - start) / (uint32_t)kInterp16Entries); };
+            auto note = [&](uint32_t v) { seen |= 1u << (((v >> sft) - start) / (uint32_t)kInterp16Entries); };
             if (al16 && x0 + 8 <= g.width) {                        // a superset of the owned pixels is fine here
                 for (int y = y_lo + phase; y < y_hi; y += phases) {
                     const u32x4 q = *reinterpret_cast<const u32x4*>(src + (long long)y * src_step + 2 * (long long)x0);
@@ -751,7 +787,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                     const f32x2 yv = {ya1, ya};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const uint32_t idx = min(px[j] - w0, (uint32_t)kInterp16F32Entries - 1);
+                        const uint32_t idx = min((px[j] >> sft) - w0, (uint32_t)kInterp16F32Entries - 1);
                         const f32x4 e = tabf[idx];
                         const f32x2 ac = {e.x, e.y}, bd = {e.z, e.w}, xw = {xa1[j], xa[j]};
                         float r;
@@ -770,7 +806,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     // owned pixels of this window index the table directly; anything else is masked out later: clamp its index
-                    const uint32_t idx = min(px[j] - w0, (uint32_t)kInterp16Entries - 1);
+                    const uint32_t idx = min((px[j] >> sft) - w0, (uint32_t)kInterp16Entries - 1);
                     const uint2 e = tab[idx];
                     const float a = (float)(e.x & 0xffffu), b = (float)(e.x >> 16), c = (float)(e.y & 0xffffu), d = (float)(e.y >> 16);
                     int r = __float2int_rn(clahe_blend_f<FMA>(a, b, c, d, xa[j], xa1[j], ya, ya1));
@@ -826,7 +862,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                         for (int j = 0; j < 8; ++j) px[j] = (own >> j) & 1u ? *reinterpret_cast<const uint16_t*>(sp + 2 * j) : 0xffffffffu;
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) if (((own >> j) & 1u) && px[j] - w0 < (uint32_t)kInterp16Entries) todo |= 1u << j;   // this window's pixels
+                    for (int j = 0; j < 8; ++j) if (((own >> j) & 1u) && (px[j] >> sft) - w0 < (uint32_t)kInterp16Entries) todo |= 1u << j;   // this window's pixels
                     if (!todo) continue;
                     blend_row(y, px, res);
 #pragma unroll
@@ -850,7 +886,8 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uin
 {
     const int f = blockIdx.z;
     const Range16 fr = frame_ranges[f];
-    if (fr.hi - (fr.lo & ~3u) < (uint32_t)kInterp16Entries || src_base != dst_base) return;   // done from LDS tables (one window, or several when not in place)
+    const uint32_t sft = range_shift(fr.hi);                        // the LUTs are stored at index value >> sft
+    if ((range_hi(fr.hi) >> sft) - ((fr.lo >> sft) & ~3u) < (uint32_t)kInterp16Entries || src_base != dst_base) return;   // done from LDS tables (one window, or several when not in place)
     const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
     const int bx = (g.width + kThreads - 1) / kThreads;
     const long long items = (long long)bx * g.height;
@@ -867,7 +904,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uin
             ys[k] = (int)(it / bx);
             xs[k] = (int)(it - (long long)ys[k] * bx) * kThreads + threadIdx.x;
             on[k] = it < items && xs[k] < g.width;
-            v[k] = on[k] ? *reinterpret_cast<const uint16_t*>(src + (long long)ys[k] * src_step + 2 * (long long)xs[k]) : 0u;
+            v[k] = on[k] ? (uint32_t)*reinterpret_cast<const uint16_t*>(src + (long long)ys[k] * src_step + 2 * (long long)xs[k]) >> sft : 0u;
         }
         float a[kChains], b[kChains], c[kChains], d[kChains], xa[kChains], ya[kChains];
 #pragma unroll
@@ -926,7 +963,8 @@ __global__ __launch_bounds__(kThreads) void transpose_lut16_kernel(const uint16_
 // as clahe_interp16_kernel, gathering from the value-major layout
 __global__ __launch_bounds__(kThreads) void clahe_interp16T_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                   uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
-                                                                  ClaheGeom g, const uint16_t* __restrict__ lutT)
+                                                                  ClaheGeom g, const uint16_t* __restrict__ lutT,
+                                                                  const Range16* __restrict__ frame_ranges)
 {
     const int f = blockIdx.z, y = blockIdx.y;
     const int x = blockIdx.x * kThreads + threadIdx.x;
@@ -940,7 +978,8 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16T_kernel(const uint8_t
     int ty1 = floor_f32_to_int(tyf);
     const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
     int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
-    const uint32_t v = *reinterpret_cast<const uint16_t*>(src_base + (long long)f * src_frame + (long long)y * src_step + 2 * (long long)x);
+    const uint32_t v = (uint32_t)*reinterpret_cast<const uint16_t*>(src_base + (long long)f * src_frame + (long long)y * src_step + 2 * (long long)x)
+                       >> range_shift(frame_ranges[f].hi);       // the LUTs are stored at index value >> shift
     const uint16_t* e = lutT + ((size_t)f * kHist16 + v) * tiles;
     const float a = (float)e[ty1 * g.tiles_x + tx1], b = (float)e[ty1 * g.tiles_x + tx2];
     const float c = (float)e[ty2 * g.tiles_x + tx1], d = (float)e[ty2 * g.tiles_x + tx2];

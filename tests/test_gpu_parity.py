@@ -1012,6 +1012,45 @@ def test_clahe16_twelve_bit_bet_mixed_outcomes(ctx):
             ctx.set_option("clahe16_fast12", 1)
 
 
+def test_clahe16_msb_aligned_content(ctx):
+    """10- and 12-bit samples stored in the HIGH bits of the 16-bit word (P010 / P016 video): every value is a multiple of 1 << shift,
+    the frame spans the whole 16-bit range but populates 1024 / 4096 values.  The LUT kernel and the interpolation then work at
+    value >> shift.  Shifts 1..8, black bars (tiles of zeros: any shift), a constant tile, one odd pixel that voids the shift, frames of
+    different shifts in one batch, vector and padded geometry, in place -- every frame against the oracle."""
+    rng = np.random.default_rng(2026)
+    def msb(bits, shift, shape): return (rng.integers(0, 1 << bits, shape, dtype=np.uint32) << shift).astype(np.uint16)
+    for (w, h, tx, ty) in [(640, 368, 8, 8), (323, 201, 4, 3), (1280, 96, 8, 2)]:
+        f10 = msb(10, 6, (h, w))
+        f12 = msb(12, 4, (h, w))
+        f8 = msb(8, 8, (h, w))
+        f15 = msb(15, 1, (h, w))                                      # 32 768 populated values: several table windows at shift 1
+        bars = f10.copy(); bars[: h // 4] = 0; bars[-h // 5:] = 64 << 6   # black bars: tiles whose own shift is larger than the frame's
+        flat = f12.copy(); flat[h // 3: h // 2, w // 4: w // 2] = 0x8000
+        odd = f10.copy(); odd[h // 2, w // 2] |= 1                        # one odd value: the frame has no shift any more
+        lsb = rng.integers(0, 4096, (h, w), dtype=np.uint16)            # ordinary 12-bit content beside them
+        frames = [f10, f12, f8, f15, bars, flat, odd, lsb]
+        for cfg in ((2.0, tx, ty), (0.0, tx, ty), (40.0, tx, ty)):
+            want = [oracle.clahe16(f, *cfg) for f in frames]
+            for k, f in enumerate(frames):
+                assert np.array_equal(ctx.clahe16(f, *cfg), want[k]), (w, h, cfg, "single", k)
+            d_in = dev(np.stack(frames).view(np.int16))
+            d_out = torch.zeros_like(d_in)
+            ctx.clahe16_batch_dev(d_in, d_out, w, h, len(frames), *cfg)
+            ctx.synchronize()
+            out = host(d_out).view(np.uint16)
+            for k in range(len(frames)):
+                assert np.array_equal(out[k], want[k]), (w, h, cfg, "batch", k)
+            ctx.clahe16_batch_dev(d_in, d_in, w, h, len(frames), *cfg)    # in place
+            ctx.synchronize()
+            assert np.array_equal(host(d_in).view(np.uint16), out), (w, h, cfg, "in place")
+    try:                                                                  # the value-major LUT layout follows the shift too
+        ctx.set_option("clahe16_transposed", 1)
+        f = msb(10, 6, (180, 320))
+        assert np.array_equal(ctx.clahe16(f, 2.0, 8, 8), oracle.clahe16(f, 2.0, 8, 8))
+    finally:
+        ctx.set_option("clahe16_transposed", 0)
+
+
 def test_clahe16_frame_done_flags_over_many_frames(ctx):
     """The last tile workgroup of each FRAME settles the frame's range and whether every tile wrote its LUT in the histogram kernel
     (the LUT kernel then leaves on one scalar load); the per-frame arrival words must come back to zero after every launch.  150

@@ -10,6 +10,8 @@ for kv in sys.argv[3:]:                                      # name=value option
     k, v = kv.split("="); ctx.set_option(k, int(v)); print("option", k, "=", v)
 def u16(lo, hi): return torch.randint(lo, hi, (n, h, w), dtype=torch.int32, device="cuda").to(torch.int16)   # bit pattern of the ushort
 cases = (("12-bit 0..4095", u16(0, 4096)), ("10-bit 0..1023", u16(0, 1024)), ("narrow 1000..1399", u16(1000, 1400)), ("13-bit 0..8191", u16(0, 8192)),
+         ("10-bit << 6 (P010)", (torch.randint(0, 1024, (n, h, w), dtype=torch.int32, device="cuda") << 6).to(torch.int16)),
+         ("12-bit << 4 (MSB-aligned)", (torch.randint(0, 4096, (n, h, w), dtype=torch.int32, device="cuda") << 4).to(torch.int16)),
          ("15-bit 0..32767", u16(0, 32768)), ("16-bit full", u16(0, 65536)), ("const 777", torch.full((n, h, w), 777, dtype=torch.int16, device="cuda")),
          # full 16-bit range over the frame, locally smooth (a diagonal ramp + 9 bits of noise): what a 16-bit photograph looks like to the windows
          ("16-bit smooth ramp", ((torch.arange(h, device="cuda").view(1, h, 1) * 12 + torch.arange(w, device="cuda").view(1, 1, w) * 10
