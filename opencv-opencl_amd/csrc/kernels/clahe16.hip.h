@@ -263,6 +263,7 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
 // A tile that loses the bet -- some value >= 4096, noticed after the first four vectors per lane or at the end -- is redone by
 // tile_hist16_careful (as many counters per sweep as fit the same LDS: 8192 with two copies, up to eight sweeps) in the same workgroup.  ranges[tile].hi carries bit 31 when the tile's LUT was written here.
 constexpr uint32_t kLutDone = 0x80000000u;
+constexpr uint32_t kHistCompressed = 0x40000000u;   // Range16.hi of a tile: its histogram is stored at index value >> shift (tile_hist12_kernel with a shift)
 constexpr int kBins12 = 4096;
 // Shipped shape: 1024 threads, 4 copies = 64 KiB of LDS, two workgroups per CU.  512 threads x 2 copies (32 KiB, four workgroups per
 // CU) measured the same on 12-bit content (16 4K frames: 59.6 us alone either way; the sweep on its own 45 us either way,
@@ -271,25 +272,27 @@ constexpr int kHist12Threads = 1024;
 constexpr int kCopies12 = 4;
 constexpr int kHist12Words = kBins12 * kCopies12;
 
+// sft / wl are wave-uniform: a pixel is counted at bits sft .. sft + wl - 1 of its value (wl = min(12, 16 - sft): v_bfe_u32 on the packed
+// pair must not reach into the neighbour's bits).  por collects the OR of everything seen: it tells at the end whether every value
+// really was a multiple of 1 << sft AND below 4096 << sft (some value has a bit set iff the OR has it), so the sweep tracks no
+// minimum / maximum -- the tile's range is read off its histogram afterwards.
 template <int COPIES>
-__device__ __forceinline__ void hist12_dword(uint32_t* h, uint32_t w, uint32_t cp, u16x2& pmin, u16x2& pmax)
+__device__ __forceinline__ void hist12_dword(uint32_t* h, uint32_t w, uint32_t cp, uint32_t sft, uint32_t wl, uint32_t& por)
 {
-    const u16x2 v = __builtin_bit_cast(u16x2, w);
-    pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
-    lds_inc(h, ((w & (kBins12 - 1)) * COPIES) | cp);
-    lds_inc(h, (((w >> 16) & (kBins12 - 1)) * COPIES) | cp);
+    por |= w;
+    lds_inc(h, (__builtin_amdgcn_ubfe(w, sft, wl) * COPIES) | cp);
+    lds_inc(h, (__builtin_amdgcn_ubfe(w, sft + 16u, wl) * COPIES) | cp);
 }
 template <int COPIES>
-__device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t cp, u16x2& pmin, u16x2& pmax)
+__device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t cp, uint32_t sft, uint32_t wl, uint32_t& por)
 {
     const uint32_t v0 = q.x & 0xffffu;
     const bool flat = q.x == q.y && q.y == q.z && q.z == q.w && v0 == (q.x >> 16);
     if (__builtin_expect(flat, 0)) {                                // flat regions never reach the LDS pixel by pixel (as hist16_fast_vec)
-        const u16x2 v = __builtin_bit_cast(u16x2, q.x);
-        pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v);
+        por |= q.x;
         const unsigned long long active = __ballot(1);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
-        const uint32_t idx = ((v0 & (kBins12 - 1)) * COPIES) | cp;
+        const uint32_t idx = (__builtin_amdgcn_ubfe(v0, sft, wl) * COPIES) | cp;
         if (__ballot(v0 == first) == active) {
             if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(active)) lds_add(h, idx, 8u * (uint32_t)__builtin_popcountll(active));
         } else {
@@ -297,14 +300,14 @@ __device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t
         }
         return;
     }
-    hist12_dword<COPIES>(h, q.x, cp, pmin, pmax); hist12_dword<COPIES>(h, q.y, cp, pmin, pmax);
-    hist12_dword<COPIES>(h, q.z, cp, pmin, pmax); hist12_dword<COPIES>(h, q.w, cp, pmin, pmax);
+    hist12_dword<COPIES>(h, q.x, cp, sft, wl, por); hist12_dword<COPIES>(h, q.y, cp, sft, wl, por);
+    hist12_dword<COPIES>(h, q.z, cp, sft, wl, por); hist12_dword<COPIES>(h, q.w, cp, sft, wl, por);
 }
 
 // grid = (tiles, frames), NT threads, 4096 * COPIES * 4 bytes of dynamic LDS; vector geometry only (the host checks: no padding,
 // tile_w % 8 == 0, 16-B aligned rows).  A thread owns 4096 / NT consecutive bins in the LUT stage.
 template <int NT, int COPIES>
-__global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
+__global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
                                                         ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
                                                         float lut_scale16, int clip16, uint16_t* __restrict__ luts,
                                                         uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done)
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
     const int vitems = g.tile_h * slots;
     const uint8_t* tbase = src + (long long)ty * g.tile_h * step + (long long)tx * g.tile_w * 2;
     const uint32_t cp = (uint32_t)t & (uint32_t)(COPIES - 1);
-    if (t == 0) { s_lo = 0xffffu; s_hi = 0; s_sum = 0; }
+    if (t == 0) { s_lo = 0xffffu; s_hi = 0; s_sum = 0; s_or = 0; }
     for (int i = t; i < kBins12 * COPIES / 4; i += NT) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
     // (row, slot) items walked incrementally, four predicated loads per set
     int row = t / slots, slot = t - row * slots;
@@ -343,33 +346,49 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
     };
     u32x4 cur[4], nxt[4]; bool cv[4], nv[4];
     load_set(t, cur, cv);
-    // the first set decides early: a frame with more than 12 bits shows it in (almost) any 32 pixels per lane
+    // The first set -- and, in wave 0, one vector per lane from 64 places spread over the tile (a letterbox bar at the top says nothing
+    // about the picture below it) -- decides the bet: sft = the trailing zero bits their OR has (0 for ordinary content; 6 for P010,
+    // 4 for MSB-aligned 12-bit), and the bet is that every value of the tile is a multiple of 1 << sft below 4096 << sft.  A frame that
+    // cannot be so shows it here (almost) always.  Whatever is assumed here is verified at the end on all pixels.
     uint32_t m0 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) m0 |= cur[k].x | cur[k].y | cur[k].z | cur[k].w;      // OR of the packed pixels: bit 12..15 of either half set?
-    const bool early_lost = __syncthreads_or((m0 & 0xf000f000u) != 0u) != 0;             // (also orders the zeroing above)
-    bool lost = early_lost;
-    u16x2 pmin = {0xffff, 0xffff}, pmax = {0, 0};
+    for (int k = 0; k < 4; ++k) m0 |= cur[k].x | cur[k].y | cur[k].z | cur[k].w;      // OR of the packed pixels
+    if (wv == 0) {
+        const int it_s = (int)(((long long)lane * vitems) >> 6);
+        const int row_s = it_s / slots, slot_s = it_s - row_s * slots;
+        const u32x4 qs = *reinterpret_cast<const u32x4*>(tbase + (long long)row_s * step + (slot_s << 4));
+        m0 |= qs.x | qs.y | qs.z | qs.w;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m0 |= (uint32_t)__shfl_xor((int)m0, d, 64);
+    if (lane == 0) s_w[wv] = m0;                                    // one slot per wave: nothing to initialise, one barrier
+    __syncthreads();                                                // (also orders the zeroing above)
+    uint32_t o32 = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) o32 |= s_w[k];
+    const uint32_t o16 = (o32 | (o32 >> 16)) & 0xffffu;
+    const uint32_t sft = o16 ? (uint32_t)__builtin_ctz(o16) : 0u;  // uniform
+    const uint32_t wl = min(12u, 16u - sft);
+    bool lost = (o16 >> sft) >= (uint32_t)kBins12;                  // uniform
     if (!lost) {
+        uint32_t por = 0;
         for (int it = t; it < vitems; it += 4 * NT) {
             const bool more = it + 4 * NT < vitems;                  // uniform per lane only; the loads are predicated anyway
             if (more) load_set(it + 4 * NT, nxt, nv);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (cv[k]) hist12_vec<COPIES>(h16, cur[k], cp, pmin, pmax);
+            for (int k = 0; k < 4; ++k) if (cv[k]) hist12_vec<COPIES>(h16, cur[k], cp, sft, wl, por);
             if (more) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { cur[k] = nxt[k]; cv[k] = nv[k]; }
             }
         }
-        uint32_t lmin = min((uint32_t)pmin.x, (uint32_t)pmin.y), lmax = max((uint32_t)pmax.x, (uint32_t)pmax.y);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64)); }
-        if (lane == 0) {
-            __hip_atomic_fetch_min(&s_lo, lmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_max(&s_hi, lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        for (int d = 32; d >= 1; d >>= 1) por |= (uint32_t)__shfl_xor((int)por, d, 64);
+        if (lane == 0 && por) __hip_atomic_fetch_or(&s_or, por, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
-        lost = s_hi >= (uint32_t)kBins12;
+        // the bet held if every value is below 4096 << sft and (with a shift) a multiple of 1 << sft
+        const uint32_t all16 = (s_or | (s_or >> 16)) & 0xffffu;
+        lost = (all16 >> sft) >= (uint32_t)kBins12 || (sft != 0 && (all16 & ((1u << sft) - 1u)) != 0u);
     }
     // The frame's range and "every tile wrote its LUT here" are settled by the LAST workgroup of the frame to arrive, so that
     // tile_lut16_kernel can leave at once on one scalar load (launched only to leave, it still cost 26 us per 16 frames in the sequence:
@@ -385,14 +404,14 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
     unsigned long long before64 = 0;
     uint32_t own_bits = 0, own_add = 1u;
     unsigned long long* const sy = reinterpret_cast<unsigned long long*>(sync) + 2 * (size_t)f;
-    if (t == 0) {
-        if (!lost) {
-            own_bits = (1u << (s_lo >> 7)) | (1u << (s_hi >> 7));
+    auto arrive = [&](bool done, uint32_t tlo, uint32_t thi) {      // thread 0
+        if (done) {
+            own_bits = (1u << (tlo >> 7)) | (1u << (thi >> 7));
             own_add = 0x10001u;
             __hip_atomic_fetch_or(sy, (unsigned long long)own_bits << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         before64 = __hip_atomic_fetch_add(sy, (unsigned long long)own_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    };
     auto settle_frame = [&]() {                                     // thread 0, last statement of either path
         if ((uint32_t)(before64 & 0xffffu) != gridDim.x - 1) return;
         const uint32_t nd = (uint32_t)((before64 >> 16) & 0xffffu) + (own_add >> 16);
@@ -404,6 +423,7 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
         frame_done[f] = nd == gridDim.x ? 1u : 0u;
     };
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
+        if (t == 0) arrive(false, 0u, 0u);
         __syncthreads();
         if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
         __syncthreads();
@@ -411,7 +431,6 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
         if (t == 0) settle_frame();
         return;
     }
-    const uint32_t lo = s_lo, hi = s_hi;
     // ---- the tile's 4096 counts: thread t owns bins BPT * t .. BPT * t + BPT - 1 (sum of the copies)
     // Read out conflict-free: consecutive lanes read the consecutive copies of consecutive bins, the 4096 sums are compacted to the head
     // of the LDS array, and each thread then picks up its consecutive bins.
@@ -434,12 +453,37 @@ __global__ __launch_bounds__(NT) void tile_hist12_kernel(const uint8_t* __restri
         }
     }
     const uint32_t b0 = (uint32_t)t * BPT;
-    // the histogram itself, for tile_lut16_kernel should the FRAME turn out wider than 4096 values (another tile lost its bet)
+    // the tile's range, read off the histogram: lowest / highest populated bin (exact: every value is a multiple of 1 << sft)
+    {
+        uint32_t first = 0xffffu, last = 0u;
 #pragma unroll
-    for (int j = 0; j < BPT / 4; ++j) {
-        const uint32_t bj = b0 + 4 * j;
-        if (bj + 3 >= (lo & ~3u) && bj <= hi)
-            *reinterpret_cast<u32x4*>(hist + tile_id * kHist16 + bj) = u32x4{(uint32_t)v[4 * j], (uint32_t)v[4 * j + 1], (uint32_t)v[4 * j + 2], (uint32_t)v[4 * j + 3]};
+        for (int k = BPT - 1; k >= 0; --k) if (v[k]) first = b0 + (uint32_t)k;
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) if (v[k]) last = b0 + (uint32_t)k;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { first = min(first, (uint32_t)__shfl_xor((int)first, d, 64)); last = max(last, (uint32_t)__shfl_xor((int)last, d, 64)); }
+        if (lane == 0) {
+            __hip_atomic_fetch_min(&s_lo, first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&s_hi, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+    }
+    const uint32_t lo = s_lo << sft, hi = s_hi << sft;
+    if (t == 0) arrive(sft == 0, lo, hi);                           // (a tile with a shift leaves its LUT to tile_lut16_kernel: the FRAME's shift decides the domain)
+    // the histogram itself (bin j = count of value j << sft), for tile_lut16_kernel: always needed with a shift, and without one should
+    // the FRAME turn out wider than 4096 values (another tile lost its bet)
+    {
+        const uint32_t lo_c = lo >> sft, hi_c = hi >> sft;
+#pragma unroll
+        for (int j = 0; j < BPT / 4; ++j) {
+            const uint32_t bj = b0 + 4 * j;
+            if (bj + 3 >= (lo_c & ~3u) && bj <= hi_c)
+                *reinterpret_cast<u32x4*>(hist + tile_id * kHist16 + bj) = u32x4{(uint32_t)v[4 * j], (uint32_t)v[4 * j + 1], (uint32_t)v[4 * j + 2], (uint32_t)v[4 * j + 3]};
+        }
+    }
+    if (sft != 0) {                                               // uniform: the LUT of a shifted tile is the LUT kernel's job
+        if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (sft << 16) | kHistCompressed; ranges[tile_id] = r; settle_frame(); }
+        return;
     }
     auto block_scan = [&](uint32_t x, uint32_t& total) -> uint32_t {  // inclusive prefix of x over the NT threads
         const uint32_t incl = wave_incl_scan(x);
@@ -544,8 +588,28 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     // tile_hist12_kernel has already written this tile's LUT for bins 0..4095: that is all anybody reads if the whole frame stayed below
     if ((own_r.hi & kLutDone) && fhi < (uint32_t)kBins12 && sft == 0) return;
     const uint32_t own_lo = own_r.lo, own_hi = range_hi(own_r.hi);
+    // where this tile's counts are: at index value (careful sweeps, unshifted bets) or at index value >> own shift (shifted bets)
+    const uint32_t own_store = (own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u;      // >= sft: sft is the minimum over the tiles
+    const uint32_t dsh = own_store - sft;
     // counts of the compressed bins j0 .. j0 + 3 of this tile (bin j holds value j << shift), zero outside the tile's stored range
     auto load4 = [&](uint32_t j0, int* v) {
+        if (own_store == sft) {                                     // stored in the frame's own domain: one 16-byte load
+            const uint32_t jl = own_lo >> sft, jh = own_hi >> sft;
+            if (j0 + 3 < jl || j0 > jh) { v[0] = v[1] = v[2] = v[3] = 0; return; }
+            const u32x4 q = *reinterpret_cast<const u32x4*>(h + j0);
+            const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (j0 + k >= jl && j0 + k <= jh) ? (int)x[k] : 0;
+            return;
+        }
+        if (own_store != 0) {                                       // stored at a coarser shift than the frame's: every (1 << dsh)-th bin
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = j0 + k, b = j << sft;
+                v[k] = ((j & ((1u << dsh) - 1u)) == 0u && b >= own_lo && b <= own_hi) ? (int)h[j >> dsh] : 0;
+            }
+            return;
+        }
         if (sft == 0) {
             if (j0 + 3 < own_lo || j0 > own_hi) { v[0] = v[1] = v[2] = v[3] = 0; return; }
             const u32x4 q = *reinterpret_cast<const u32x4*>(h + j0);
