@@ -796,9 +796,10 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
                                                     src_frame=(h + 8) * pitch, dst_step=pitch, dst_frame=(h + 8) * pitch, stream=stream), 10)
     res["strided_roi_equalize_frames_per_s"] = round(Br / (ms * 1e-3), 1)
     # 12-bit content (what 16-bit video carries: the range fits the LDS pair tables) and full-range 16-bit content (L2 gathers)
-    for name, hi, nb in (("clahe16_8x8_12bit_frames_per_s", 4096, 16), ("clahe16_8x8_12bit_32_per_call_frames_per_s", 4096, 32),
-                         ("clahe16_8x8_fullrange_frames_per_s", 65536, 4)):
-        s16 = torch.randint(0, hi, (nb, h, w), dtype=torch.int32, device="cuda").to(torch.int16)     # bit pattern of the ushort
+    # ... and 10-bit samples in the HIGH bits of the word, as P010 video stores them: full 16-bit span, 1024 populated values
+    for name, hi, nb, shift in (("clahe16_8x8_12bit_frames_per_s", 4096, 16, 0), ("clahe16_8x8_12bit_32_per_call_frames_per_s", 4096, 32, 0),
+                                ("clahe16_8x8_p010_10bit_msb_frames_per_s", 1024, 16, 6), ("clahe16_8x8_fullrange_frames_per_s", 65536, 4, 0)):
+        s16 = (torch.randint(0, hi, (nb, h, w), dtype=torch.int32, device="cuda") << shift).to(torch.int16)     # bit pattern of the ushort
         o16 = torch.empty_like(s16)
         ms = timeit(lambda: ctx.clahe16_batch_dev(s16, o16, w, h, nb, 2.0, 8, 8, stream=stream), 5)
         res[name] = round(nb / (ms * 1e-3), 1)

@@ -396,8 +396,8 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
     // bits 0..15 arrivals, 16..31 tiles whose bet held, 32..63 which 128-value buckets hold a tile's lowest / highest value.  A tile
     // ORs its two bucket bits in and then adds its arrival -- two relaxed agent-scope atomics on the SAME address, so every arrival
     // the last workgroup sees comes with its bits (performed at the L2: no write-back / invalidate of this XCD's L2, see
-    // hist_lut_kernel).  Thread 0 issues them here, as soon as the tile knows whether its bet held, and looks at the returned
-    // value only at the very end: waiting here held the whole workgroup at its next barrier (9 us per 16 frames), arriving after
+    // hist_lut_kernel).  Thread 0 issues them as soon as the tile knows its range (or that its bet is lost), and looks at the returned
+    // value only at the very end: waiting for it held the whole workgroup at its next barrier (9 us per 16 frames), arriving after
     // the LUT made thread 0 sit on its own stores.  The range so reported is rounded out to buckets, which only makes the
     // interpolation stage a few more (existing) table entries.  A tile that lost its bet adds an arrival and nothing else: the
     // frame is then not "done" and tile_lut16_kernel derives the exact range itself.

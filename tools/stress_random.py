@@ -53,7 +53,14 @@ while time.time() - t0 < budget:
         lo = int(rng.integers(0, 65000)); hi = min(65536, lo + int(rng.choice([1, 50, 1000, 4096, 4097, 8192, 8193, 20000, 65536])))
         y = rng.integers(lo, hi, (h, w), dtype=np.uint16)
         if rng.integers(0, 3) == 0: y[: h // 2] = lo
-        if not np.array_equal(ctx.clahe16(y, 2.0, 4, 4), oracle.clahe16(y, 2.0, 4, 4)): fail("c16", w, h, lo, hi)
+        sh = 0
+        if rng.integers(0, 2) == 0:                                   # samples in the high bits of the word (P010 / P016): every value a multiple of 1 << sh
+            sh = int(rng.integers(1, 9)); bits = int(rng.integers(1, 17 - sh))
+            y = (rng.integers(0, 1 << bits, (h, w), dtype=np.uint32) << sh).astype(np.uint16)
+            r = int(rng.integers(0, 4))
+            if r == 0: y[: h // 3] = 0                                  # a black bar: tiles with a larger shift than the frame's
+            elif r == 1: y[int(rng.integers(0, h)), int(rng.integers(0, w))] |= 1 << int(rng.integers(0, sh))   # one value voids (or lowers) the shift
+        if not np.array_equal(ctx.clahe16(y, 2.0, 4, 4), oracle.clahe16(y, 2.0, 4, 4)): fail("c16", w, h, lo, hi, sh)
         n["c16"] += 1
     elif k == 5:    # NV12 batches of random even sizes through the fused kernel (or the three-kernel path where it does not apply), both ops
         w, h, nf = int(rng.integers(1, 400)) * 2, int(rng.integers(1, 200)) * 2, int(rng.integers(1, 9))
