@@ -192,7 +192,10 @@ mi_status mi_analyze_diff_u8_batch_dev(mi_ctx* ctx, const void* d_a, size_t a_st
 
 /* ---- CLAHE on CV_16UC1 (OpenCV surface beyond what the reference uses) ------------------------
  * cv::createCLAHE(clip, Size(tx,ty))->apply on 16-bit single-channel images: 65 536 bins, ushort LUTs.
- * Steps / frame strides in BYTES (>= 2*width).  In place allowed. */
+ * Steps / frame strides in BYTES (>= 2*width).  In place allowed.  Results never depend on the content, speed does: frames
+ * that populate at most 4096 values -- 10/12-bit samples in the LOW bits, or in the HIGH bits of the word as P010 / P016
+ * video stores them (every value a multiple of 1 << shift) -- take one pass of tile histograms and one interpolation from
+ * a single table; wider content is walked in windows of the value range. */
 mi_status mi_clahe_u16(mi_ctx* ctx, const uint16_t* src, size_t src_step, uint16_t* dst, size_t dst_step,
                        int width, int height, double clip_limit, int tiles_x, int tiles_y);
 mi_status mi_clahe_u16_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
