@@ -78,11 +78,11 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
             if (g.contract)
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<true>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf);
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges);
             else
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<false>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf);
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges);
             // IN-PLACE frames whose range does not fit the LDS table (their workgroups above returned at once); the launch is a no-op for
             // every other frame, and is left out altogether when the call is not in place (it cost 8 us per call)
             if (sp == dp) {

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
 
 // grid = (tiles, frames), 1024 threads.  Works in the frame's COMPRESSED domain j = value >> shift (shift = the smallest of its tiles'
 // shifts; 0 for ordinary content, where j is the value itself): bins are walked in chunks of 4096, four consecutive j per thread, over
-// [frame lo >> shift & ~3, frame hi >> shift] only, and the LUT is stored at index j.  Semantics of clahe.cpp for histSize 65536: clip at
+// the range of the tile and its eight neighbours only (nobody else's pixels read this LUT), and the LUT is stored at index j.  Semantics of clahe.cpp for histSize 65536: clip at
 // clip16, excess / 65536 added to every one of the 65 536 bins, the residual spread with stride max(65536 / residual, 1); then the
 // prefix sum scaled by lut_scale16.  Bins that cannot be populated (below the range, between multiples of 1 << shift) still receive
 // `batch` and their share of the residual increments: in closed form,
@@ -585,8 +585,23 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     const uint32_t flo = s_flo, fhi = s_fhi, sft = s_fs;
     const Range16 own_r = ranges[tile_id];
     if (blockIdx.x == 0 && t == 0) { Range16 r; r.lo = flo; r.hi = fhi | (sft << 16); frame_ranges[blockIdx.y] = r; }
-    // tile_hist12_kernel has already written this tile's LUT for bins 0..4095: that is all anybody reads if the whole frame stayed below
-    if ((own_r.hi & kLutDone) && fhi < (uint32_t)kBins12 && sft == 0) return;
+    // Who reads this tile's LUT, and where?  Pixels of the tile itself and of its eight neighbours, at THEIR values.  So the LUT is
+    // needed over the union of those nine tiles' ranges only, not over the frame's: one hot pixel at 65535 in a 12-bit frame then
+    // costs the nine tiles around it a long LUT, not all 64 (the interpolation stages by the same rule, see clahe_interp16_kernel).
+    uint32_t need_lo = 0xffffu, need_hi = 0u;
+    {
+        const int tx0 = (int)blockIdx.x % g.tiles_x, ty0 = (int)blockIdx.x / g.tiles_x;
+        const Range16* fr = ranges + (size_t)blockIdx.y * tiles;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int nx = tx0 + dx, ny = ty0 + dy;
+                if (nx < 0 || ny < 0 || nx >= g.tiles_x || ny >= g.tiles_y) continue;
+                const Range16 r = fr[ny * g.tiles_x + nx];
+                need_lo = min(need_lo, r.lo); need_hi = max(need_hi, range_hi(r.hi));
+            }
+    }
+    // tile_hist12_kernel has already written this tile's LUT for bins 0..4095: that is all anybody reads if its neighbourhood stayed below
+    if ((own_r.hi & kLutDone) && need_hi < (uint32_t)kBins12 && sft == 0) return;
     const uint32_t own_lo = own_r.lo, own_hi = range_hi(own_r.hi);
     // where this tile's counts are: at index value (careful sweeps, unshifted bets) or at index value >> own shift (shifted bets)
     const uint32_t own_store = (own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u;      // >= sft: sft is the minimum over the tiles
@@ -624,7 +639,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
             v[k] = (b >= own_lo && b <= own_hi) ? (int)h[b] : 0;
         }
     };
-    const uint32_t jhi = fhi >> sft, own_jlo = own_lo >> sft, own_jhi = own_hi >> sft;
+    const uint32_t jhi = need_hi >> sft, own_jlo = own_lo >> sft, own_jhi = own_hi >> sft;
     int batch = 0, residual = 0, rstep = 1;
     if (clip16 > 0) {
         uint32_t excess = 0;
@@ -640,7 +655,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
         residual = (int)clipped - batch * kHist16;
         if (residual != 0) { rstep = kHist16 / residual; if (rstep < 1) rstep = 1; }
     }
-    const uint32_t start = (flo >> sft) & ~3u;
+    const uint32_t start = (need_lo >> sft) & ~3u;
     uint32_t running = 0;                                           // clipped counts of the populated bins before the chunk
     for (uint32_t c0 = start; c0 <= jhi; c0 += 4096) {
         const uint32_t j0 = c0 + (uint32_t)t * 4;
@@ -687,7 +702,8 @@ template <bool FMA>
 __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                          uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                          ClaheGeom g, const uint16_t* __restrict__ luts,
-                                                                         const Range16* __restrict__ frame_ranges, int subs, int n_frames)
+                                                                         const Range16* __restrict__ frame_ranges, int subs, int n_frames,
+                                                                         const Range16* __restrict__ tile_ranges)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 tab[];      // [kInterp16Entries] {a | b << 16, c | d << 16}
     const int t = threadIdx.x;
@@ -715,12 +731,21 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const Range16 fr_raw = frame_ranges[f];
     const uint32_t sft = range_shift(fr_raw.hi);
     Range16 fr; fr.lo = fr_raw.lo >> sft; fr.hi = range_hi(fr_raw.hi) >> sft;
-    const uint32_t start = fr.lo & ~3u;
     // A range wider than the table is walked in WINDOWS of kInterp16Entries values: the table is staged once per window and a pixel is
     // finished in the window its value falls into (2-byte stores).  That re-reads the workgroup's pixels once per window, so it
-    // cannot be done in place: in-place calls with a wide range are left to clahe_interp16_wide_kernel.
+    // cannot be done in place: in-place calls on a FRAME with a wide range are left to clahe_interp16_wide_kernel, whole.
+    if (fr.hi - (fr.lo & ~3u) >= (uint32_t)kInterp16Entries && src_base == dst_base) return;
+    // The table only has to cover the values this workgroup's pixels can have: they lie in (at most) the four tiles whose LUTs it blends,
+    // so the union of THOSE tiles' ranges replaces the frame's (a hot pixel, a bright corner widen the table of their own rectangles
+    // only; tile_lut16_kernel writes every LUT over its tile's 3 x 3 neighbourhood, which contains these four).
+    {
+        const Range16* tr = tile_ranges + (size_t)f * g.tiles_x * g.tiles_y;
+        const Range16 r00 = tr[ty1 * g.tiles_x + tx1], r01 = tr[ty1 * g.tiles_x + tx2], r10 = tr[ty2 * g.tiles_x + tx1], r11 = tr[ty2 * g.tiles_x + tx2];
+        fr.lo = min(min(r00.lo, r01.lo), min(r10.lo, r11.lo)) >> sft;
+        fr.hi = max(max(range_hi(r00.hi), range_hi(r01.hi)), max(range_hi(r10.hi), range_hi(r11.hi))) >> sft;
+    }
+    const uint32_t start = fr.lo & ~3u;
     const bool multi = fr.hi - start >= (uint32_t)kInterp16Entries;
-    if (multi && src_base == dst_base) return;
     // A range of at most kInterp16F32Entries values (every 12-bit source) gets the table as FLOATS, {a, c, b, d} in 16 bytes: one
     // ds_read_b128 per pixel feeds v_pk_mul / v_pk_add directly and the four ushort -> float conversions per pixel are gone
     // (the blend was VALU-bound: ~25 instructions per pixel, now ~12).  Same 64 KiB of LDS either way.

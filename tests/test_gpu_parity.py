@@ -1051,6 +1051,38 @@ def test_clahe16_msb_aligned_content(ctx):
         ctx.set_option("clahe16_transposed", 0)
 
 
+def test_clahe16_tables_follow_the_local_range(ctx):
+    """The LUT kernel writes a tile's LUT over the range of the tile and its eight neighbours, and an interpolation workgroup stages
+    its table over the range of the four tiles it blends -- not over the frame's.  Frames whose tiles differ wildly: one hot pixel in a
+    corner / on an edge / in the middle of a 12-bit frame, a full-range half beside a 12-bit half, a bright corner tile, a dark frame
+    with one full-range tile; out of place and in place (in-place frames with a wide range take the gathering kernel, whole)."""
+    rng = np.random.default_rng(404)
+    for (w, h, tx, ty) in [(640, 368, 8, 8), (640, 368, 4, 2), (323, 201, 5, 3)]:
+        base = rng.integers(0, 4096, (h, w), dtype=np.uint16)
+        hot_corner = base.copy(); hot_corner[0, 0] = 65535
+        hot_edge = base.copy(); hot_edge[h - 1, w // 2] = 40000
+        hot_mid = base.copy(); hot_mid[h // 2, w // 2] = 65535; hot_mid[h // 2 + 1, w // 2] = 5000
+        halves = base.copy(); halves[:, w // 2:] = rng.integers(0, 65536, (h, w - w // 2), dtype=np.uint16)
+        corner = base.copy(); corner[: h // ty, : w // tx] = rng.integers(30000, 65536, (h // ty, w // tx), dtype=np.uint16)
+        dark = rng.integers(0, 64, (h, w), dtype=np.uint16)
+        dark[h // ty: 2 * (h // ty), w // tx: 2 * (w // tx)] = rng.integers(0, 65536, (h // ty, w // tx), dtype=np.uint16)
+        frames = [hot_corner, hot_edge, hot_mid, halves, corner, dark, base]
+        for cfg in ((2.0, tx, ty), (40.0, tx, ty)):
+            want = [oracle.clahe16(f, *cfg) for f in frames]
+            d_in = dev(np.stack(frames).view(np.int16))
+            d_out = torch.zeros_like(d_in)
+            ctx.clahe16_batch_dev(d_in, d_out, w, h, len(frames), *cfg)
+            ctx.synchronize()
+            out = host(d_out).view(np.uint16)
+            for k in range(len(frames)):
+                assert np.array_equal(out[k], want[k]), (w, h, cfg, "batch", k)
+            ctx.clahe16_batch_dev(d_in, d_in, w, h, len(frames), *cfg)    # in place
+            ctx.synchronize()
+            got = host(d_in).view(np.uint16)
+            for k in range(len(frames)):
+                assert np.array_equal(got[k], want[k]), (w, h, cfg, "in place", k)
+
+
 def test_clahe16_frame_done_flags_over_many_frames(ctx):
     """The last tile workgroup of each FRAME settles the frame's range and whether every tile wrote its LUT in the histogram kernel
     (the LUT kernel then leaves on one scalar load); the per-frame arrival words must come back to zero after every launch.  150
