@@ -393,20 +393,22 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
     // The frame's range and "every tile wrote its LUT here" are settled by the LAST workgroup of the frame to arrive, so that
     // tile_lut16_kernel can leave at once on one scalar load (launched only to leave, it still cost 26 us per 16 frames in the sequence:
     // every workgroup re-derived the frame's range from the tiles' ranges first).  ONE 64-bit word per frame, zero between launches:
-    // bits 0..15 arrivals, 16..31 tiles whose bet held, 32..63 which 128-value buckets hold a tile's lowest / highest value.  A tile
-    // ORs its two bucket bits in and then adds its arrival -- two relaxed agent-scope atomics on the SAME address, so every arrival
+    // bits 0..15 arrivals, 16..31 tiles whose bet held, 32..47 which 256-bin buckets hold a tile's lowest / highest bin, 48..63 which
+    // shifts the tiles bet on.  The frame is done if every tile's bet held AND they all used one shift (their LUTs then share a
+    // domain); a letterboxed P010 frame, whose bars have another shift than its picture, goes through tile_lut16_kernel.  A tile
+    // ORs its bits in and then adds its arrival -- two relaxed agent-scope atomics on the SAME address, so every arrival
     // the last workgroup sees comes with its bits (performed at the L2: no write-back / invalidate of this XCD's L2, see
     // hist_lut_kernel).  Thread 0 issues them as soon as the tile knows its range (or that its bet is lost), and looks at the returned
     // value only at the very end: waiting for it held the whole workgroup at its next barrier (9 us per 16 frames), arriving after
-    // the LUT made thread 0 sit on its own stores.  The range so reported is rounded out to buckets, which only makes the
-    // interpolation stage a few more (existing) table entries.  A tile that lost its bet adds an arrival and nothing else: the
-    // frame is then not "done" and tile_lut16_kernel derives the exact range itself.
+    // the LUT made thread 0 sit on its own stores.  The frame range so reported is rounded out to buckets (the interpolation sizes
+    // its tables by the tiles' own exact ranges).  A tile that lost its bet adds an arrival and nothing else: the frame is then not
+    // "done" and tile_lut16_kernel derives the exact range itself.
     unsigned long long before64 = 0;
     uint32_t own_bits = 0, own_add = 1u;
     unsigned long long* const sy = reinterpret_cast<unsigned long long*>(sync) + 2 * (size_t)f;
-    auto arrive = [&](bool done, uint32_t tlo, uint32_t thi) {      // thread 0
+    auto arrive = [&](bool done, uint32_t jlo, uint32_t jhi) {      // thread 0; jlo / jhi: lowest / highest populated bin
         if (done) {
-            own_bits = (1u << (tlo >> 7)) | (1u << (thi >> 7));
+            own_bits = (1u << (jlo >> 8)) | (1u << (jhi >> 8)) | (0x10000u << sft);
             own_add = 0x10001u;
             __hip_atomic_fetch_or(sy, (unsigned long long)own_bits << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -417,10 +419,16 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
         const uint32_t nd = (uint32_t)((before64 >> 16) & 0xffffu) + (own_add >> 16);
         const uint32_t bits = (uint32_t)(before64 >> 32) | own_bits;
         __hip_atomic_store(sy, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t buckets = bits & 0xffffu, shifts = bits >> 16;
+        const bool done = nd == gridDim.x && __builtin_popcount(shifts) == 1;
         Range16 r; r.lo = 0xffffu; r.hi = 0;
-        if (bits) { r.lo = (uint32_t)__builtin_ctz(bits) << 7; r.hi = (((31u - (uint32_t)__builtin_clz(bits)) << 7) | 127u); }
+        if (done) {
+            const uint32_t fs = (uint32_t)__builtin_ctz(shifts);
+            r.lo = ((uint32_t)__builtin_ctz(buckets) << 8) << fs;
+            r.hi = min(((((31u - (uint32_t)__builtin_clz(buckets)) << 8) | 255u) << fs), 0xffffu) | (fs << 16);
+        }
         frame_ranges[f] = r;
-        frame_done[f] = nd == gridDim.x ? 1u : 0u;
+        frame_done[f] = done ? 1u : 0u;
     };
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
         if (t == 0) arrive(false, 0u, 0u);
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
         __syncthreads();
     }
     const uint32_t lo = s_lo << sft, hi = s_hi << sft;
-    if (t == 0) arrive(sft == 0, lo, hi);                           // (a tile with a shift leaves its LUT to tile_lut16_kernel: the FRAME's shift decides the domain)
+    if (t == 0) arrive(true, s_lo, s_hi);
     // the histogram itself (bin j = count of value j << sft), for tile_lut16_kernel: always needed with a shift, and without one should
     // the FRAME turn out wider than 4096 values (another tile lost its bet)
     {
@@ -481,10 +489,6 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
                 *reinterpret_cast<u32x4*>(hist + tile_id * kHist16 + bj) = u32x4{(uint32_t)v[4 * j], (uint32_t)v[4 * j + 1], (uint32_t)v[4 * j + 2], (uint32_t)v[4 * j + 3]};
         }
     }
-    if (sft != 0) {                                               // uniform: the LUT of a shifted tile is the LUT kernel's job
-        if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (sft << 16) | kHistCompressed; ranges[tile_id] = r; settle_frame(); }
-        return;
-    }
     auto block_scan = [&](uint32_t x, uint32_t& total) -> uint32_t {  // inclusive prefix of x over the NT threads
         const uint32_t incl = wave_incl_scan(x);
         __syncthreads();
@@ -495,7 +499,9 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
         total = tot;
         return off + incl;
     };
-    // ---- clip, redistribute, prefix sum, scale: clahe.cpp for histSize 65536, exactly as tile_lut16_kernel does it from bin 0
+    // ---- clip, redistribute, prefix sum, scale: clahe.cpp for histSize 65536, exactly as tile_lut16_kernel does it, in this tile's
+    // own domain (bin j stands for value j << sft; the bins in between in closed form).  The LUT is stored at index j: it is THE
+    // LUT if the frame's shift turns out to be this tile's, else tile_lut16_kernel writes it again
     int batch = 0, residual = 0, rstep = 1;
     if (clip16 > 0) {
         uint32_t excess = 0;
@@ -514,28 +520,29 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
     uint32_t local = 0;
 #pragma unroll
     for (int k = 0; k < BPT; ++k) {
-        if (clip16 > 0) {
-            if (v[k] > clip16) v[k] = clip16;
-            v[k] += batch;
-            const int b = (int)b0 + k;
-            if (residual != 0 && b % rstep == 0 && b / rstep < residual) ++v[k];
-        }
+        if (clip16 > 0 && v[k] > clip16) v[k] = clip16;
         local += (uint32_t)v[k];
-        v[k] = (int)local;
+        v[k] = (int)local;                                           // inclusive prefix of the clipped counts within the thread's bins
     }
     uint32_t total;
     const uint32_t before = block_scan(local, total) - local;
     uint32_t packed[BPT / 2];
 #pragma unroll
     for (int k = 0; k < BPT; ++k) {
-        int r = __float2int_rn(__fmul_rn((float)(int)(before + (uint32_t)v[k]), lut_scale16));
+        uint32_t sum = before + (uint32_t)v[k];
+        if (clip16 > 0) {
+            const uint32_t b = (b0 + (uint32_t)k) << sft;            // the value this bin stands for
+            sum += (uint32_t)batch * (b + 1u);
+            if (residual != 0) sum += min((uint32_t)residual, b / (uint32_t)rstep + 1u);
+        }
+        int r = __float2int_rn(__fmul_rn((float)(int)sum, lut_scale16));
         r = r < 0 ? 0 : (r > 65535 ? 65535 : r);
         if (k & 1) packed[k >> 1] |= (uint32_t)r << 16; else packed[k >> 1] = (uint32_t)r;
     }
 #pragma unroll
     for (int j = 0; j < BPT / 4; ++j)
         *reinterpret_cast<uint2*>(luts + tile_id * kHist16 + b0 + 4 * j) = make_uint2(packed[2 * j], packed[2 * j + 1]);
-    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | kLutDone; ranges[tile_id] = r; settle_frame(); }
+    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (sft << 16) | (sft ? kHistCompressed : 0u) | kLutDone; ranges[tile_id] = r; settle_frame(); }
 }
 
 // grid = (tiles, frames), 1024 threads.  Works in the frame's COMPRESSED domain j = value >> shift (shift = the smallest of its tiles'
@@ -600,8 +607,9 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
                 need_lo = min(need_lo, r.lo); need_hi = max(need_hi, range_hi(r.hi));
             }
     }
-    // tile_hist12_kernel has already written this tile's LUT for bins 0..4095: that is all anybody reads if its neighbourhood stayed below
-    if ((own_r.hi & kLutDone) && need_hi < (uint32_t)kBins12 && sft == 0) return;
+    // tile_hist12_kernel has already written this tile's LUT for bins 0..4095 of ITS domain: that is all anybody reads if that domain
+    // is the frame's and the neighbourhood stayed inside it
+    if ((own_r.hi & kLutDone) && ((own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u) == sft && (need_hi >> sft) < (uint32_t)kBins12) return;
     const uint32_t own_lo = own_r.lo, own_hi = range_hi(own_r.hi);
     // where this tile's counts are: at index value (careful sweeps, unshifted bets) or at index value >> own shift (shifted bets)
     const uint32_t own_store = (own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u;      // >= sft: sft is the minimum over the tiles
