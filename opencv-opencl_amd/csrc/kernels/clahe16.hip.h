@@ -367,7 +367,9 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
 #pragma unroll
     for (int k = 0; k < NW; ++k) o32 |= s_w[k];
     const uint32_t o16 = (o32 | (o32 >> 16)) & 0xffffu;
-    const uint32_t sft = o16 ? (uint32_t)__builtin_ctz(o16) : 0u;  // uniform
+    // No shift while everything seen is below 4096: a flat tile of an ordinary 12-bit frame (a letterbox bar at black level 256) must
+    // not pick a shift of its own -- the frame is only "done" when all its tiles used one.
+    const uint32_t sft = o16 >= (uint32_t)kBins12 ? (uint32_t)__builtin_ctz(o16) : 0u;  // uniform
     const uint32_t wl = min(12u, 16u - sft);
     bool lost = (o16 >> sft) >= (uint32_t)kBins12;                  // uniform
     if (!lost) {
