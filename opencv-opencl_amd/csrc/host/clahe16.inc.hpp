@@ -24,9 +24,9 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
     st = grow_dev(c, &c->d_c16, &c->c16_bytes, per_frame * (size_t)chunk);
     if (st) return st;
     // per-frame arrival words of tile_hist12_kernel: zero between launches (its last workgroup per frame leaves them so)
-    const size_t sync_need = (size_t)chunk * 4 * sizeof(uint32_t);
+    const size_t sync_need = ((size_t)chunk * 4 + 4) * sizeof(uint32_t);      // + the context's shift hint (last word group)
     if (sync_need > c->sync16_bytes) {
-        st = grow_dev(c, &c->d_sync16, &c->sync16_bytes, std::max<size_t>(sync_need, 64 * 4 * sizeof(uint32_t)));
+        st = grow_dev(c, &c->d_sync16, &c->sync16_bytes, std::max<size_t>(sync_need, (64 * 4 + 4) * sizeof(uint32_t)));
         if (st) return st;
         HIPCHK(c, hipMemsetAsync(c->d_sync16, 0, c->sync16_bytes, s));
     }
@@ -46,12 +46,13 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         if (bet12)
             LAUNCH(c, s, MI_K_TILE_HIST, (tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
-                   c->d_sync16, franges, fdone);
+                   c->d_sync16, franges, fdone, c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 4);
         else
             LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, vec);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, (const Range16*)ranges, g,
-               lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr));
+               lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr),
+               bet12 ? c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 4 : (uint32_t*)nullptr);
         if (tiles <= 64 && c->clahe16_transposed) {
             // value-major LUTs (one cache line per pixel value): transposed into the histogram area, which is dead by now
             uint16_t* lutT = reinterpret_cast<uint16_t*>(hist);

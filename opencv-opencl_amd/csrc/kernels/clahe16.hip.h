@@ -310,7 +310,8 @@ template <int NT, int COPIES>
 __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
                                                         ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
                                                         float lut_scale16, int clip16, uint16_t* __restrict__ luts,
-                                                        uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done)
+                                                        uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done,
+                                                        uint32_t* __restrict__ shift_hint)
 {
     static_assert(COPIES == 2 || COPIES == 4, "copies");
     constexpr int NW = NT / 64, BPT = kBins12 / NT;                // waves; bins per thread
@@ -369,7 +370,16 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
     const uint32_t o16 = (o32 | (o32 >> 16)) & 0xffffu;
     // No shift while everything seen is below 4096: a flat tile of an ordinary 12-bit frame (a letterbox bar at black level 256) must
     // not pick a shift of its own -- the frame is only "done" when all its tiles used one.
-    const uint32_t sft = o16 >= (uint32_t)kBins12 ? (uint32_t)__builtin_ctz(o16) : 0u;  // uniform
+    // With values >= 4096 every shift from bitlen(OR) - 12 up to the OR's trailing zeros would do, and the results do not depend on the
+    // choice -- only whether the frame's tiles agree does.  The letterbox bars of a P010 frame (black = 64 << 6: trailing zeros 12) and
+    // its picture (6) agree if the bars take the shift the context's previous frame ran with (*shift_hint, written when a frame is
+    // settled): a video stream keeps its format.
+    uint32_t sft = 0u;                                               // uniform
+    if (o16 >= (uint32_t)kBins12) {
+        const uint32_t smax = (uint32_t)__builtin_ctz(o16), smin = 20u - (uint32_t)__builtin_clz(o16);     // bitlen(o16) - 12
+        const uint32_t hint = *shift_hint;
+        sft = (hint >= smin && hint <= smax) ? hint : smax;
+    }
     const uint32_t wl = min(12u, 16u - sft);
     bool lost = (o16 >> sft) >= (uint32_t)kBins12;                  // uniform
     if (!lost) {
@@ -431,6 +441,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
         }
         frame_ranges[f] = r;
         frame_done[f] = done ? 1u : 0u;
+        if (done) *shift_hint = (uint32_t)__builtin_ctz(shifts);
     };
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
         if (t == 0) arrive(false, 0u, 0u);
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
 //     sum over bins <= b  =  (clipped counts of the populated bins <= b)  +  batch * (b + 1)  +  min(residual, b / rstep + 1).
 __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, const Range16* __restrict__ ranges, ClaheGeom g,
                                                          float lut_scale16, int clip16, uint16_t* __restrict__ luts, Range16* __restrict__ frame_ranges,
-                                                         const uint32_t* __restrict__ frame_done)
+                                                         const uint32_t* __restrict__ frame_done, uint32_t* __restrict__ shift_hint)
 {
     // tile_hist12_kernel has written every LUT of this frame (bins 0..4095: all anybody reads) and the frame's range: one scalar load
     if (frame_done && frame_done[blockIdx.y]) return;
@@ -593,7 +604,10 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     __syncthreads();
     const uint32_t flo = s_flo, fhi = s_fhi, sft = s_fs;
     const Range16 own_r = ranges[tile_id];
-    if (blockIdx.x == 0 && t == 0) { Range16 r; r.lo = flo; r.hi = fhi | (sft << 16); frame_ranges[blockIdx.y] = r; }
+    if (blockIdx.x == 0 && t == 0) {
+        Range16 r; r.lo = flo; r.hi = fhi | (sft << 16); frame_ranges[blockIdx.y] = r;
+        if (shift_hint) *shift_hint = sft;                          // what the next frame's flat tiles should go along with
+    }
     // Who reads this tile's LUT, and where?  Pixels of the tile itself and of its eight neighbours, at THEIR values.  So the LUT is
     // needed over the union of those nine tiles' ranges only, not over the frame's: one hot pixel at 65535 in a 12-bit frame then
     // costs the nine tiles around it a long LUT, not all 64 (the interpolation stages by the same rule, see clahe_interp16_kernel).

@@ -1043,6 +1043,15 @@ def test_clahe16_msb_aligned_content(ctx):
             ctx.clahe16_batch_dev(d_in, d_in, w, h, len(frames), *cfg)    # in place
             ctx.synchronize()
             assert np.array_equal(host(d_in).view(np.uint16), out), (w, h, cfg, "in place")
+    # letterboxed frames of alternating formats, call after call: the bars' tiles may take any shift their value allows, and take the one
+    # the context's previous frame ran with -- a choice that must never show in the result
+    w, h = 640, 368
+    def letterbox(bits, shift, bar):
+        f = msb(bits, shift, (h, w)); f[: h // 8] = bar; f[-(h // 8):] = bar; return f
+    seq = [letterbox(10, 6, 64 << 6), letterbox(12, 4, 256 << 4), letterbox(10, 6, 64 << 6), letterbox(12, 0, 256), letterbox(10, 6, 0),
+           letterbox(8, 8, 16 << 8), letterbox(10, 6, 64 << 6)]
+    for k, f in enumerate(seq):
+        assert np.array_equal(ctx.clahe16(f, 2.0, 8, 8), oracle.clahe16(f, 2.0, 8, 8)), ("letterbox sequence", k)
     try:                                                                  # the value-major LUT layout follows the shift too
         ctx.set_option("clahe16_transposed", 1)
         f = msb(10, 6, (180, 320))

@@ -51,7 +51,7 @@ int main(int argc, char** argv)
     Range16* ranges = (Range16*)(scratch + (size_t)nf * tiles * kHist16 * 6);
     Range16* franges = ranges + (size_t)nf * tiles;
     uint32_t* fdone = (uint32_t*)(franges + nf);
-    uint32_t* sync; CK(hipMalloc(&sync, 16 * (size_t)nf)); CK(hipMemset(sync, 0, 16 * (size_t)nf));
+    uint32_t* sync; CK(hipMalloc(&sync, 16 * (size_t)nf + 16)); CK(hipMemset(sync, 0, 16 * (size_t)nf + 16)); uint32_t* hint = sync + 4 * (size_t)nf;
     {
         std::vector<uint16_t> hb((size_t)W * H);
         uint32_t x = 777u;
@@ -76,8 +76,8 @@ int main(int argc, char** argv)
     const int subs = argc > 4 ? atoi(argv[4]) : subs_rule;
     const long long rows = (long long)bands * subs * nf;
     const unsigned igrid = (unsigned)((rows + 7) / 8 * 8 * npairs);
-    auto k_hist = [&] { hipLaunchKernelGGL((tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * 4, 0, (const uint8_t*)src, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone); };
-    auto k_lut = [&] { hipLaunchKernelGGL(tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, 0, (const uint32_t*)hist, (const Range16*)ranges, g, lut_scale16, clip16, luts, franges, (const uint32_t*)fdone); };
+    auto k_hist = [&] { hipLaunchKernelGGL((tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * 4, 0, (const uint8_t*)src, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone, hint); };
+    auto k_lut = [&] { hipLaunchKernelGGL(tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, 0, (const uint32_t*)hist, (const Range16*)ranges, g, lut_scale16, clip16, luts, franges, (const uint32_t*)fdone, hint); };
     auto k_int = [&] { hipLaunchKernelGGL(clahe_interp16_kernel<false>, dim3(igrid), dim3(kInterp16Threads), kInterp16Entries * 8, 0,
                                           (const uint8_t*)src, (long long)step, (long long)plane, dst, (long long)step, (long long)plane, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges); };
     k_hist(); k_lut(); k_int(); CK(hipDeviceSynchronize());
@@ -105,8 +105,8 @@ int main(int argc, char** argv)
         const float tc = time_us([&] {
             for (int f0 = 0; f0 < nf; f0 += chunk) {
                 const uint8_t* sp = src + plane * f0; uint8_t* dp = dst + plane * f0;
-                hipLaunchKernelGGL((tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, chunk), dim3(kHist12Threads), kHist12Words * 4, 0, sp, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone);
-                hipLaunchKernelGGL(tile_lut16_kernel, dim3(tiles, chunk), dim3(1024), 0, 0, (const uint32_t*)hist, (const Range16*)ranges, g, lut_scale16, clip16, luts, franges, (const uint32_t*)fdone);
+                hipLaunchKernelGGL((tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, chunk), dim3(kHist12Threads), kHist12Words * 4, 0, sp, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone, hint);
+                hipLaunchKernelGGL(tile_lut16_kernel, dim3(tiles, chunk), dim3(1024), 0, 0, (const uint32_t*)hist, (const Range16*)ranges, g, lut_scale16, clip16, luts, franges, (const uint32_t*)fdone, hint);
                 hipLaunchKernelGGL(clahe_interp16_kernel<false>, dim3(cgrid), dim3(kInterp16Threads), kInterp16Entries * 8, 0,
                                    sp, (long long)step, (long long)plane, dp, (long long)step, (long long)plane, g, (const uint16_t*)luts, (const Range16*)franges, subs, chunk, (const Range16*)ranges);
             }

@@ -13,6 +13,7 @@ cases = (("12-bit 0..4095", u16(0, 4096)), ("10-bit 0..1023", u16(0, 1024)), ("n
          ("10-bit << 6 (P010)", (torch.randint(0, 1024, (n, h, w), dtype=torch.int32, device="cuda") << 6).to(torch.int16)),
          ("12-bit << 4 (MSB-aligned)", (torch.randint(0, 4096, (n, h, w), dtype=torch.int32, device="cuda") << 4).to(torch.int16)),
          ("12-bit, black bars at level 256", "bars"),
+         ("P010 with bars at 64 << 6", "p010bars"),
          ("12-bit + one 65535 pixel per frame", None),
          ("15-bit 0..32767", u16(0, 32768)), ("16-bit full", u16(0, 65536)), ("const 777", torch.full((n, h, w), 777, dtype=torch.int16, device="cuda")),
          # full 16-bit range over the frame, locally smooth (a diagonal ramp + 9 bits of noise): what a 16-bit photograph looks like to the windows
@@ -22,7 +23,10 @@ for name, s16 in cases:
     if only == "12bit" and not name.startswith("12-bit 0"):
         continue
     if isinstance(s16, str):                                     # letterboxed ordinary content: flat tiles whose value is a multiple of 256
-        s16 = u16(0, 4096); s16[:, : h // 8] = 256; s16[:, -(h // 8):] = 256
+        if s16 == "bars":
+            s16 = u16(0, 4096); s16[:, : h // 8] = 256; s16[:, -(h // 8):] = 256
+        else:                                                    # the same in P010: picture = 10 bits << 6, bars = 64 << 6 (trailing zeros 12)
+            s16 = (torch.randint(64, 941, (n, h, w), dtype=torch.int32, device="cuda") << 6).to(torch.int16); s16[:, : h // 8] = 4096; s16[:, -(h // 8):] = 4096
     if s16 is None:                                              # a hot pixel: one tile per frame loses its bet and the frame's range is the whole word
         s16 = u16(0, 4096); s16[:, 1000, 2000] = -1
     o16 = torch.empty_like(s16)
