@@ -379,6 +379,8 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
         const uint32_t smax = (uint32_t)__builtin_ctz(o16), smin = 20u - (uint32_t)__builtin_clz(o16);     // bitlen(o16) - 12
         const uint32_t hint = *shift_hint;
         sft = (hint >= smin && hint <= smax) ? hint : smax;
+    } else if (o16 == 0u) {
+        sft = min(*shift_hint, 15u);                                // nothing but zeros seen: any shift will do, so go along with the frame before
     }
     const uint32_t wl = min(12u, 16u - sft);
     bool lost = (o16 >> sft) >= (uint32_t)kBins12;                  // uniform
