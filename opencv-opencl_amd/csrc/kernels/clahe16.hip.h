@@ -89,38 +89,48 @@ __device__ __forceinline__ void hist16_add_vec(uint32_t* h16, const u32x4& q, in
     hist16_add_dword<kWinBits>(h16, q.z, half, lmin, lmax, lor); hist16_add_dword<kWinBits>(h16, q.w, half, lmin, lmax, lor);
 }
 
-// OPTIMISTIC sweep (vector path): count every pixel at (value & 32767) without asking which half it belongs to, and track the range
-// with packed 16-bit min / max (one v_pk_min_u16 / v_pk_max_u16 per TWO pixels).  If the tile turns out to hold a value >= 32768 the
-// counters have aliased and the careful two-sweep code below starts over; for everything up to 15 bits -- all video -- this sweep is
-// the whole job at ~4 VALU instructions per pixel instead of ~14 (no per-pixel half test, no divergent branch around the ds_add).
+// OPTIMISTIC sweep (vector path): count the pixels of window 0 (values below 1 << kWinBits) with one test per PAIR of pixels -- no
+// bit above the window in either half -- and track the range with packed 16-bit min / max (one v_pk_min_u16 / v_pk_max_u16 per two
+// pixels).  For everything that fits the window this sweep is the whole job at ~5 VALU instructions per pixel instead of ~14.
+// A value beyond the window is not counted but its window is noted (wmask): the counters stay exact for window 0, and only the
+// windows that hold something are swept afterwards, one sweep each -- a 12-bit tile with one hot pixel costs two sweeps, not five.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 template <int kWinBits>
-__device__ __forceinline__ void hist16_fast_dword(uint32_t* h16, uint32_t w, u16x2& pmin, u16x2& pmax, uint32_t& lor)
+__device__ __forceinline__ void hist16_fast_dword(uint32_t* h16, uint32_t w, u16x2& pmin, u16x2& pmax, uint32_t& lor, uint32_t& wmask)
 {
     const u16x2 v = __builtin_bit_cast(u16x2, w);
     pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v); lor |= w;
-    lds_inc(h16, w & ((1u << kWinBits) - 1));
-    lds_inc(h16, (w >> 16) & ((1u << kWinBits) - 1));
+    constexpr uint32_t kHigh = ((0xffffu << kWinBits) & 0xffffu) * 0x10001u;          // the bits a value of window 0 does not have
+    if (__builtin_expect((w & kHigh) == 0u, 1)) {
+        lds_inc(h16, w & ((1u << kWinBits) - 1));
+        lds_inc(h16, w >> 16);
+        return;
+    }
+    // a value beyond window 0 is NOT counted (the counters stay exact for window 0); its window is noted for a sweep of its own
+    const uint32_t a = w & 0xffffu, b = w >> 16;
+    if (a < (1u << kWinBits)) lds_inc(h16, a); else wmask |= 1u << (a >> kWinBits);
+    if (b < (1u << kWinBits)) lds_inc(h16, b); else wmask |= 1u << (b >> kWinBits);
 }
 template <int kWinBits>
-__device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u16x2& pmin, u16x2& pmax, uint32_t& lor)
+__device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u16x2& pmin, u16x2& pmax, uint32_t& lor, uint32_t& wmask)
 {
     const uint32_t v0 = q.x & 0xffffu;
     const bool flat = q.x == q.y && q.y == q.z && q.z == q.w && v0 == (q.x >> 16);
     if (__builtin_expect(flat, 0)) {                                // as hist16_add_vec: flat regions never reach the LDS pixel by pixel
         const u16x2 v = __builtin_bit_cast(u16x2, q.x);
         pmin = __builtin_elementwise_min(pmin, v); pmax = __builtin_elementwise_max(pmax, v); lor |= q.x;
+        if (v0 >= (1u << kWinBits)) { wmask |= 1u << (v0 >> kWinBits); return; }     // beyond window 0: noted, not counted
         const unsigned long long active = __ballot(1);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v0);
         if (__ballot(v0 == first) == active) {
-            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(active)) lds_add(h16, v0 & ((1u << kWinBits) - 1), 8u * (uint32_t)__builtin_popcountll(active));
+            if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(active)) lds_add(h16, v0, 8u * (uint32_t)__builtin_popcountll(active));
         } else {
-            lds_add(h16, v0 & ((1u << kWinBits) - 1), 8u);
+            lds_add(h16, v0, 8u);
         }
         return;
     }
-    hist16_fast_dword<kWinBits>(h16, q.x, pmin, pmax, lor); hist16_fast_dword<kWinBits>(h16, q.y, pmin, pmax, lor);
-    hist16_fast_dword<kWinBits>(h16, q.z, pmin, pmax, lor); hist16_fast_dword<kWinBits>(h16, q.w, pmin, pmax, lor);
+    hist16_fast_dword<kWinBits>(h16, q.x, pmin, pmax, lor, wmask); hist16_fast_dword<kWinBits>(h16, q.y, pmin, pmax, lor, wmask);
+    hist16_fast_dword<kWinBits>(h16, q.z, pmin, pmax, lor, wmask); hist16_fast_dword<kWinBits>(h16, q.w, pmin, pmax, lor, wmask);
 }
 
 // grid = (tiles, frames), NT threads (1024 in tile_hist16_kernel), (4 << kWinBits) bytes of dynamic LDS.  steps in BYTES.
@@ -149,13 +159,15 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
     };
     uint32_t lmin = 0xffffu, lmax = 0, lor = 0;
     auto vadd = [&](const u32x4& q, int half) { hist16_add_vec<kWinBits>(h16, q, half, lmin, lmax, lor); };
-    if (t == 0) { s_lo = 0xffffu; s_hi = 0; s_or = 0; }
+    __shared__ uint32_t s_wm;                                     // which windows beyond the first hold a value (vector path)
+    if (t == 0) { s_lo = 0xffffu; s_hi = 0; s_or = 0; s_wm = 0; }
     uint32_t lo = 0, hi = 0;
-    bool range_known = false;
-    if (vec) {                                                    // optimistic sweep, see hist16_fast_vec
+    if (vec) {
+        // ---- optimistic sweep: window 0 counted, the others noted (see hist16_fast_vec)
         for (int i = t; i < kWin / 4; i += NT) reinterpret_cast<u32x4*>(h16)[i] = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
         u16x2 pmin = {0xffff, 0xffff}, pmax = {0, 0};
+        uint32_t wmask = 0;
         int row = t / slots, slot = t - row * slots;
         const int vdrow = NT / slots, vdslot = NT - vdrow * slots;
         const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -170,40 +182,56 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
                 if (slot >= slots) { slot -= slots; ++row; }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (qv[k]) hist16_fast_vec<kWinBits>(h16, q[k], pmin, pmax, lor);
+            for (int k = 0; k < 4; ++k) if (qv[k]) hist16_fast_vec<kWinBits>(h16, q[k], pmin, pmax, lor, wmask);
         }
         lmin = min((uint32_t)pmin.x, (uint32_t)pmin.y); lmax = max((uint32_t)pmax.x, (uint32_t)pmax.y);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
-            lor |= (uint32_t)__shfl_xor((int)lor, d, 64);
+            lor |= (uint32_t)__shfl_xor((int)lor, d, 64); wmask |= (uint32_t)__shfl_xor((int)wmask, d, 64);
         }
         if ((t & 63) == 0) {
             __hip_atomic_fetch_min(&s_lo, lmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_max(&s_hi, lmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_or(&s_or, lor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wmask) __hip_atomic_fetch_or(&s_wm, wmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         lo = s_lo; hi = s_hi;
-        if (hi < (uint32_t)kWin) {                                // nothing aliased: the counters are the histogram
-            for (uint32_t i = (lo & ~3u) + (uint32_t)t; i <= hi; i += NT) out[i] = h16[i];
-            if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (shift_of_or(s_or) << 16); ranges[tile_id] = r; }
-            return;
-        }
-        range_known = true;                                       // a value >= 32768: start over, one half of the value range per sweep
-        __syncthreads();
-    }
-    for (int half = 0; half < (kHist16 >> kWinBits); ++half) {    // one window of the value range per sweep
-        for (int i = t; i < kWin; i += NT) h16[i] = 0;
-        __syncthreads();
-        if (vec) {
+        const uint32_t wm = s_wm;
+        // window 0: the counters are its histogram (bins are stored from a 4-aligned start: the LUT kernel loads 16 bytes)
+        if (lo < (uint32_t)kWin)
+            for (uint32_t i = (lo & ~3u) + (uint32_t)t; i <= min(hi, (uint32_t)kWin - 1u); i += NT) out[i] = h16[i];
+        // the windows above it: one sweep for each that holds something, zeros for the stretches of [lo, hi] in the others
+        for (int half = 1; half < (kHist16 >> kWinBits); ++half) {
+            const uint32_t base = (uint32_t)half * (uint32_t)kWin;
+            if (hi < base) break;
+            const uint32_t b0 = max(lo, base), b1 = min(hi, base + (uint32_t)kWin - 1);
+            if (b0 > b1) continue;                                  // (the range starts above this window)
+            if (!((wm >> half) & 1u)) {
+                for (uint32_t i = (b0 & ~3u) + (uint32_t)t; i <= b1; i += NT) out[i] = 0u;
+                continue;
+            }
+            __syncthreads();                                        // the previous window's counters have been stored
+            for (int i = t; i < kWin / 4; i += NT) reinterpret_cast<u32x4*>(h16)[i] = zero;
+            __syncthreads();
             int it = t;
             for (; it + 3 * NT < vitems; it += 4 * NT) {
                 const u32x4 a = vload(it), b = vload(it + NT), c = vload(it + 2 * NT), d = vload(it + 3 * NT);
                 vadd(a, half); vadd(b, half); vadd(c, half); vadd(d, half);
             }
             for (; it < vitems; it += NT) vadd(vload(it), half);
-        } else {
+            __syncthreads();
+            for (uint32_t i = (b0 & ~3u) + (uint32_t)t; i <= b1; i += NT) out[i] = h16[i & ((1u << kWinBits) - 1)];
+        }
+        if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (shift_of_or(s_or) << 16); ranges[tile_id] = r; }
+        return;
+    }
+    // ---- scalar path (REFLECT_101 padding, odd tile widths): one window of the value range per sweep
+    for (int half = 0; half < (kHist16 >> kWinBits); ++half) {
+        for (int i = t; i < kWin; i += NT) h16[i] = 0;
+        __syncthreads();
+        {
             int row = t / g.tile_w, col = t - row * g.tile_w;
             for (long long it = t; it < items; it += NT) {
                 const int y = reflect101(ty * g.tile_h + row, g.height);
@@ -215,7 +243,7 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
                 if (col >= g.tile_w) { col -= g.tile_w; ++row; }
             }
         }
-        if (half == 0 && !range_known) {                          // the tile's range is known after the first sweep
+        if (half == 0) {                                          // the tile's range is known after the first sweep
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
                 lmin = min(lmin, (uint32_t)__shfl_xor((int)lmin, d, 64)); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d, 64));
@@ -229,7 +257,7 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
         }
         __syncthreads();
         lo = s_lo; hi = s_hi;
-        // store the populated bins of this half only: [max(lo, base), min(hi, base + 32767)]
+        // store the populated bins of this window only: [max(lo, base), min(hi, base + kWin - 1)]
         const uint32_t base = (uint32_t)half * (uint32_t)kWin;
         const uint32_t b0 = max(lo, base), b1 = min(hi, base + (uint32_t)kWin - 1);
         if (b0 <= b1)
@@ -374,14 +402,15 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
     // choice -- only whether the frame's tiles agree does.  The letterbox bars of a P010 frame (black = 64 << 6: trailing zeros 12) and
     // its picture (6) agree if the bars take the shift the context's previous frame ran with (*shift_hint, written when a frame is
     // settled): a video stream keeps its format.
-    uint32_t sft = 0u;                                               // uniform
+    uint32_t sft_v = 0u;                                             // uniform (made scalar below)
     if (o16 >= (uint32_t)kBins12) {
         const uint32_t smax = (uint32_t)__builtin_ctz(o16), smin = 20u - (uint32_t)__builtin_clz(o16);     // bitlen(o16) - 12
         const uint32_t hint = *shift_hint;
-        sft = (hint >= smin && hint <= smax) ? hint : smax;
+        sft_v = (hint >= smin && hint <= smax) ? hint : smax;
     } else if (o16 == 0u) {
-        sft = min(*shift_hint, 15u);                                // nothing but zeros seen: any shift will do, so go along with the frame before
+        sft_v = min(*shift_hint, 15u);                              // nothing but zeros seen: any shift will do, so go along with the frame before
     }
+    const uint32_t sft = (uint32_t)__builtin_amdgcn_readfirstlane((int)sft_v);       // in SGPRs: the sweep has no VGPR to spare
     const uint32_t wl = min(12u, 16u - sft);
     bool lost = (o16 >> sft) >= (uint32_t)kBins12;                  // uniform
     if (!lost) {
@@ -446,12 +475,9 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
         if (done) *shift_hint = (uint32_t)__builtin_ctz(shifts);
     };
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
-        if (t == 0) arrive(false, 0u, 0u);
-        __syncthreads();
-        if (t == 0) { s_lo = 0xffffu; s_hi = 0; }
         __syncthreads();
         tile_hist16_careful<kCarefulBits, NT>(h16, s_lo, s_hi, s_or, src_base, step, frame_stride, g, hist, ranges, 1);   // its counters fill the same LDS
-        if (t == 0) settle_frame();
+        if (t == 0) { arrive(false, 0u, 0u); settle_frame(); }      // (after the sweeps: nothing of the arrival is live across them)
         return;
     }
     // ---- the tile's 4096 counts: thread t owns bins BPT * t .. BPT * t + BPT - 1 (sum of the copies)
