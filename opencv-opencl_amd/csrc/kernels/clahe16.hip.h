@@ -40,6 +40,15 @@ struct Range16 { uint32_t lo, hi; };                 // populated value range of
 // A frame with a shift runs in the COMPRESSED domain j = value >> shift from the LUT kernel on: its LUTs are stored at index j and
 // the interpolation looks pixels up at (pixel >> shift), so MSB-aligned 10- and 12-bit content needs one 1024- / 4096-entry table
 // like LSB-aligned content instead of windows over the whole 16-bit range.
+// lo of a TILE carries, above its 16 bits, a presence mask: bit c set if the tile may hold a value in [4096 c, 4096 c + 4095] (conservative).
+// tile_lut16_kernel writes a LUT only over the 4096-value stretches some tile of the 3 x 3 neighbourhood populates.
+__device__ __forceinline__ uint32_t range_lo(uint32_t lo) { return lo & 0xffffu; }
+__device__ __forceinline__ uint32_t range_mask(uint32_t lo) { return lo >> 16; }
+__device__ __forceinline__ uint32_t chunk_bits(uint32_t vlo, uint32_t vhi)      // presence bits of the 4096-value stretches [vlo >> 12, vhi >> 12]
+{
+    const uint32_t a = vlo >> 12, b = min(vhi, 0xffffu) >> 12;
+    return ((2u << b) - 1u) & ~((1u << a) - 1u);
+}
 constexpr uint32_t kRangeHiMask = 0xffffu;
 __device__ __forceinline__ uint32_t range_hi(uint32_t hi) { return hi & kRangeHiMask; }
 __device__ __forceinline__ uint32_t range_shift(uint32_t hi) { return (hi >> 16) & 15u; }
@@ -224,7 +233,12 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
             __syncthreads();
             for (uint32_t i = (b0 & ~3u) + (uint32_t)t; i <= b1; i += NT) out[i] = h16[i & ((1u << kWinBits) - 1)];
         }
-        if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (shift_of_or(s_or) << 16); ranges[tile_id] = r; }
+        if (t == 0) {
+            constexpr uint32_t kPer = (uint32_t)kWin >> 12;             // 4096-value stretches per window
+            uint32_t m = lo < (uint32_t)kWin ? (1u << kPer) - 1u : 0u;
+            for (uint32_t w = 1; w < (uint32_t)(kHist16 >> kWinBits); ++w) if ((wm >> w) & 1u) m |= ((1u << kPer) - 1u) << (w * kPer);
+            Range16 r; r.lo = lo | ((m & chunk_bits(lo, hi)) << 16); r.hi = hi | (shift_of_or(s_or) << 16); ranges[tile_id] = r;
+        }
         return;
     }
     // ---- scalar path (REFLECT_101 padding, odd tile widths): one window of the value range per sweep
@@ -265,7 +279,7 @@ __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinB
         if (hi < base + (uint32_t)kWin) break;                    // nothing above this window: done
         __syncthreads();
     }
-    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (shift_of_or(s_or) << 16); ranges[tile_id] = r; }
+    if (t == 0) { Range16 r; r.lo = lo | (chunk_bits(lo, hi) << 16); r.hi = hi | (shift_of_or(s_or) << 16); ranges[tile_id] = r; }
 }
 
 __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
 #pragma unroll
     for (int j = 0; j < BPT / 4; ++j)
         *reinterpret_cast<uint2*>(luts + tile_id * kHist16 + b0 + 4 * j) = make_uint2(packed[2 * j], packed[2 * j + 1]);
-    if (t == 0) { Range16 r; r.lo = lo; r.hi = hi | (sft << 16) | (sft ? kHistCompressed : 0u) | kLutDone; ranges[tile_id] = r; settle_frame(); }
+    if (t == 0) { Range16 r; r.lo = lo | (chunk_bits(lo, hi) << 16); r.hi = hi | (sft << 16) | (sft ? kHistCompressed : 0u) | kLutDone; ranges[tile_id] = r; settle_frame(); }
 }
 
 // grid = (tiles, frames), 1024 threads.  Works in the frame's COMPRESSED domain j = value >> shift (shift = the smallest of its tiles'
@@ -622,7 +636,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     {
         uint32_t l = 0xffffu, u = 0, sh = 15u;
         const Range16* fr = ranges + (size_t)blockIdx.y * tiles;
-        for (int i = t; i < tiles; i += 1024) { const Range16 r = fr[i]; l = min(l, r.lo); u = max(u, range_hi(r.hi)); sh = min(sh, range_shift(r.hi)); }
+        for (int i = t; i < tiles; i += 1024) { const Range16 r = fr[i]; l = min(l, range_lo(r.lo)); u = max(u, range_hi(r.hi)); sh = min(sh, range_shift(r.hi)); }
         if (t < tiles) {
             __hip_atomic_fetch_min(&s_flo, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_max(&s_fhi, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -639,7 +653,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     // Who reads this tile's LUT, and where?  Pixels of the tile itself and of its eight neighbours, at THEIR values.  So the LUT is
     // needed over the union of those nine tiles' ranges only, not over the frame's: one hot pixel at 65535 in a 12-bit frame then
     // costs the nine tiles around it a long LUT, not all 64 (the interpolation stages by the same rule, see clahe_interp16_kernel).
-    uint32_t need_lo = 0xffffu, need_hi = 0u;
+    uint32_t need_lo = 0xffffu, need_hi = 0u, need_mask = 0u;
     {
         const int tx0 = (int)blockIdx.x % g.tiles_x, ty0 = (int)blockIdx.x / g.tiles_x;
         const Range16* fr = ranges + (size_t)blockIdx.y * tiles;
@@ -648,13 +662,13 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
                 const int nx = tx0 + dx, ny = ty0 + dy;
                 if (nx < 0 || ny < 0 || nx >= g.tiles_x || ny >= g.tiles_y) continue;
                 const Range16 r = fr[ny * g.tiles_x + nx];
-                need_lo = min(need_lo, r.lo); need_hi = max(need_hi, range_hi(r.hi));
+                need_lo = min(need_lo, range_lo(r.lo)); need_hi = max(need_hi, range_hi(r.hi)); need_mask |= range_mask(r.lo);
             }
     }
     // tile_hist12_kernel has already written this tile's LUT for bins 0..4095 of ITS domain: that is all anybody reads if that domain
     // is the frame's and the neighbourhood stayed inside it
     if ((own_r.hi & kLutDone) && ((own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u) == sft && (need_hi >> sft) < (uint32_t)kBins12) return;
-    const uint32_t own_lo = own_r.lo, own_hi = range_hi(own_r.hi);
+    const uint32_t own_lo = range_lo(own_r.lo), own_hi = range_hi(own_r.hi);
     // where this tile's counts are: at index value (careful sweeps, unshifted bets) or at index value >> own shift (shifted bets)
     const uint32_t own_store = (own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u;      // >= sft: sft is the minimum over the tiles
     const uint32_t dsh = own_store - sft;
@@ -710,6 +724,8 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     const uint32_t start = (need_lo >> sft) & ~3u;
     uint32_t running = 0;                                           // clipped counts of the populated bins before the chunk
     for (uint32_t c0 = start; c0 <= jhi; c0 += 4096) {
+        // nobody in the neighbourhood has a value in this chunk's stretch of the value range: nothing will ever be looked up here
+        if (!(need_mask & chunk_bits(c0 << sft, ((c0 + 4095u) << sft) | ((1u << sft) - 1u)))) continue;      // uniform over the workgroup
         const uint32_t j0 = c0 + (uint32_t)t * 4;
         const bool active = j0 <= jhi;
         int v[4] = {0, 0, 0, 0};
@@ -793,7 +809,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     {
         const Range16* tr = tile_ranges + (size_t)f * g.tiles_x * g.tiles_y;
         const Range16 r00 = tr[ty1 * g.tiles_x + tx1], r01 = tr[ty1 * g.tiles_x + tx2], r10 = tr[ty2 * g.tiles_x + tx1], r11 = tr[ty2 * g.tiles_x + tx2];
-        fr.lo = min(min(r00.lo, r01.lo), min(r10.lo, r11.lo)) >> sft;
+        fr.lo = min(min(range_lo(r00.lo), range_lo(r01.lo)), min(range_lo(r10.lo), range_lo(r11.lo))) >> sft;
         fr.hi = max(max(range_hi(r00.hi), range_hi(r01.hi)), max(range_hi(r10.hi), range_hi(r11.hi))) >> sft;
     }
     const uint32_t start = fr.lo & ~3u;
