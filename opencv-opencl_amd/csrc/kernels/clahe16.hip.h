@@ -786,7 +786,9 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const int pr = (int)(k % npairs);
     const long long row = (k / npairs) * 8 + xcd;
     if (row >= (long long)bands * subs * n_frames) return;
-    const int sub = (int)(row % subs), band = (int)((row / subs) % bands), f = (int)(row / ((long long)subs * bands));
+    // frames are walked last-to-first: the histogram pass has just streamed the batch first-to-last, so its tail is what the memory-side
+    // Infinity Cache still holds
+    const int sub = (int)(row % subs), band = (int)((row / subs) % bands), f = n_frames - 1 - (int)(row / ((long long)subs * bands));
     const int ty1u = band - 1;
     const int ty1 = max(ty1u, 0), ty2 = min(ty1u + 1, g.tiles_y - 1);
     const int tx1 = max(pr - 1, 0), tx2 = min(pr, g.tiles_x - 1);
