@@ -1050,6 +1050,12 @@ def test_clahe16_msb_aligned_content(ctx):
         f = msb(bits, shift, (h, w)); f[: h // 8] = bar; f[-(h // 8):] = bar; return f
     seq = [letterbox(10, 6, 64 << 6), letterbox(12, 4, 256 << 4), letterbox(10, 6, 64 << 6), letterbox(12, 0, 256), letterbox(10, 6, 0),
            letterbox(8, 8, 16 << 8), letterbox(10, 6, 64 << 6)]
+    # ... and after a P010 frame (hint: shift 6) a nearly black frame with sparse ODD speckles: most tiles see nothing but zeros in
+    # what they sample, go along with shift 6, and lose that bet on the pixels that follow
+    speckle = np.zeros((h, w), np.uint16)
+    idx = rng.choice(h * w, size=h * w // 4000, replace=False)
+    speckle.reshape(-1)[idx] = rng.integers(1, 4096, idx.size, dtype=np.uint16) | 1
+    seq += [speckle, letterbox(10, 6, 64 << 6), (speckle.astype(np.uint32) << 3).astype(np.uint16)]
     for k, f in enumerate(seq):
         assert np.array_equal(ctx.clahe16(f, 2.0, 8, 8), oracle.clahe16(f, 2.0, 8, 8)), ("letterbox sequence", k)
     try:                                                                  # the value-major LUT layout follows the shift too
