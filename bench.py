@@ -63,7 +63,40 @@ def parse_args(argv=None):
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="rehearsal only: every rank uses this GPU index instead of LOCAL_RANK")
     ap.add_argument("--no-numa-bind", action="store_true", help="do not bind each rank to the CPUs of its GPU's NUMA node")
+    ap.add_argument("--deadline-s", type=float, default=900.0,
+                    help="whole-job deadline: the launcher ends its children by PID, says which phase each rank was in and exits 124; "
+                         "a rank started by torchrun ends itself 30 s later (0 = none)")
     return ap.parse_args(argv)
+
+
+# ---- heartbeats ------------------------------------------------------------------------------------------------------
+# Every rank says on stderr which phase it is entering; the launcher keeps each rank's last phase, so a job that stops making
+# progress is reported as "rank r was in phase p" instead of ending in silence (round 3's four-rank rehearsal left an empty record).
+_T0 = time.monotonic()
+_PHASE = {"name": "start", "rank": int(os.environ.get("RANK", "0"))}
+HB_TAG = "[bench hb]"
+
+
+def hb(phase):
+    _PHASE["name"] = phase
+    print(f"{HB_TAG} rank={_PHASE['rank']} phase={phase} t=+{time.monotonic() - _T0:.1f}s", file=sys.stderr, flush=True)
+
+
+def arm_rank_watchdog(deadline_s):
+    """A rank that outlives the deadline (+30 s, so that a launcher acts first and can report every rank) says where it was and
+    leaves with 124.  os._exit: the main thread may sit in a collective or in a HIP call that never returns."""
+    if not deadline_s or deadline_s <= 0:
+        return None
+    import threading
+
+    def fire():
+        print(f"{HB_TAG} rank={_PHASE['rank']} DEADLINE of {deadline_s:.0f} s passed in phase={_PHASE['name']}: leaving with 124",
+              file=sys.stderr, flush=True)
+        os._exit(124)
+    t = threading.Timer(deadline_s + 30.0, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 # ---- self-launch for N > 1 -----------------------------------------------------------------------------------------
@@ -74,19 +107,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_children(n, argv, child_cmd=None, grace_s=30.0, env_extra=None):
+def launch_children(n, argv, child_cmd=None, grace_s=30.0, env_extra=None, deadline_s=900.0):
     """Start n fresh processes of this script, one per GPU (RANK / LOCAL_RANK = 0..n-1, WORLD_SIZE = n, rendezvous on 127.0.0.1),
     relay rank 0's JSON line(s) to stdout and everything else to stderr, return the worst exit code.  The calling process must
     not have touched the GPU: nothing here does, and nothing is exec'd in place -- the children are ordinary child processes.
     When a rank dies, the others get `grace_s` seconds to notice (they may sit in a collective with it) and are then ended, by
-    their own PIDs.  `child_cmd` replaces `python bench.py` (the CPU test passes a stub)."""
+    their own PIDs.  When the job as a whole outlives `deadline_s`, every child still running is ended the same way, the phase
+    each rank last announced (hb()) is printed and 124 is returned.  `child_cmd` replaces `python bench.py` (the CPU tests pass stubs)."""
     import subprocess
     import threading
     port = _free_port()
     cmd = list(child_cmd) if child_cmd else [sys.executable, str(Path(__file__).resolve())]
     procs, pumps, rank0_lines = [], [], []
+    phase = {r: "not started" for r in range(n)}
 
-    def pump(rank, stream):
+    def pump_out(rank, stream):
         for line in stream:
             if rank == 0 and line.lstrip().startswith("{"):
                 rank0_lines.append(line)
@@ -96,6 +131,16 @@ def launch_children(n, argv, child_cmd=None, grace_s=30.0, env_extra=None):
                 sys.stderr.write(f"[rank {rank}] {line}")
                 sys.stderr.flush()
 
+    def pump_err(rank, stream):
+        for line in stream:
+            if line.startswith(HB_TAG):
+                bits = dict(kv.split("=", 1) for kv in line[len(HB_TAG):].split() if "=" in kv)
+                if "phase" in bits:
+                    phase[rank] = f"{bits['phase']} (since {bits.get('t', '?')})"
+            sys.stderr.write(line if line.startswith(HB_TAG) else f"[rank {rank}] {line}")
+            sys.stderr.flush()
+
+    t_start = time.monotonic()
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -103,35 +148,56 @@ def launch_children(n, argv, child_cmd=None, grace_s=30.0, env_extra=None):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL on this pool: dmabuf IPC only
         if env_extra:
             env.update(env_extra)
-        p = subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
-        t = threading.Thread(target=pump, args=(r, p.stdout), daemon=True)
-        t.start()
+        p = subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1)
+        phase[r] = "started"
+        for fn, stream in ((pump_out, p.stdout), (pump_err, p.stderr)):
+            t = threading.Thread(target=fn, args=(r, stream), daemon=True)
+            t.start()
+            pumps.append(t)
         procs.append(p)
-        pumps.append(t)
-    deadline, own_failure = None, 0
+
+    def end_children():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                                      # by PID: never by pattern
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    deadline, own_failure, timed_out = None, 0, False
     while any(p.poll() is None for p in procs):
         if deadline is None and any(p.poll() not in (None, 0) for p in procs):
             deadline = time.monotonic() + grace_s                 # a rank failed: the rest may be waiting for it forever
             own_failure = next(p.poll() for p in procs if p.poll() not in (None, 0))     # ... and ITS code is the job's, not the
                                                                   # SIGTERM the launcher hands the others afterwards
         if deadline is not None and time.monotonic() > deadline:
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
+            end_children()
+            break
+        if deadline_s and deadline_s > 0 and time.monotonic() - t_start > deadline_s:
+            timed_out = True
+            running = [r for r, p in enumerate(procs) if p.poll() is None]
+            print(f"bench.py launcher: DEADLINE of {deadline_s:.0f} s passed; ranks still running: {running}", file=sys.stderr)
+            for r in range(n):
+                print(f"bench.py launcher:   rank {r}: {'running' if r in running else f'exited {procs[r].poll()}'}, last phase: {phase[r]}",
+                      file=sys.stderr)
+            sys.stderr.flush()
+            end_children()
             break
         time.sleep(0.05)
     for t in pumps:
         t.join(timeout=10)
     codes = [p.wait() for p in procs]
+    if timed_out:
+        return 124
     worst = own_failure
     for c in codes:
         if c != 0 and worst == 0:
             worst = c
+    if worst != 0:
+        for r in range(n):
+            print(f"bench.py launcher:   rank {r}: exit code {codes[r]}, last phase: {phase[r]}", file=sys.stderr)
     if worst == 0 and not rank0_lines:
         print("bench.py launcher: rank 0 printed no JSON line", file=sys.stderr)
         worst = 1
@@ -238,7 +304,9 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (no torch import yet).
-        sys.exit(launch_children(args.gpus, sys.argv[1:]))
+        sys.exit(launch_children(args.gpus, sys.argv[1:], deadline_s=args.deadline_s))
+    arm_rank_watchdog(args.deadline_s)
+    hb("import")
     import torch
     import torch.distributed as dist
     import mi_lumaeq
@@ -249,9 +317,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.all_ranks_on_device is not None:
         local_rank = args.all_ranks_on_device
+    _PHASE["rank"] = rank
     if world > 1:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs HIP devices (no CPU fallback)")
+        hb(f"dist_init({args.dist_backend})")
         torch.cuda.set_device(local_rank)
         # No silent substitution: if RCCL was asked for and does not come up with every rank, the run fails.  (gloo is only
         # ever used when asked for by name, to rehearse the N>1 path on a one-GPU box.)
@@ -286,6 +356,7 @@ def main():
             placement = mi_lumaeq.bind_thread_near_device(local_rank)
         except mi_lumaeq.MiError as e:
             placement = {"node": None, "cpus": 0, "why": f"not bound: {e}"}
+    hb("context")
     ctx = mi_lumaeq.Context(local_rank)
 
     # this rank's shard: global frame indices k with k mod world == rank (no collective on the data path); the synthetic batch is
@@ -309,9 +380,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    hb("warmup")
     for _ in range(args.warmup):
         step()
     barrier()
+    hb("timed")
     ctx.profile_read(reset=True)
     # HIP events stamped by the kernel dispatches themselves (hipExtLaunchKernelGGL start / stop events), on the launch stream
     ctx.set_profiling(True)
@@ -321,6 +394,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
+    hb("verdict")
     # The library's own verdict on the timed launches, on EVERY rank: synchronize() raises if the fused path met a frame it
     # could not repair, and a launch that had to be repaired on the device (correct output, but slower) is disclosed.
     run_ok, run_err = True, ""
@@ -356,16 +430,17 @@ def main():
     # ranks) on 4x as many frames of a quarter of the size, so that it is reported by the 1/2/4/8 runs as well.  Not the headline.
     second = None
     if (w, h) == (3840, 2160) and not args.no_second_resolution:
-        hw, hh, hb = 1920, 1080, 4 * B
+        hw, hh, hb2 = 1920, 1080, 4 * B
+        hb("second_resolution")
         del d_in, d_out
-        e_in = synth.nv12_batch_torch(hw, hh, hb, args.dist, device, seed=0x5EED1080 + rank)
+        e_in = synth.nv12_batch_torch(hw, hh, hb2, args.dist, device, seed=0x5EED1080 + rank)
         e_out = torch.empty_like(e_in)
 
         def step2():
             if args.op == "equalize":
-                ctx.equalize_hist_nv12_batch_dev(e_in, e_out, hw, hh, hb, uv_mode, stream=stream)
+                ctx.equalize_hist_nv12_batch_dev(e_in, e_out, hw, hh, hb2, uv_mode, stream=stream)
             else:
-                ctx.clahe_nv12_batch_dev(e_in, e_out, hw, hh, hb, uv_mode, 2.0, 8, 8, stream=stream)
+                ctx.clahe_nv12_batch_dev(e_in, e_out, hw, hh, hb2, uv_mode, 2.0, 8, 8, stream=stream)
         for _ in range(max(3, args.warmup // 2)):
             step2()
         barrier()
@@ -375,30 +450,35 @@ def main():
             step2()
         barrier()
         el2 = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
-        second = {"workload": f"{hb} x {hw}x{hh} NV12 frames per GPU per step, same op", "value": round(hb * world * steps2 / el2, 1), "unit": "frames/s",
+        second = {"workload": f"{hb2} x {hw}x{hh} NV12 frames per GPU per step, same op", "value": round(hb2 * world * steps2 / el2, 1), "unit": "frames/s",
                   "steps": steps2, "ms_per_step": round(el2 / steps2 * 1e3, 4),
-                  "whole_path_frac_of_8TBs": round((3 * hw * hh + (hw * hh // 2) * (2 if args.uv == "copy" else 1)) * hb * steps2 / el2 / 1e9 / HBM_PEAK_GBS, 4)}        # per GPU
+                  "whole_path_frac_of_8TBs": round((3 * hw * hh + (hw * hh // 2) * (2 if args.uv == "copy" else 1)) * hb2 * steps2 / el2 / 1e9 / HBM_PEAK_GBS, 4)}        # per GPU
         del e_in, e_out
 
-    # BASELINE.json configs[3] as written -- 512 4K frames at 60 fps, frame-per-GPU across the node: with N > 1 every rank streams through
-    # ONE pool worker on its own GPU, all ranks at the same time (they share the host's memory bandwidth and PCIe root complexes, which is
-    # what this figure is about); reduced over the ranks below.  Every rank takes part in the reductions whatever happened to its child.
+    # BASELINE.json configs[3] as written -- 512 4K frames at 60 fps, frame-per-GPU across the node: with N > 1 every rank streams 512
+    # host frames through an mi_pipe on its own GPU, all ranks at the same time (they share the host's memory bandwidth and PCIe root
+    # complexes, which is what this figure is about); reduced over the ranks below.  IN THIS PROCESS: the round-3 form started one
+    # nv12_stream child per rank, which doubles the processes on the GPUs (four ranks rehearsed on one GPU = 8 GPU processes, more than
+    # a gpurun box allows -- docs/experiments.md R4.1).  Every rank takes part in the reductions whatever happened to its own leg.
     stream_all = None
     if world > 1 and not args.no_extras and (w, h) == (3840, 2160):
         barrier()
+        hb("stream_all_ranks")
         try:
-            mine = stream_config4(w, h, device=local_rank)
-        except Exception as e:                   # a failed child must not leave the other ranks in a collective
+            mine = stream_in_process(torch, mi_lumaeq, synth, local_rank, w, h, check_with_oracle=(rank == 0))
+        except Exception as e:                   # a failed leg must not leave the other ranks in a collective
             mine = {"error": repr(e)}
-        ok = 1.0 if ("p99_ms" in mine and mine.get("returncode") == 0) else 0.0
+            print(f"[bench] rank {rank}: stream leg failed: {e!r}", file=sys.stderr, flush=True)
+        ok = 1.0 if ("p99_ms" in mine and mine.get("errors", 1) == 0 and mine.get("parity", True) is not False) else 0.0
         red = lambda v, op: shard.reduce_over_ranks(float(v), dist, op)
-        stream_all = {"what": "every rank: 512 4K NV12 frames paced at 60 fps through one pool worker on its own GPU, all ranks at once (host -> host, PCIe inclusive)",
+        stream_all = {"what": "every rank: 512 4K NV12 frames paced at 60 fps through an mi_pipe on its own GPU (pinned frame ring, in-process), "
+                              "all ranks at once (host -> host, PCIe inclusive); then the same pipe unpaced",
                       "ranks_ok": int(red(ok, "sum")),
                       "p50_ms_max": red(mine.get("p50_ms", -1.0), "max"), "p99_ms_max": red(mine.get("p99_ms", -1.0), "max"),
                       "max_ms_max": red(mine.get("max_ms", -1.0), "max"), "late_total": int(red(mine.get("late", 0), "sum")),
                       "errors_total": int(red(mine.get("errors", 0), "sum")),
                       "unpaced_frames_per_s_total": round(red(mine.get("unpaced_frames_per_s", 0.0), "sum"), 1),
-                      "placement_rank0": mine.get("placement")}          # NUMA binding of rank 0's streamer (every rank prints its own)
+                      "parity_rank0": mine.get("parity")}
     # ---- kernel timing of THIS rank, then the figures every rank contributes to (before anybody leaves) ----------------
     # Algorithmic bytes per frame (SURVEY.md 8d / DESIGN.md): equalizeHist on Y = 3*W*H (histogram read +
     # apply read + apply write); + UV fill W*H/2 (write) or UV copy 2*(W*H/2).  The fused kernel performs
@@ -421,6 +501,7 @@ def main():
     dom = max(cands, key=lambda k: kinfo[k]["avg_ms"] * kinfo[k]["launches"]) if cands else None
     # the dominant kernel's average launch time on every rank: mean, fastest and slowest GPU (the same kernel dominates everywhere:
     # all ranks run the same configuration; a rank without timings contributes a negative value and voids the mean)
+    hb("reduce")
     dom_ms_mine = kinfo[dom]["avg_ms"] if dom else -1.0
     dgroup = dist if world > 1 else None
     dom_ms_sum = shard.reduce_over_ranks(dom_ms_mine, dgroup, "sum")
@@ -432,6 +513,7 @@ def main():
         dist.barrier()                           # every reduction is done: the ranks leave together, rank 0 goes on alone
         dist.destroy_process_group()
     if rank != 0:
+        hb("done")
         return
 
     total_frames = B * world * args.steps
@@ -507,10 +589,78 @@ def main():
     if world == 1:
         out["opencv_cross_check"] = guarded(opencv_cross_check, ctx, w, h, args.dist)
     if world == 1 and not args.no_extras:
+        hb("extras")
         out["extras"] = guarded(extras, ctx, args, torch, mi_lumaeq, synth)
-    if not args.no_cpu_baseline:                                   # N > 1 as well: rank 0 alone by now, the other ranks have exited
+    if not args.no_cpu_baseline:
+        hb("cpu_baseline")                                   # N > 1 as well: rank 0 alone by now, the other ranks have exited
         out["cpu_baseline"] = guarded(cpu_baseline, args, w, h)
     print(json.dumps(out), flush=True)
+    hb("done")
+
+
+def stream_in_process(torch, mi_lumaeq, synth, device, w, h, frames=512, fps=60, unpaced_frames=1500, check_with_oracle=False):
+    """BASELINE.json configs[3] inside THIS process: `frames` WxH NV12 host frames released at `fps` through an mi_pipe on `device`
+    (a context of its own; pinned frame ring, the way a recycled buffer pool is registered once), latency = release -> delivered;
+    then the same pipe unpaced with its depth kept in flight.  The N > 1 ranks use this instead of an nv12_stream child each, so a
+    job never has more GPU processes than ranks."""
+    import numpy as np
+    fb = w * h * 3 // 2
+    ring, depth = 8, 4
+    pin_in = torch.empty((ring, fb), dtype=torch.uint8).pin_memory()
+    pin_out = torch.empty((ring, fb), dtype=torch.uint8).pin_memory()
+    ins, outs = pin_in.numpy(), pin_out.numpy()
+    base = [synth.nv12_frame(w, h, "D2", 4000 + k) for k in range(2)]
+    for k in range(ring):
+        ins[k][:] = base[k % 2]
+    res = {"frames": frames, "fps": fps, "driver": "in-process mi_pipe (python), depth 4, pinned ring of 8", "errors": 0}
+    ctx2 = mi_lumaeq.Context(device)
+    try:
+        with mi_lumaeq.Pipe(ctx2, w, h, op=mi_lumaeq.OP_EQUALIZE, uv_mode=mi_lumaeq.UV_FILL128, depth=depth) as pipe:
+            for k in range(4):                                  # warm: staging verdicts, queues
+                pipe.submit(ins[k % ring], outs[k % ring], k)
+                pipe.wait()
+            lat, period = [], 1.0 / fps
+            t0 = time.perf_counter() + 0.002
+            for k in range(frames):
+                release = t0 + k * period
+                while True:                                     # sleep most of the way, spin the last half millisecond
+                    left = release - time.perf_counter()
+                    if left <= 0:
+                        break
+                    if left > 0.0007:
+                        time.sleep(left - 0.0005)
+                try:
+                    pipe.submit(ins[k % ring], outs[k % ring], k)
+                    pipe.wait()
+                    lat.append((time.perf_counter() - release) * 1e3)
+                except mi_lumaeq.MiError:
+                    res["errors"] += 1
+            if lat:
+                lat.sort()
+                budget = 1000.0 / fps
+                res.update(p50_ms=round(lat[len(lat) // 2], 3), p90_ms=round(lat[len(lat) * 9 // 10], 3),
+                           p99_ms=round(lat[min(len(lat) - 1, len(lat) * 99 // 100)], 3), max_ms=round(lat[-1], 3),
+                           late=sum(1 for v in lat if v > budget))
+            if check_with_oracle:                               # checker only: the last delivered frame of this rank against the oracle
+                import oracle
+                k = (frames - 1) % ring
+                res["parity"] = bool(np.array_equal(outs[k], oracle.nv12_frame(ins[k], w, h, uv_mode=0, op=0)))
+            sub = done = 0
+            t0 = time.perf_counter()
+            try:
+                while done < unpaced_frames:
+                    while sub < unpaced_frames and sub - done < depth:
+                        pipe.submit(ins[sub % ring], outs[sub % ring], sub)
+                        sub += 1
+                    pipe.wait()
+                    done += 1
+            except mi_lumaeq.MiError:
+                res["errors"] += 1
+            if done:
+                res["unpaced_frames_per_s"] = round(done / (time.perf_counter() - t0), 1)
+    finally:
+        ctx2.close()
+    return res
 
 
 def stream_config4(w, h, device=None):

@@ -156,8 +156,10 @@ void mi_ctx_destroy(mi_ctx* c)
     if (!c) return;
     if (c->fused_slot && c->device >= 0 && c->device < kMaxDevices) g_fused_ctx_live[c->device].fetch_sub(1);
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
+    // The device-resident forms are stream-ordered on streams the CALLER owns: a kernel of this context may still be reading the scratch
+    // freed below or about to write the pinned mirror words (fused_finish_kernel -> h_mirror).  Wait for the whole device before the
+    // first free -- explicitly, not through hipFree's implicit wait (contexts are destroyed at the end of a worker's life, never per frame).
+    (void)hipDeviceSynchronize();
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     for (auto e : c->chunk_events) (void)hipEventDestroy(e);
@@ -240,13 +242,15 @@ mi_status mi_host_register(void* ptr, size_t bytes)
 mi_status mi_host_unregister(void* ptr)
 {
     if (!ptr) return MI_ERR_BAD_ARG;
-    {
-        std::lock_guard<std::mutex> lk(g_pin_mu);
-        auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [&](const PinnedRange& r) { return r.lo == (uintptr_t)ptr; });
-        if (it == g_pinned.end()) return MI_ERR_BAD_ARG;
-        g_pinned.erase(it);
-        g_pin_generation.fetch_add(1, std::memory_order_relaxed);
-    }
+    // one critical section from the pending-DMA check to the end of hipHostUnregister (host_range_pinned judges under the same lock)
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [&](const PinnedRange& r) { return r.lo == (uintptr_t)ptr; });
+    if (it == g_pinned.end()) return MI_ERR_BAD_ARG;
+    // a pipe still has a transfer queued on this buffer (submitted, not yet retired by mi_pipe_wait): unpinning it now would leave the
+    // copy engine with an ordinary heap address.  The caller waits for its frames (or destroys the pipe) and asks again.
+    if (g_pending_dma.overlaps(it->lo, it->hi)) return MI_ERR_BUSY;
+    g_pinned.erase(it);
+    g_pin_generation.fetch_add(1, std::memory_order_relaxed);
     if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return MI_ERR_HIP; }
     return MI_OK;
 }
@@ -330,6 +334,8 @@ mi_status mi_ctx_get_stat(mi_ctx* c, const char* name, uint64_t* out)
     if (!strcmp(name, "fused_demotions")) { *out = c->fused_demotions; return MI_OK; }
     if (!strcmp(name, "fused_demoted")) { *out = c->fused_demoted ? 1 : 0; return MI_OK; }
     if (!strcmp(name, "error_drains")) { *out = c->error_drains; return MI_OK; }
+    if (!strcmp(name, "host_planes_staged")) { *out = c->planes_staged; return MI_OK; }
+    if (!strcmp(name, "host_planes_direct")) { *out = c->planes_direct; return MI_OK; }
     if (!strcmp(name, "host_copies_shared")) { *out = c->crew ? c->crew->shared_jobs() : 0; return MI_OK; }
     static const char* names[4] = {"fused_fallbacks", "fused_frames_repaired", "fused_hard_errors", "fused_last_status"};
     for (int k = 0; k < 4; ++k)
@@ -529,6 +535,7 @@ static mi_status host_op(mi_ctx* c, const uint8_t* src, size_t src_step, uint8_t
     const bool out_pinned = dst_step == (size_t)width && host_range_pinned(dst, ybytes, &c->pin_neg);
     if (!in_pinned && (st = grow_pinned(c, &c->h_pin_in, &c->pin_in_bytes, ybytes))) return st;
     if (!out_pinned && (st = grow_pinned(c, &c->h_pin_out, &c->pin_out_bytes, ybytes))) return st;
+    for (bool direct : {in_pinned, out_pinned}) ++(direct ? c->planes_direct : c->planes_staged);
     CrewCall crew(c, !(in_pinned && out_pinned) && ybytes >= 4 * mi_host::CopyCrew::kMinBytes);
     StreamDrain drain(HipStreamSync{}, drain_counter(c));
     drain.watch(s); drain.watch(sb);

@@ -12,6 +12,8 @@ struct PinnedRange { uintptr_t lo, hi; };
 static std::mutex g_pin_mu;
 static std::vector<PinnedRange> g_pinned;
 static std::atomic<uint64_t> g_pin_generation{1};                // bumped by mi_host_register / mi_host_unregister
+// caller memory that a pipe's queued DMA still reads or writes (pending_ranges.hpp): mi_host_unregister answers MI_ERR_BUSY for it
+static mi_host::PendingRanges g_pending_dma;
 
 // Per-context memory of ranges the runtime was asked about and did NOT know as pinned.  Only the negative verdict is remembered:
 // "not pinned" is always safe (the plane is packed through the library's own staging), while a remembered "pinned" could outlive
@@ -37,21 +39,33 @@ static bool host_range_pinned(const void* p, size_t bytes, PinnedNegCache* neg =
 {
     if (!p || bytes == 0) return false;
     const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
-    {
-        std::lock_guard<std::mutex> lk(g_pin_mu);
-        for (const auto& r : g_pinned) if (lo >= r.lo && hi <= r.hi) return true;
-    }
+    // the whole verdict under the registry's lock: mi_host_unregister holds it from its pending-DMA check to the end of
+    // hipHostUnregister, so a range is never judged "pinned" while it is being unpinned
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const auto& r : g_pinned) if (lo >= r.lo && hi <= r.hi) return true;
     if (neg && neg->hit(lo, bytes)) return false;
     // not registered through mi_host_register: memory the caller pinned itself (hipHostMalloc / hipHostRegister, a pinned torch
     // tensor) is recognised by asking the runtime about both ends of the range.  An unknown pointer is not an error worth keeping:
     // only the error THIS query raised is cleared (a pending error of an earlier asynchronous call is left for its own check).
-    auto pinned_at = [](const void* q) {
+    auto quiet = [](hipError_t before, hipError_t e) { if (e != hipSuccess && before == hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
+    auto pinned_at = [&](const void* q) {
         hipPointerAttribute_t at{};
         const hipError_t before = hipPeekAtLastError();
-        if (hipPointerGetAttributes(&at, q) != hipSuccess) { if (before == hipSuccess) (void)hipGetLastError(); return false; }
-        return at.type == hipMemoryTypeHost;
+        return quiet(before, hipPointerGetAttributes(&at, q)) && at.type == hipMemoryTypeHost;
     };
-    const bool pinned = pinned_at(p) && pinned_at((const uint8_t*)p + bytes - 1);
+    // ... and both ends must lie in ONE allocation: two pinned buffers with pageable memory between them, or a registration that covers
+    // only part of the plane, would otherwise be DMA'd as they are -- the pageable path this library does not take.  An allocation the
+    // runtime cannot describe is treated as unpinned (the plane is staged: slower, never wrong).
+    auto allocation_of = [&](const void* q, void** base, size_t* size) {
+        const hipError_t before = hipPeekAtLastError();
+        return quiet(before, hipMemGetAddressRange((hipDeviceptr_t*)base, size, (hipDeviceptr_t)const_cast<void*>(q)));
+    };
+    bool pinned = pinned_at(p) && pinned_at((const uint8_t*)p + bytes - 1);
+    if (pinned) {
+        void *b0 = nullptr, *b1 = nullptr;
+        size_t s0 = 0, s1 = 0;
+        pinned = allocation_of(p, &b0, &s0) && allocation_of((const uint8_t*)p + bytes - 1, &b1, &s1) && b0 == b1 && s0 == s1 && s0 >= bytes;
+    }
     if (!pinned && neg) neg->remember(lo, bytes);
     return pinned;
 }
@@ -120,6 +134,8 @@ struct mi_ctx {
     bool fused_pair_open = false;                                // a fused kernel was launched and its finish kernel was not (a failed launch in between):
                                                                  // the hand-off block's counters are in an unknown state and are reset before the next launch
     unsigned long long error_drains = 0;                                // statistic "error_drains": error exits that had to drain a stream first
+    unsigned long long planes_staged = 0, planes_direct = 0;            // statistics "host_planes_staged" / "host_planes_direct": host planes packed through
+                                                                        // the library's pinned staging / DMA'd as the caller pinned them
     PinnedNegCache pin_neg;
     mi_host::CopyCrew* crew = nullptr;                           // helper thread for staging copies of the host forms (created on first use)
     int pipe_private_streams = 0;                                // option "pipe_private_streams": a pipe created from now on owns its streams instead of sharing the device's

@@ -116,6 +116,7 @@ void pipe_free(mi_pipe* p)
     if (!p) return;
     (void)hipSetDevice(p->c->device);
     for (hipStream_t s : {p->s_h2d[0], p->s_h2d[1], p->s_k, p->s_d2h[0], p->s_d2h[1]}) if (s) (void)hipStreamSynchronize(s);
+    g_pending_dma.retire_all(p);                                  // frames never waited for: their transfers ended with the streams above
     for (auto& sl : p->slots) {
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_out) (void)hipFree(sl.d_out);
@@ -286,12 +287,23 @@ mi_status mi_pipe_submit(mi_pipe* p, const uint8_t* in, uint8_t* out, uint64_t t
         return MI_OK;
     };
     // pinned memory is DMA'd as it is; anything else goes through the slot's pinned staging buffers.  Both are settled before
-    // anything is enqueued: an allocation failure leaves nothing to undo.
+    // anything is enqueued: an allocation failure leaves nothing to undo.  The caller's ranges are entered into the pending-DMA table
+    // BEFORE they are judged (pending_ranges.hpp: mi_host_unregister then answers MI_ERR_BUSY until mi_pipe_wait has retired the frame)
+    // and leave it again on every exit that queued nothing on them.
+    const uint64_t slot_id = (uint64_t)(&sl - p->slots.data());
+    const size_t out_bytes = p->uv_dev ? fbytes : p->ybytes;
+    g_pending_dma.add(p, slot_id, in, p->xfer_in);
+    g_pending_dma.add(p, slot_id, out, out_bytes);
+    struct PendingGuard {                                         // error exits: the drain guard below has waited for the streams by then
+        mi_pipe* p; uint64_t id; bool keep = false;               // (declared first, so destroyed last)
+        ~PendingGuard() { if (!keep) g_pending_dma.retire(p, id); }
+    } pending{p, slot_id};
     const bool in_pinned = host_range_pinned(in, p->xfer_in, &c->pin_neg);
-    const bool out_pinned = host_range_pinned(out, p->uv_dev ? fbytes : p->ybytes, &c->pin_neg);
+    const bool out_pinned = host_range_pinned(out, out_bytes, &c->pin_neg);
     mi_status st;
     if (!in_pinned && (st = staging(&sl.h_in, fbytes))) return st;
     if (!out_pinned && (st = staging(&sl.h_out, fbytes))) return st;
+    for (bool direct : {in_pinned, out_pinned}) ++(direct ? c->planes_direct : c->planes_staged);
     sl.out_staged = !out_pinned;
     const uint8_t* h2d_src = in;
     if (!in_pinned) {
@@ -321,6 +333,7 @@ mi_status mi_pipe_submit(mi_pipe* p, const uint8_t* in, uint8_t* out, uint64_t t
     HIPCHK(c, hipMemcpyAsync(sl.out_staged ? sl.h_out : out, sl.d_out, p->xfer_out, hipMemcpyDeviceToHost, s_d2h));
     HIPCHK(c, hipEventRecord(sl.ev_done, s_d2h));
     drain.done();                                                 // success: the frame stays in flight, that is the point of a pipe
+    pending.keep = in_pinned || out_pinned;                       // a staged frame's transfers run on the slot's own buffers, not the caller's
     ++p->count; ++p->submitted; ++c->pipe_pending;
     return MI_OK;
 }
@@ -363,6 +376,8 @@ mi_status mi_pipe_wait(mi_pipe* p, uint64_t* tag, uint8_t** out_frame)
         crew.copy(sl.out, p->xfer_out, sl.h_out, p->xfer_out, (int)std::min<size_t>(p->xfer_out, 0x7fffffff), 1);
     }
     // the slot is retired WHATEVER happened: one mi_pipe_wait = one tag gone, so the caller's own queue stays in step
+    // (its transfers are over on both paths above -- the event was reached, or the streams were drained)
+    g_pending_dma.retire(p, (uint64_t)slot);
     p->head = (p->head + 1) % p->slots.size();
     --p->count; ++p->completed; --c->pipe_pending;
     if (st) return st;

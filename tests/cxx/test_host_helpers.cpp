@@ -3,6 +3,7 @@
 //                         itself waited for its streams synchronises them (stubbed synchronise call, stubbed failures)
 //   host/copy_crew.hpp    the calling thread + one helper copying a plane into / out of pinned staging
 //   host/numa_affinity.hpp  GPU PCI address -> NUMA node -> CPU list -> thread affinity, against a FAKE sysfs tree
+//   host/pending_ranges.hpp  caller memory a pipe's queued DMA still owns: what mi_host_unregister consults before it unpins
 // No GPU, no HIP: both headers are written against injected / standard facilities so that their exit paths can be checked here.
 #include <algorithm>
 #include <cstdio>
@@ -14,6 +15,9 @@
 #include "../../opencv-opencl_amd/csrc/host/copy_crew.hpp"
 #include "../../opencv-opencl_amd/csrc/host/drain_guard.hpp"
 #include "../../opencv-opencl_amd/csrc/host/numa_affinity.hpp"
+#include "../../opencv-opencl_amd/csrc/host/pending_ranges.hpp"
+
+#include <thread>
 
 #include <sys/stat.h>
 #include <unistd.h>
@@ -231,9 +235,68 @@ static void test_numa_affinity()
     (void)!system(rm.c_str());
 }
 
+// ---- pending DMA ranges ------------------------------------------------------------------------------------
+// The sequence of mi_pipe_submit / mi_pipe_wait / mi_host_unregister / pipe destruction, with the HIP calls left out: unregister
+// must see BUSY exactly while a frame that is DMA'd from / into the caller's own (pinned) buffer is between submit and wait.
+struct FakePipe { int dummy; };
+
+static bool submit_like(mi_host::PendingRanges& t, FakePipe* p, uint64_t slot, const uint8_t* in, uint8_t* out, size_t bytes,
+                        bool in_pinned, bool out_pinned, bool fail_after_enqueue, std::vector<void*>* synced)
+{
+    t.add(p, slot, in, bytes);                                 // entered BEFORE the ranges are judged
+    t.add(p, slot, out, bytes);
+    struct G { mi_host::PendingRanges& t; FakePipe* p; uint64_t id; bool keep = false; ~G() { if (!keep) t.retire(p, id); } } g{t, p, slot};
+    Drain drain(SyncLog{synced}, nullptr);
+    drain.watch(p);
+    if (fail_after_enqueue) return false;                      // the drain guard waits first (declared later), then the ranges leave
+    drain.done();
+    g.keep = in_pinned || out_pinned;
+    return true;
+}
+
+static void test_pending_ranges()
+{
+    mi_host::PendingRanges t;
+    FakePipe a{}, b{};
+    std::vector<uint8_t> f0(4096), f1(4096), o0(4096), o1(4096);
+    auto busy = [&](const std::vector<uint8_t>& v) { return t.overlaps((uintptr_t)v.data(), (uintptr_t)v.data() + v.size()); };
+    std::vector<void*> synced;
+    CHECK(!busy(f0) && t.size() == 0);
+    CHECK(submit_like(t, &a, 0, f0.data(), o0.data(), 4096, true, true, false, &synced));        // pinned frame in flight
+    CHECK(busy(f0) && busy(o0) && !busy(f1) && t.size() == 2);
+    CHECK(t.overlaps((uintptr_t)f0.data() + 4095, (uintptr_t)f0.data() + 4097));                  // partial overlap counts
+    CHECK(!t.overlaps((uintptr_t)f0.data() + 4096, (uintptr_t)f0.data() + 4097));                 // half-open: the byte after the end does not
+    CHECK(submit_like(t, &a, 1, f1.data(), o1.data(), 4096, false, false, false, &synced));      // staged frame: the DMA runs on the slot's staging
+    CHECK(!busy(f1) && !busy(o1) && t.size() == 2);
+    CHECK(submit_like(t, &b, 0, f1.data(), o1.data(), 4096, true, false, false, &synced));       // another pipe, same slot number, input pinned only
+    CHECK(busy(f1) && busy(o1));                                                                  // (both ranges stay: one entry per frame side)
+    t.retire(&a, 0);                                                                              // mi_pipe_wait of pipe a's frame
+    CHECK(!busy(f0) && !busy(o0) && busy(f1));                                                    // ... does not touch pipe b's slot 0
+    CHECK(synced.empty());
+    CHECK(!submit_like(t, &a, 2, f0.data(), o0.data(), 4096, true, true, true, &synced));        // a failed submit: drained, nothing left pending
+    CHECK(synced.size() == 1 && !busy(f0) && !busy(o0));
+    t.retire_all(&b);                                                                             // pipe b destroyed with its frame never waited for
+    CHECK(!busy(f1) && t.size() == 0);
+    t.add(&a, 0, nullptr, 100); t.add(&a, 0, f0.data(), 0);                                       // nothing to guard
+    CHECK(t.size() == 0);
+    // two threads submitting and retiring while a third keeps asking: no entry is lost or left behind
+    std::thread th[2];
+    for (int k = 0; k < 2; ++k)
+        th[k] = std::thread([&, k] {
+            FakePipe* p = k ? &b : &a;
+            for (int i = 0; i < 20000; ++i) { t.add(p, (uint64_t)(i & 3), f0.data() + 64 * k, 64); t.retire(p, (uint64_t)(i & 3)); }
+        });
+    size_t seen = 0;
+    for (int i = 0; i < 20000; ++i) seen += busy(f0) ? 1 : 0;
+    for (auto& x : th) x.join();
+    CHECK(t.size() == 0 && !busy(f0));
+    (void)seen;
+}
+
 int main()
 {
     test_drain_guard();
+    test_pending_ranges();
     test_copy_crew();
     test_numa_affinity();
     if (g_fail) { fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }

@@ -46,6 +46,12 @@ elif mode == "rank1_fails":
     time.sleep(600)                                       # "blocked in a collective with the dead rank"
 elif mode == "no_line":
     pass
+elif mode == "rank2_hangs":                               # every rank announces its phases; rank 2 never leaves "stream_all_ranks"
+    print(f"[bench hb] rank={rank} phase=timed t=+0.1s", file=sys.stderr, flush=True)
+    if rank == 2:
+        print(f"[bench hb] rank={rank} phase=stream_all_ranks t=+0.2s", file=sys.stderr, flush=True)
+        time.sleep(600)
+    print(f"[bench hb] rank={rank} phase=done t=+0.3s", file=sys.stderr, flush=True)
 '''
 
 
@@ -71,6 +77,36 @@ def test_self_launcher_starts_one_fresh_child_per_gpu(tmp_path, capfd):
     assert rc == 7 and time.monotonic() - t0 < 30                # rank 0 did not keep the launcher for its 600 s
     capfd.readouterr()
     assert bench.launch_children(2, ["no_line"], child_cmd=cmd) == 1     # all ranks fine but no result: still a failure
+
+
+def test_launcher_deadline_reports_each_ranks_phase(tmp_path, capfd):
+    """A job that stops making progress must not end in silence (round 3's four-rank rehearsal left an empty record): at the
+    deadline the launcher ends the children by PID, says which phase each rank last announced, and returns 124."""
+    import time
+    import bench
+    stub = tmp_path / "stub_child.py"
+    stub.write_text(_STUB)
+    t0 = time.monotonic()
+    rc = bench.launch_children(4, ["rank2_hangs"], child_cmd=[sys.executable, str(stub)], deadline_s=3.0)
+    assert rc == 124 and time.monotonic() - t0 < 40
+    _, err = capfd.readouterr()
+    assert "DEADLINE of 3 s passed; ranks still running: [2]" in err
+    assert "rank 2: running, last phase: stream_all_ranks" in err
+    for r in (0, 1, 3):
+        assert f"rank {r}: exited 0, last phase: done" in err
+    assert "[bench hb] rank=2 phase=stream_all_ranks" in err           # heartbeats are relayed as they come
+
+
+def test_rank_watchdog_leaves_with_124():
+    """A rank started by torchrun has no launcher above it: its own watchdog ends it (deadline + 30 s), naming the
+    phase it was in."""
+    # (the 30 s slack after the deadline is shortened to one second by substituting the Timer the watchdog builds)
+    code = ("import sys, time, threading; sys.argv=['bench.py']; import bench; bench._PHASE['name']='timed'; "
+            "real = threading.Timer; threading.Timer = lambda s, f: real(1.0, f); "
+            "bench.arm_rank_watchdog(5.0); time.sleep(60)")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=str(ROOT))
+    assert r.returncode == 124, (r.returncode, r.stderr[-500:])
+    assert "DEADLINE of 5 s passed in phase=timed" in r.stderr
 
 
 def test_plain_invocation_with_gpus_n_launches_instead_of_exiting(tmp_path):
@@ -114,6 +150,34 @@ def test_bench_two_ranks_contract_on_gpu():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     assert d["parity_spot_check"] is True and isinstance(d["fused_fallbacks_in_run"], int)
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_contract_on_gpu():
+    """Four ranks rehearsed on ONE GPU over gloo, extras ON so that the all-ranks stream leg and its reductions run -- the code that
+    only exists for world > 1 and that the driver's 4- and 8-GPU runs execute.  The job must end by itself with one line, every rank
+    must have announced its phases, and no rank may start a further GPU process (a gpurun box allows six)."""
+    import json
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--dist-backend", "gloo", "--all-ranks-on-device", "0",
+                        "--steps", "5", "--warmup", "2", "--cpu-seconds", "1.5", "--batch", "16", "--deadline-s", "600"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["steps"] == 5 and d["scaling"] == "weak"
+    assert d["dist_backend_used"] == "gloo" and d["world_seen_by_backend"] == 4
+    assert abs(d["value"] - 4 * 16 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 0.01
+    assert d["roofline"]["ranks"] == 4 and d["config"]["numa"]["ranks"] == 4 and d["parity_spot_check"] is True
+    sa = d["stream_4k60_512_all_gpus"]
+    assert sa["ranks_ok"] == 4 and sa["errors_total"] == 0 and sa["parity_rank0"] is True, sa
+    assert sa["p50_ms_max"] > 0 and sa["unpaced_frames_per_s_total"] > 0
+    assert d["nv12_1080p"]["value"] > 0 and d["cpu_baseline"]["value"] > 0
+    for rank in range(4):
+        for phase in ("context", "timed", "stream_all_ranks", "reduce", "done"):
+            assert f"[bench hb] rank={rank} phase={phase}" in r.stderr, (rank, phase)
+    assert "nv12_stream" not in r.stderr
 
 
 @pytest.mark.gpu
