@@ -222,7 +222,8 @@ def cpu_baseline(args, w, h):
     except AttributeError:
         avail = os.cpu_count() or 1
     best_t, best_rate = 1, 0.0
-    for cand in sorted({c for c in (1, 4, 8, 16, 32, 64) if c <= avail}):
+    swept = sorted({c for c in (1, 4, 8, 16, 32, 64) if c <= avail})
+    for cand in swept:
         oracle.set_threads(cand)
         oracle.nv12_frame(frames[0], w, h, uv_mode=uv_mode, op=op)
         n0, t0 = 0, time.perf_counter()
@@ -266,10 +267,14 @@ def cpu_baseline(args, w, h):
                 break
     except OSError:
         pass
+    # `cores` is the number of OpenMP THREADS the figure was measured with -- the best of the sweep above -- not a count of physical
+    # cores: the box's affinity mask is far wider than the CPU share it grants, and the sample string says all three numbers
     return {"value": round(multi, 2), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": cpu_model,
             "sample": f"{done} x {w}x{h} NV12 frames ({args.dist}, {args.op}, uv={args.uv}) in {el:.1f} s, "
-                      f"OpenMP row/tile-striped CPU restatement of OpenCV 4.4 (oracle/lumaeq_oracle.c), "
+                      f"OpenMP row/tile-striped CPU restatement of OpenCV 4.4 (oracle/lumaeq_oracle.c); "
+                      f"{threads} OpenMP threads = best of a sweep over {swept} threads, affinity mask {avail} CPUs, "
                       f"host has {os.cpu_count()} logical CPUs",
+            "threads_swept": swept, "affinity_cpus": avail,
             "value_1thread": round(single, 2), "value_1080p": round(fps1080, 2)}
 
 

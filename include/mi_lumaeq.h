@@ -352,9 +352,10 @@ typedef struct mi_profile {
                                      /* distribution of the per-launch durations since the last reset (over at most the
                                       * 65 536 most recent launches of each kernel; 0 when there were none) */
 } mi_profile;
-mi_status   mi_ctx_set_profiling(mi_ctx* ctx, int enabled);   /* 0 off; 1 every kernel; 2 every kernel except the few-microsecond
-                                                                * housekeeping launch behind each fused kernel (two events fewer per
-                                                                * batch: what bench.py's timed region uses) */
+mi_status   mi_ctx_set_profiling(mi_ctx* ctx, int enabled);   /* 0 off; 1 every kernel (what bench.py's timed region uses: its line
+                                                                * lists the finish launches too); 2 every kernel except the
+                                                                * few-microsecond housekeeping launch behind each fused kernel (two
+                                                                * events fewer per batch) */
 mi_status   mi_ctx_profile_read(mi_ctx* ctx, mi_profile* out, int reset);
 const char* mi_kernel_name(int k);
 

@@ -42,17 +42,18 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         Range16* franges = ranges + (size_t)nf * tiles;
         uint32_t* fdone = reinterpret_cast<uint32_t*>(franges + nf);
         const bool bet12 = vec && c->clahe16_fast12;
+        // the context's shift hint: two words at the end of the arrival scratch (read / collect, rolled over by the interpolation kernel)
+        uint32_t* hint = bet12 ? c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 4 : nullptr;
         // 12-bit bet (kernels/clahe16.hip.h): vector geometry only; a tile that loses it is redone the careful way in the same workgroup
         if (bet12)
             LAUNCH(c, s, MI_K_TILE_HIST, (tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
-                   c->d_sync16, franges, fdone, c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 4);
+                   c->d_sync16, franges, fdone, hint);
         else
             LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, vec);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, (const Range16*)ranges, g,
-               lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr),
-               bet12 ? c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 4 : (uint32_t*)nullptr);
+               lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr), hint);
         if (tiles <= 64 && c->clahe16_transposed) {
             // value-major LUTs (one cache line per pixel value): transposed into the histogram area, which is dead by now
             uint16_t* lutT = reinterpret_cast<uint16_t*>(hist);
@@ -60,7 +61,7 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                    (const uint16_t*)luts, lutT, tiles);
             LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16T_kernel, dim3((width + kThreads - 1) / kThreads, height, nf), dim3(kThreads), 0,
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame,
-                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)lutT, (const Range16*)franges);
+                   dst + (size_t)f0 * dst_frame, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)lutT, (const Range16*)franges, hint);
         } else {
             // one workgroup per (tile pair, band, sub-band).  Few frames: enough sub-bands to fill the chip (four workgroups per CU), never
             // less than ~16 rows each.  Many frames: still TWO sub-bands per band while they keep 64 rows -- 2 workgroups are resident per
@@ -79,11 +80,11 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
             if (g.contract)
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<true>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges);
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint);
             else
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<false>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges);
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint);
             // IN-PLACE frames whose range does not fit the LDS table (their workgroups above returned at once); the launch is a no-op for
             // every other frame, and is left out altogether when the call is not in place (it cost 8 us per call)
             if (sp == dp) {

@@ -138,7 +138,7 @@ struct mi_ctx {
                                                                         // the library's pinned staging / DMA'd as the caller pinned them
     PinnedNegCache pin_neg;
     mi_host::CopyCrew* crew = nullptr;                           // helper thread for staging copies of the host forms (created on first use)
-    int pipe_private_streams = 0;                                // option "pipe_private_streams": a pipe created from now on owns its streams instead of sharing the device's
+    int pipe_private_streams = 0;                                // MI_LUMAEQ_PIPE_PRIVATE_STREAMS=1 (measurements): a pipe created from now on owns its streams instead of sharing the device's
     int pipe_copy_streams = 2;                                   // option "pipe_copy_streams": copy streams per direction of a pipe created from now on
     int host_copy_streams = 2;                                   // option "host_copy_streams": 1 = every chunk DMA of a host form on the one stream
     int host_copy_threads = 2;                                   // option "host_copy_threads": 1 = the calling thread copies alone

@@ -86,28 +86,80 @@ struct NumaBinding {
     std::string why;        // human-readable outcome for banners
 };
 
-// Binds the CALLING THREAD to the CPUs of the device's node that the thread may already run on.  Never fails hard: an unknown
-// node, an empty intersection or a refused sched_setaffinity leave the thread where it was and say so in `why`.
+// A dynamically sized CPU set (CPU_ALLOC): the fixed cpu_set_t holds 1024 CPUs, and sched_getaffinity fails with EINVAL on a
+// host that has more.  Grows until the kernel accepts it.
+struct CpuSet {
+    cpu_set_t* set = nullptr;
+    size_t bytes = 0;
+    int ncpus = 0;
+    explicit CpuSet(int n) { resize(n); }
+    CpuSet(const CpuSet& o) { resize(o.ncpus); if (set && o.set) memcpy(set, o.set, bytes); }
+    CpuSet& operator=(const CpuSet&) = delete;
+    ~CpuSet() { if (set) CPU_FREE(set); }
+    void resize(int n)
+    {
+        if (set) CPU_FREE(set);
+        ncpus = n; bytes = CPU_ALLOC_SIZE(n); set = CPU_ALLOC(n);
+        if (set) CPU_ZERO_S(bytes, set);
+    }
+    bool has(int c) const { return set && c >= 0 && c < ncpus && CPU_ISSET_S(c, bytes, set); }
+    void add(int c) { if (set && c >= 0 && c < ncpus) CPU_SET_S(c, bytes, set); }
+    // the calling thread's current affinity mask; false when the kernel refuses every size up to 2^20 CPUs
+    bool load_current()
+    {
+        for (int n = ncpus < 1024 ? 1024 : ncpus; n <= (1 << 20); n *= 2) {
+            if (n != ncpus) resize(n);
+            if (!set) return false;
+            if (sched_getaffinity(0, bytes, set) == 0) return true;
+        }
+        return false;
+    }
+};
+
+// The mask a thread had BEFORE this library first bound it: every later binding of the same thread starts from it, so a thread that
+// was put next to GPU A can be moved next to GPU B on another node (intersecting with the CURRENT mask, as round 3 did, left such a
+// thread with "none of its CPUs is available" and pinned to the wrong socket).
+inline CpuSet*& thread_original_mask()
+{
+    static thread_local struct Holder { CpuSet* p = nullptr; ~Holder() { delete p; } } h;
+    return h.p;
+}
+
+// Binds the CALLING THREAD to the CPUs of the device's node that the thread was allowed to run on before its first binding.  Never
+// fails hard: an unknown node, an empty intersection or a refused sched_setaffinity leave the thread where it was and say so in `why`.
 inline NumaBinding bind_thread_near_pci(const std::string& bdf, const std::string& sysfs_root = "/sys", bool apply = true)
 {
     NumaBinding r;
     r.node = numa_node_of_pci(bdf, sysfs_root);
     if (r.node < 0) { r.why = "device " + normalize_bdf(bdf) + ": no NUMA node reported, thread not bound"; return r; }
     const std::vector<int> node_cpus = cpus_of_node(r.node, sysfs_root);
-    cpu_set_t allowed, want;
-    CPU_ZERO(&allowed); CPU_ZERO(&want);
-    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) { r.why = "sched_getaffinity failed, thread not bound"; return r; }
+    CpuSet*& original = thread_original_mask();
+    CpuSet current(1024);
+    if (!original && !current.load_current()) { r.why = "sched_getaffinity failed, thread not bound"; return r; }
+    const CpuSet& base = original ? *original : current;           // where this thread may run at all
+    CpuSet want(base.ncpus);
     int n = 0;
     for (int c : node_cpus)
-        if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) { CPU_SET(c, &want); ++n; }
+        if (base.has(c)) { want.add(c); ++n; }
     if (n == 0) {
         r.why = "device " + normalize_bdf(bdf) + " is on NUMA node " + std::to_string(r.node) + " but none of its CPUs is available to this process, thread not bound";
         return r;
     }
-    if (apply && sched_setaffinity(0, sizeof want, &want) != 0) { r.why = "sched_setaffinity refused, thread not bound"; return r; }
+    if (apply) {
+        if (!want.set || sched_setaffinity(0, want.bytes, want.set) != 0) { r.why = "sched_setaffinity refused, thread not bound"; return r; }
+        if (!original) original = new CpuSet(current);             // first binding of this thread: remember where it came from
+    }                                                              // (a dry run, apply == false, changes and remembers nothing)
     r.cpus = n;
     r.why = "device " + normalize_bdf(bdf) + " -> NUMA node " + std::to_string(r.node) + ", thread bound to " + std::to_string(n) + " of its CPUs";
     return r;
+}
+
+// Gives the calling thread back the mask it had before its first binding (a pool thread that is done with its GPU); false when the
+// thread was never bound through this header.
+inline bool unbind_thread()
+{
+    CpuSet* original = thread_original_mask();
+    return original && original->set && sched_setaffinity(0, original->bytes, original->set) == 0;
 }
 
 }  // namespace mi_host

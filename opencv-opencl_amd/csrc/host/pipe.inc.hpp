@@ -63,12 +63,15 @@ struct mi_pipe {
     mi_pipe_config cfg{};
     hipStream_t s_h2d[2] = {nullptr, nullptr}, s_k = nullptr, s_d2h[2] = {nullptr, nullptr};
     int n_copy = 2;                                               // copy streams per direction in use (1 or 2)
-    bool private_streams = false;                                 // option "pipe_private_streams": this pipe owns its five streams
+    bool private_streams = false;                                 // MI_LUMAEQ_PIPE_PRIVATE_STREAMS=1: this pipe owns its five streams
     std::vector<PipeSlot> slots;
     size_t head = 0, count = 0;
     size_t ybytes = 0, uvbytes = 0, xfer_in = 0, xfer_out = 0;
     bool uv_dev = false;
     uint32_t* h_hard = nullptr;                                   // pinned: [slot] = device "unrecoverable frames" counter after that frame
+    int wait_mode = 0;                                            // how mi_pipe_wait waits (MI_LUMAEQ_PIPE_WAIT, read once at mi_pipe_create):
+                                                                  // 0 poll with back-off (default), 1 hipEventSynchronize, 2 poll without sleeping
+    int wait_spin_us = 20;                                        // mode 0: how long it polls before the first sleep (MI_LUMAEQ_PIPE_WAIT_SPIN_US)
     uint64_t submitted = 0, completed = 0;
 };
 
@@ -168,6 +171,9 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
     auto bail = [&](mi_status st) { pipe_free(p); return st; };
     if (c->device >= kMaxDevices) { fail(c, MI_ERR_UNSUPPORTED, "pipe: device index too large"); return bail(MI_ERR_UNSUPPORTED); }
     p->private_streams = c->pipe_private_streams != 0;
+    if (const char* e = getenv("MI_LUMAEQ_PIPE_WAIT")) p->wait_mode = !strcmp(e, "sync") ? 1 : (!strcmp(e, "spin") ? 2 : 0);
+    if (getenv("MI_LUMAEQ_PIPE_WAIT_SYNC")) p->wait_mode = 1;     // (round-3 spelling)
+    if (const char* e = getenv("MI_LUMAEQ_PIPE_WAIT_SPIN_US")) p->wait_spin_us = std::max(0, std::min(100000, atoi(e)));
     if (p->private_streams) {
         PipeStreams own;
         for (int i = 0; i < 5; ++i) {
@@ -355,14 +361,23 @@ mi_status mi_pipe_wait(mi_pipe* p, uint64_t* tag, uint8_t** out_frame)
     }
     mi_status st = MI_OK;
     // Wait by polling hipEventQuery: hipEventSynchronize holds runtime locks while it blocks, and a second worker's enqueue calls on
-    // the same device then queue up behind it (2 workers 4600 frames/s against 5400 for one).
+    // the same device then queue up behind it (2 workers 4600 frames/s against 5400 for one).  Polling without a pause, as round 3
+    // did, keeps one host core per worker 100 % busy for nothing (a streaming host also captures and encodes:
+    // OpenCVequalHist.cpp:102-196), so after `wait_spin_us` the thread SLEEPS between polls, each time for a quarter of the time it
+    // has waited so far (at most 200 us): the completion is noticed at most 25 % (+ the kernel's timer slack) late, whatever the
+    // transfer takes, and the frames queued behind this one keep the engines busy meanwhile.  A frame with NOTHING queued behind it
+    // is a caller waiting for its result (a paced stream: one 0.35 ms wait per 16.7 ms frame period): it is polled for up to 2 ms
+    // before the first sleep, so its latency is what the transfer takes (sleeping cost it 0.09 ms of 0.38: profiles/r04_c_*).
     hipError_t e = hipSuccess;
-    if (getenv("MI_LUMAEQ_PIPE_WAIT_SYNC")) e = hipEventSynchronize(sl.ev_done);
+    if (p->wait_mode == 1) e = hipEventSynchronize(sl.ev_done);
     else {
-        for (unsigned spins = 0;; ++spins) {
+        const auto t_wait = std::chrono::steady_clock::now();
+        for (;;) {
             e = hipEventQuery(sl.ev_done);
             if (e != hipErrorNotReady) break;
-            if (spins < 2000) __builtin_ia32_pause(); else std::this_thread::yield();
+            const long long waited_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wait).count();
+            if (p->wait_mode == 2 || waited_us < (p->count == 1 ? std::max(2000, p->wait_spin_us) : p->wait_spin_us)) { for (int k = 0; k < 16; ++k) __builtin_ia32_pause(); }
+            else std::this_thread::sleep_for(std::chrono::microseconds(std::min<long long>(200, std::max<long long>(1, waited_us / 4))));
         }
     }
     e = MI_HOOKED(c, e);

@@ -346,6 +346,19 @@ __device__ __forceinline__ void hist12_vec(uint32_t* h, const u32x4& q, uint32_t
     hist12_dword<COPIES>(h, q.z, cp, sft, wl, por); hist12_dword<COPIES>(h, q.w, cp, sft, wl, por);
 }
 
+// The context's shift hint ("which shift did the previous call's frames settle on"): TWO words.  Word 0 is only READ while the tile
+// kernels of a call run -- every tile of every frame of a launch sees one value, so tiles of a frame cannot disagree because they
+// read at different times -- word 1 collects what this call's frames settle on (any of them: a stream keeps its format), and the
+// interpolation kernel, which runs when all of that is over, copies word 1 to word 0 for the next call.  Relaxed agent-scope
+// accesses: the words live across launches and XCDs.  Speed only: bytes never depend on the hint (see tile_hist12_kernel).
+__device__ __forceinline__ uint32_t hint_in(const uint32_t* h) { return __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hint_out(uint32_t* h, uint32_t v) { __hip_atomic_store(h + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hint_roll(uint32_t* h)
+{
+    if (h && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        __hip_atomic_store(h, __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // grid = (tiles, frames), NT threads, 4096 * COPIES * 4 bytes of dynamic LDS; vector geometry only (the host checks: no padding,
 // tile_w % 8 == 0, 16-B aligned rows).  A thread owns 4096 / NT consecutive bins in the LUT stage.
 template <int NT, int COPIES>
@@ -419,10 +432,10 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
     uint32_t sft_v = 0u;                                             // uniform (made scalar below)
     if (o16 >= (uint32_t)kBins12) {
         const uint32_t smax = (uint32_t)__builtin_ctz(o16), smin = 20u - (uint32_t)__builtin_clz(o16);     // bitlen(o16) - 12
-        const uint32_t hint = *shift_hint;
+        const uint32_t hint = hint_in(shift_hint);
         sft_v = (hint >= smin && hint <= smax) ? hint : smax;
     } else if (o16 == 0u) {
-        sft_v = min(*shift_hint, 15u);                              // nothing but zeros seen: any shift will do, so go along with the frame before
+        sft_v = min(hint_in(shift_hint), 15u);                      // nothing but zeros seen: any shift will do, so go along with the frame before
     }
     const uint32_t sft = (uint32_t)__builtin_amdgcn_readfirstlane((int)sft_v);       // in SGPRs: the sweep has no VGPR to spare
     const uint32_t wl = min(12u, 16u - sft);
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
         }
         frame_ranges[f] = r;
         frame_done[f] = done ? 1u : 0u;
-        if (done) *shift_hint = (uint32_t)__builtin_ctz(shifts);
+        if (done) hint_out(shift_hint, (uint32_t)__builtin_ctz(shifts));
     };
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
         __syncthreads();
@@ -648,7 +661,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     const Range16 own_r = ranges[tile_id];
     if (blockIdx.x == 0 && t == 0) {
         Range16 r; r.lo = flo; r.hi = fhi | (sft << 16); frame_ranges[blockIdx.y] = r;
-        if (shift_hint) *shift_hint = sft;                          // what the next frame's flat tiles should go along with
+        if (shift_hint) hint_out(shift_hint, sft);                  // what the next frame's flat tiles should go along with
     }
     // Who reads this tile's LUT, and where?  Pixels of the tile itself and of its eight neighbours, at THEIR values.  So the LUT is
     // needed over the union of those nine tiles' ranges only, not over the frame's: one hot pixel at 65535 in a 12-bit frame then
@@ -771,10 +784,11 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                                                                          uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                          ClaheGeom g, const uint16_t* __restrict__ luts,
                                                                          const Range16* __restrict__ frame_ranges, int subs, int n_frames,
-                                                                         const Range16* __restrict__ tile_ranges)
+                                                                         const Range16* __restrict__ tile_ranges, uint32_t* shift_hint)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 tab[];      // [kInterp16Entries] {a | b << 16, c | d << 16}
     const int t = threadIdx.x;
+    hint_roll(shift_hint);
     const int npairs = g.tiles_x + 1, bands = g.tiles_y + 1;
     // Workgroups reach the 8 XCDs round-robin in launch order.  A ROW of workgroups -- the tiles_x + 1 pairs of one (frame, band,
     // sub-band) -- is given to ONE XCD, its pairs one after the other: the rectangles of neighbouring pairs meet in the middle of a
@@ -1123,8 +1137,9 @@ __global__ __launch_bounds__(kThreads) void transpose_lut16_kernel(const uint16_
 __global__ __launch_bounds__(kThreads) void clahe_interp16T_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                   uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                   ClaheGeom g, const uint16_t* __restrict__ lutT,
-                                                                  const Range16* __restrict__ frame_ranges)
+                                                                  const Range16* __restrict__ frame_ranges, uint32_t* shift_hint)
 {
+    hint_roll(shift_hint);
     const int f = blockIdx.z, y = blockIdx.y;
     const int x = blockIdx.x * kThreads + threadIdx.x;
     if (x >= g.width) return;

@@ -4,6 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// gfx950 ONLY, and not merely as a tuning choice.  The hand-offs between workgroups (hist_lut_kernel, tile_hist12_kernel, the fused
+// equalize kernel) order their data with RELAXED agent-scope atomics drained by `s_waitcnt vmcnt(0)`: that is sound where a
+// no-return atomic is counted by vmcnt and performed at the L2, the device's point of coherence -- the gfx9 family.  The HIP memory
+// model promises neither; gfx10 and later count stores with vscnt, and there a LUT would silently be computed from incomplete
+// histograms.  Building the device code for anything else is therefore an error, not a slower build (csrc/Makefile's ARCH is
+// overridable).  tests/test_gpu_parity.py::test_equalize_paths_agree runs the last-workgroup path (two_kernel_max_frames=64), the fused and
+// the three-kernel path over the same batches against the oracle.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmi_lumaeq's kernels rely on gfx950 (gfx9-family) memory semantics: relaxed agent-scope atomics + s_waitcnt vmcnt(0); build with --offload-arch=gfx950"
+#endif
+
 namespace mi {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

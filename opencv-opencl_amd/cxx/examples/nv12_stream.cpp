@@ -16,6 +16,7 @@
 // the binding is printed in the banner), --max-workers-per-gpu K (default 2; 0 = no cap).  --workers may exceed the GPU count
 // (worker w -> GPU w mod N), up to 64; at most K of them are started per GPU.
 #include <sched.h>
+#include <sys/resource.h>
 
 #include <algorithm>
 #include <chrono>
@@ -134,6 +135,14 @@ int main(int argc, char** argv)
         // synthetic source: the ring's frames exist before the clock starts (a camera / decoder hands over finished frames;
         // generating 12 MB of noise per frame on the submitting thread would otherwise be the slowest stage of the first lap)
         if (!fin) for (int k = 0; k < ring && k < frames; ++k) synth(in[k], k);
+        // what the stream costs the HOST: CPU time of the whole process (submitting thread, workers, the library's helper threads, the
+        // runtime's own threads) between the first submit and the last delivery -- the cores a capture / encode stage would not get
+        auto cpu_seconds = [] {
+            rusage ru{};
+            getrusage(RUSAGE_SELF, &ru);
+            return std::pair<double, double>(ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6);
+        };
+        const auto cpu0 = cpu_seconds();
         const auto t0 = std::chrono::steady_clock::now();
         auto last_tick = t0;
         uint64_t last_out = 0;
@@ -162,6 +171,7 @@ int main(int argc, char** argv)
         }
         pool.finish();
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const auto cpu1 = cpu_seconds();
         printf("done: %llu frames in %.3f s = %.1f frames/s (host NV12 in -> host NV12 out, PCIe inclusive), errors=%llu\n",
                (unsigned long long)pool.stats().frames_out.load(), el, pool.stats().frames_out.load() / el,
                (unsigned long long)pool.stats().processing_errors.load());
@@ -170,6 +180,12 @@ int main(int argc, char** argv)
             printf("worker time per frame (us, summed over %d worker(s)): submit %.1f, wait %.1f, deliver %.1f, idle %.1f\n", pool.workers(),
                    pool.stats().ns_submit.load() / n / 1e3, pool.stats().ns_wait.load() / n / 1e3, pool.stats().ns_deliver.load() / n / 1e3,
                    pool.stats().ns_idle.load() / n / 1e3);
+        }
+        {
+            const double n = (double)std::max<uint64_t>(1, pool.stats().frames_out.load());
+            const double us = cpu1.first - cpu0.first, ss = cpu1.second - cpu0.second;
+            printf("host CPU: %.1f us per frame (user %.1f + sys %.1f), %.2f host cores busy on average over the %.3f s (whole process, getrusage)\n",
+                   (us + ss) / n * 1e6, us / n * 1e6, ss / n * 1e6, (us + ss) / el, el);
         }
         // submit -> in-order delivery latency (the reference only prints averages: clahevideo.cpp:54-84)
         std::vector<float> lat;

@@ -229,7 +229,30 @@ static void test_numa_affinity()
     if (!n1.empty()) {
         b = bind_thread_near_pci("0000:e3:00.0", root);
         CHECK(b.node == 1 && b.cpus == (int)n1.size());
-        CHECK(sched_setaffinity(0, sizeof allowed, &allowed) == 0);
+        // ... and straight on to a GPU on the OTHER node, without anybody widening the mask in between: the thread's mask from before
+        // its first binding is the base, not the one it has now (round 3: "none of its CPUs is available", stuck on the wrong socket)
+        b = bind_thread_near_pci("0000:c1:00.0", root);
+        CHECK(b.node == 0 && b.cpus == (int)n0.size());
+        CPU_ZERO(&now);
+        CHECK(sched_getaffinity(0, sizeof now, &now) == 0 && CPU_COUNT(&now) == (int)n0.size());
+        for (int c : n0) CHECK(CPU_ISSET(c, &now) != 0);
+        CHECK(unbind_thread());                                                      // back where the thread came from
+        CPU_ZERO(&now);
+        CHECK(sched_getaffinity(0, sizeof now, &now) == 0 && CPU_COUNT(&now) == (int)mine.size());
+        // another thread has its own "original" mask: bound, it narrows; unbind_thread() on a thread never bound says so
+        bool fresh_unbind = true; int fresh_cpus = -1;
+        std::thread([&] { fresh_unbind = unbind_thread(); fresh_cpus = bind_thread_near_pci("0000:e3:00.0", root).cpus; }).join();
+        CHECK(!fresh_unbind && fresh_cpus == (int)n1.size());
+    }
+    {   // CpuSet: sized beyond the 1024 CPUs a cpu_set_t holds
+        CpuSet big(5000);
+        big.add(4999); big.add(7); big.add(5000); big.add(-1);
+        CHECK(big.has(4999) && big.has(7) && !big.has(5000) && !big.has(8) && big.bytes >= 5000 / 8);
+        CpuSet copy(big);
+        CHECK(copy.has(4999) && copy.ncpus == 5000);
+        CpuSet cur(8);
+        CHECK(cur.load_current() && cur.ncpus >= 1024);
+        for (int c : mine) CHECK(cur.has(c));
     }
     const std::string rm = "rm -rf " + root;
     (void)!system(rm.c_str());

@@ -483,3 +483,77 @@ def test_pipe_randomized_sessions():
             c.close()
             for a in registered:
                 mi_lumaeq.host_unregister(a)
+
+
+def test_host_unregister_is_refused_while_a_pipe_dma_is_pending():
+    """A frame the caller registered is DMA'd as it is, asynchronously: between mi_pipe_submit and the mi_pipe_wait that retires it the
+    copy engines own its pages, and unpinning them then is a GPU access to an ordinary heap address (the round-3 memory fault was one).
+    mi_host_unregister answers MI_ERR_BUSY in that window -- for the input and the output buffer -- and works once the frame has been
+    waited for, or once the pipe has been destroyed with the frame never waited for.  Unregistered frames are staged: never guarded."""
+    w, h = 1920, 1080
+    f = synth.nv12_frame(w, h, "D2", 31).copy()
+    o, o2 = np.zeros_like(f), np.zeros_like(f)
+    plain_in, plain_out = f.copy(), np.zeros_like(f)
+    want = oracle.nv12_frame(f, w, h, uv_mode=0, op=0)
+    for a in (f, o, o2):
+        mi_lumaeq.host_register(a)
+    registered = {id(a): a for a in (f, o, o2)}                    # (by identity: `in` / remove on a list would compare array contents)
+
+    def unregister(a):
+        mi_lumaeq.host_unregister(a)
+        del registered[id(a)]
+    try:
+        with mi_lumaeq.Context(0) as c:
+            with mi_lumaeq.Pipe(c, w, h, depth=3) as pipe:
+                assert pipe.submit(f, o, 1)
+                for a in (f, o):
+                    with pytest.raises(mi_lumaeq.MiError) as e:
+                        mi_lumaeq.host_unregister(a)
+                    assert e.value.status == mi_lumaeq.ERR_BUSY
+                assert pipe.submit(plain_in, plain_out, 2)             # staged both ways: the DMA never sees these arrays
+                assert pipe.wait()[0] == 1 and np.array_equal(o, want)
+                unregister(o)                                          # frame 1 retired: its output buffer is free
+                with pytest.raises(mi_lumaeq.MiError):
+                    mi_lumaeq.host_unregister(plain_in)                # never registered: BAD_ARG as before, pending or not
+                assert pipe.wait()[0] == 2 and np.array_equal(plain_out, want)
+                assert pipe.submit(f, o2, 3)                           # left in flight on purpose
+                with pytest.raises(mi_lumaeq.MiError) as e:
+                    mi_lumaeq.host_unregister(o2)
+                assert e.value.status == mi_lumaeq.ERR_BUSY
+            # the pipe is gone (its streams were drained): nothing is pending any more
+            unregister(o2)
+            unregister(f)
+            assert np.array_equal(o2, want)
+            assert c.get_stat("host_planes_direct") >= 4 and c.get_stat("host_planes_staged") >= 2
+    finally:
+        for a in list(registered.values()):
+            mi_lumaeq.host_unregister(a)
+
+
+def test_a_plane_is_only_dmad_directly_when_it_lies_in_one_pinned_allocation(ctx):
+    """Both ends of a plane pinned is not enough: two separately pinned blocks with ordinary memory between them, or a registration
+    that covers part of the plane, must be packed through the library's staging like any unpinned plane (host_range_pinned asks the
+    runtime for the allocation around each end).  A pinned torch tensor -- one allocation -- is still DMA'd as it is."""
+    w, h = 2048, 512                                                # 1 MiB plane, page-aligned inside a larger array
+    raw = np.zeros(w * h + 8192, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    y = raw[off: off + w * h].reshape(h, w)
+    y[:] = synth.y_plane(w, h, "D2", 12)
+    want = oracle.equalize_hist(y)
+    head, tail = y[: h // 4], y[3 * h // 4:]                         # first and last quarter pinned, the middle half pageable
+    mi_lumaeq.host_register(head)
+    mi_lumaeq.host_register(tail)
+    try:
+        s0, d0 = ctx.get_stat("host_planes_staged"), ctx.get_stat("host_planes_direct")
+        got = ctx.equalize_hist(y)
+        assert np.array_equal(got, want)
+        assert ctx.get_stat("host_planes_staged") == s0 + 2 and ctx.get_stat("host_planes_direct") == d0      # source AND fresh destination staged
+        assert np.array_equal(ctx.equalize_hist(head), oracle.equalize_hist(head))                            # a plane inside ONE registration
+        assert ctx.get_stat("host_planes_direct") == d0 + 1
+    finally:
+        mi_lumaeq.host_unregister(head)
+        mi_lumaeq.host_unregister(tail)
+    pin_in, pin_out = torch.from_numpy(y.copy()).pin_memory(), torch.empty((h, w), dtype=torch.uint8).pin_memory()
+    d1 = ctx.get_stat("host_planes_direct")
+    got = ctx.equalize_hist(pin_in.numpy(), pin_out.numpy())
+    assert np.array_equal(got, want) and ctx.get_stat("host_planes_direct") == d1 + 2

@@ -79,7 +79,7 @@ int main(int argc, char** argv)
     auto k_hist = [&] { hipLaunchKernelGGL((tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * 4, 0, (const uint8_t*)src, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone, hint); };
     auto k_lut = [&] { hipLaunchKernelGGL(tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, 0, (const uint32_t*)hist, (const Range16*)ranges, g, lut_scale16, clip16, luts, franges, (const uint32_t*)fdone, hint); };
     auto k_int = [&] { hipLaunchKernelGGL(clahe_interp16_kernel<false>, dim3(igrid), dim3(kInterp16Threads), kInterp16Entries * 8, 0,
-                                          (const uint8_t*)src, (long long)step, (long long)plane, dst, (long long)step, (long long)plane, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges); };
+                                          (const uint8_t*)src, (long long)step, (long long)plane, dst, (long long)step, (long long)plane, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint); };
     k_hist(); k_lut(); k_int(); CK(hipDeviceSynchronize());
     const char* names[3] = {"12-bit noise", "constant 777", "smooth 12-bit + 4 bits of noise"};
     printf("%d frames of %d x %d CV_16UC1, %s, subs = %d\n", nf, W, H, names[content], subs);
@@ -108,7 +108,7 @@ int main(int argc, char** argv)
                 hipLaunchKernelGGL((tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, chunk), dim3(kHist12Threads), kHist12Words * 4, 0, sp, (long long)step, (long long)plane, g, hist, ranges, lut_scale16, clip16, luts, sync, franges, fdone, hint);
                 hipLaunchKernelGGL(tile_lut16_kernel, dim3(tiles, chunk), dim3(1024), 0, 0, (const uint32_t*)hist, (const Range16*)ranges, g, lut_scale16, clip16, luts, franges, (const uint32_t*)fdone, hint);
                 hipLaunchKernelGGL(clahe_interp16_kernel<false>, dim3(cgrid), dim3(kInterp16Threads), kInterp16Entries * 8, 0,
-                                   sp, (long long)step, (long long)plane, dp, (long long)step, (long long)plane, g, (const uint16_t*)luts, (const Range16*)franges, subs, chunk, (const Range16*)ranges);
+                                   sp, (long long)step, (long long)plane, dp, (long long)step, (long long)plane, g, (const uint16_t*)luts, (const Range16*)franges, subs, chunk, (const Range16*)ranges, hint);
             }
         }, reps);
         printf("sequence in chunks of %2d    %7.1f us  = %.0f frames/s\n", chunk, tc, nf / (tc * 1e-6));
