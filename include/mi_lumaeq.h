@@ -207,7 +207,14 @@ mi_status mi_clahe_u16_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step
  * Video pipelines recycle a small pool of frame buffers (GstBufferPool; the reference maps such buffers at
  * OpenCVequalHist.cpp:115/:158).  Registering a pool's memory once lets the host-pointer forms DMA straight
  * from / into it instead of staging through the context's pinned buffers (contiguous planes only; anything
- * else still stages).  Process-wide, thread-safe; the memory must stay valid until mi_host_unregister(). */
+ * else still stages).  Process-wide, thread-safe; the memory must stay valid -- and must not be freed -- until
+ * mi_host_unregister() has returned MI_OK.
+ * mi_host_unregister returns MI_ERR_BUSY, and leaves the buffer registered, while a pipe still has a transfer queued on it
+ * (between the mi_pipe_submit that took the frame and the mi_pipe_wait that returns it, or the pipe's destruction): unpinning
+ * pages under the copy engine is a GPU access to an ordinary heap address, which ends the process.  The reference's accelerator
+ * path has the same window and no guard (OpenCLequalHist.cpp:356-367).  MI_ERR_BAD_ARG: `ptr` is not the start of a registered range.
+ * Memory the caller pinned by other means (hipHostMalloc, hipHostRegister) is recognised as pinned when the whole plane lies in ONE
+ * such allocation; releasing it while frames are pending is the caller's responsibility. */
 mi_status mi_host_register(void* ptr, size_t bytes);
 mi_status mi_host_unregister(void* ptr);
 
@@ -334,7 +341,9 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  *                        reference's own board: txf = fma(x, 1/tw, -0.5), res = fma(fma(l11, xa1, l12*xa), ya1,
  *                        fma(l21, xa1, l22*xa) * ya).  The two differ by 1 in about 0.03 % of the pixels.
  * Other statistics (mi_ctx_get_stat): "error_drains" (error returns that had to wait for a stream first),
- * "host_copies_shared" (staging copies of the host forms the context's helper thread took half of). */
+ * "host_copies_shared" (staging copies of the host forms the context's helper thread took half of), "host_planes_staged" /
+ * "host_planes_direct" (host planes -- inputs and outputs of the host forms and of pipe frames -- packed through the library's
+ * pinned staging / DMA'd as the caller pinned them: the library never gives the runtime memory it did not find pinned). */
 mi_status mi_ctx_synchronize(mi_ctx* ctx, void* stream);
 mi_status mi_ctx_set_option(mi_ctx* ctx, const char* name, int value);
 mi_status mi_ctx_get_stat(mi_ctx* ctx, const char* name, uint64_t* out);

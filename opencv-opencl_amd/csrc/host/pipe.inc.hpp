@@ -71,7 +71,9 @@ struct mi_pipe {
     uint32_t* h_hard = nullptr;                                   // pinned: [slot] = device "unrecoverable frames" counter after that frame
     int wait_mode = 0;                                            // how mi_pipe_wait waits (MI_LUMAEQ_PIPE_WAIT, read once at mi_pipe_create):
                                                                   // 0 poll with back-off (default), 1 hipEventSynchronize, 2 poll without sleeping
-    int wait_spin_us = 20;                                        // mode 0: how long it polls before the first sleep (MI_LUMAEQ_PIPE_WAIT_SPIN_US)
+    int wait_spin_us = 0;                                         // mode 0: how long it polls before the first sleep when frames are queued behind
+                                                                  // (MI_LUMAEQ_PIPE_WAIT_SPIN_US; 0 / 5 / 20 / 50 us: 1.51 / 1.58 / 1.63 / 1.80 host cores
+                                                                  // per unpaced 4K worker at the same 5.44 k frames/s, profiles/r04_d_*)
     uint64_t submitted = 0, completed = 0;
 };
 

@@ -199,7 +199,9 @@ int main(int argc, char** argv)
                    lat[lat.size() / 2], lat[lat.size() * 9 / 10], lat[std::min(lat.size() - 1, lat.size() * 99 / 100)], lat.back(), budget, late,
                    paced ? "" : "  (unpaced: latency includes queueing)");
         }
-        if (pin) for (int k = 0; k < ring; ++k) { unregisterHostBuffer(in[k].data()); unregisterHostBuffer(out[k].data()); }
+        if (pin)                                                  // every frame was delivered (pool.finish()): nothing is pending on the ring
+            for (int k = 0; k < ring; ++k)
+                if (!unregisterHostBuffer(in[k].data()) || !unregisterHostBuffer(out[k].data())) fprintf(stderr, "frame ring slot %d still has a transfer pending\n", k);
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -402,7 +402,16 @@ inline void registerHostBuffer(void* ptr, size_t bytes)
         MI_CV_ERROR(st == MI_ERR_NO_DEVICE ? GpuNotSupported : GpuApiCallError,
                     std::string("mi_host_register: ") + mi_status_str(st) + (st == MI_ERR_NO_DEVICE ? " (no HIP device: this backend has no CPU fallback)" : ""));
 }
-inline void unregisterHostBuffer(void* ptr) { (void)mi_host_unregister(ptr); }
+// Unpin it again BEFORE its memory is released.  Returns false -- and the buffer stays registered -- while a pipe still has a transfer
+// queued on it (MI_ERR_BUSY: wait for the pending frames or destroy the pool first, then ask again); any other failure throws.
+// (Non-throwing on the busy case on purpose: it is called from destructors and clean-up paths.)
+inline bool unregisterHostBuffer(void* ptr)
+{
+    const mi_status st = mi_host_unregister(ptr);
+    if (st == MI_ERR_BUSY) return false;
+    if (st != MI_OK) MI_CV_ERROR(st == MI_ERR_BAD_ARG ? StsBadArg : GpuApiCallError, std::string("mi_host_unregister: ") + mi_status_str(st));
+    return true;
+}
 
 // ---- whole NV12 frame helpers (what every caller of the reference does around the call) ----
 enum UVMode { UV_FILL128 = MI_UV_FILL128, UV_COPY = MI_UV_COPY };

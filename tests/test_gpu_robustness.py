@@ -523,7 +523,7 @@ def test_host_unregister_is_refused_while_a_pipe_dma_is_pending():
             # the pipe is gone (its streams were drained): nothing is pending any more
             unregister(o2)
             unregister(f)
-            assert np.array_equal(o2, want)
+            assert np.array_equal(o2[: w * h], want[: w * h])         # its Y plane arrived (the UV half is written by the wait that never came)
             assert c.get_stat("host_planes_direct") >= 4 and c.get_stat("host_planes_staged") >= 2
     finally:
         for a in list(registered.values()):
