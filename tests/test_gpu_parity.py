@@ -282,6 +282,17 @@ def test_clahe_kats(ctx):
     src = rng.integers(0, 256, (37, 53), dtype=np.uint8)
     lut = oracle.clahe_tile_luts(src, 4.0, 1, 1)[0]
     assert np.array_equal(ctx.clahe(src, 4.0, 1, 1), lut[src])                           # CL-2
+    import json
+    from pathlib import Path
+    kats = {k["id"]: k for k in json.loads((Path(__file__).parent / "golden" / "kat.json").read_text())["clahe"]}
+    k = kats["CL-4"]                                                                     # interpolation weights on step-function LUTs
+    q = np.empty((8, 8), np.uint8)
+    q[:4, :4], q[:4, 4:], q[4:, :4], q[4:, 4:] = k["src_quadrants"]
+    assert ctx.clahe(q, k["clip"], *k["tiles"]).reshape(-1).tolist() == k["dst"]
+    k = kats["CL-5"]                                                                     # ties to even inside CLAHE's LUT
+    a = np.concatenate([np.full(n, v, np.uint8) for v, n in k["src_runs"]])[None, :]
+    o = ctx.clahe(a, k["clip"], *k["tiles"])
+    assert (o[a == 1] == 126).all() and (o[a == 2] == 255).all()
 
 
 def test_clahe_tile_luts_stage(ctx):

@@ -23,6 +23,11 @@ def _kat_src(k):
         return np.full((h, w), k["src_const"], np.uint8)
     if "src_arange" in k:
         return np.arange(k["src_arange"], dtype=np.uint8).reshape(h, w)
+    if "src_quadrants" in k:                 # four constant quadrants: top-left, top-right, bottom-left, bottom-right
+        q = k["src_quadrants"]
+        a = np.empty((h, w), np.uint8)
+        a[: h // 2, : w // 2], a[: h // 2, w // 2:], a[h // 2:, : w // 2], a[h // 2:, w // 2:] = q
+        return a
     raise KeyError(k["id"])
 
 
@@ -49,6 +54,21 @@ def test_clahe_kat_cl1(impl):
     f = oracle.clahe if impl == "c" else oracle.np_clahe
     out = f(src, k["clip"], *k["tiles"])
     assert (out == k["dst_const"]).all()
+
+
+@pytest.mark.parametrize("k", [k for k in KAT["clahe"] if k["id"] in ("CL-4", "CL-5")], ids=lambda k: k["id"])
+@pytest.mark.parametrize("impl", ["c", "numpy"])
+def test_clahe_kat_interpolation_weights_and_lut_tie(k, impl):
+    """CL-4: the bilinear weights (computed before the tile indices are clamped) on an image whose tile LUTs are step functions;
+    CL-5: round-half-to-even inside CLAHE's own LUT (cvRound of cum * lutScale)."""
+    src = _kat_src(k)
+    f = oracle.clahe if impl == "c" else oracle.np_clahe
+    out = f(src, k["clip"], *k["tiles"])
+    if "dst" in k:
+        assert out.reshape(-1).tolist() == k["dst"]
+    if "lut" in k:
+        for v, want in k["lut"].items():
+            assert (out[src == int(v)] == want).all(), (v, want)
 
 
 def test_clahe_kat_cl3_pad_quirk():
