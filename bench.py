@@ -603,14 +603,13 @@ def main():
     hb("done")
 
 
-def stream_in_process(torch, mi_lumaeq, synth, device, w, h, frames=512, fps=60, unpaced_frames=1500, check_with_oracle=False):
+def stream_in_process(torch, mi_lumaeq, synth, device, w, h, frames=512, fps=60, unpaced_frames=1500, check_with_oracle=False, ring=8, depth=0):
     """BASELINE.json configs[3] inside THIS process: `frames` WxH NV12 host frames released at `fps` through an mi_pipe on `device`
     (a context of its own; pinned frame ring, the way a recycled buffer pool is registered once), latency = release -> delivered;
     then the same pipe unpaced with its depth kept in flight.  The N > 1 ranks use this instead of an nv12_stream child each, so a
     job never has more GPU processes than ranks."""
     import numpy as np
     fb = w * h * 3 // 2
-    ring, depth = 8, 4
     # the ring is ordinary memory registered ONCE with the library (mi_host_register), the way nv12_stream registers its ring and a
     # pipeline would register a recycled buffer pool: registered ranges are recognised without asking the runtime about every frame
     ins = [np.empty(fb, np.uint8) for _ in range(ring)]
@@ -618,7 +617,7 @@ def stream_in_process(torch, mi_lumaeq, synth, device, w, h, frames=512, fps=60,
     base = [synth.nv12_frame(w, h, "D2", 4000 + k) for k in range(2)]
     for k in range(ring):
         ins[k][:] = base[k % 2]
-    res = {"frames": frames, "fps": fps, "driver": "in-process mi_pipe (python), depth 4, registered ring of 8", "errors": 0}
+    res = {"frames": frames, "fps": fps, "errors": 0}
     registered = []
     ctx2 = mi_lumaeq.Context(device)
     try:
@@ -626,6 +625,8 @@ def stream_in_process(torch, mi_lumaeq, synth, device, w, h, frames=512, fps=60,
             mi_lumaeq.host_register(a)
             registered.append(a)
         with mi_lumaeq.Pipe(ctx2, w, h, op=mi_lumaeq.OP_EQUALIZE, uv_mode=mi_lumaeq.UV_FILL128, depth=depth) as pipe:
+            depth = pipe.depth                                  # 0 asked for the library's default for this frame size
+            res["driver"] = f"in-process mi_pipe (python), depth {depth}, registered ring of {ring}"
             for k in range(4):                                  # warm: staging verdicts, queues
                 pipe.submit(ins[k % ring], outs[k % ring], k)
                 pipe.wait()

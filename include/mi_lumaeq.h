@@ -239,7 +239,9 @@ mi_status mi_host_unregister(void* ptr);
  *              128 / copied by the calling thread inside mi_pipe_wait while the engines work (the reference's own
  *              memset / memcpy, OpenCVequalHist.cpp:160-162, ColoropenCVCwqualHist.cpp:165);
  *              MI_PIPE_UV_DEVICE: whole frames cross the bus and the kernels write the UV half (no host CPU work)
- *   depth      frames in flight, 2..16 (0 = default 4)
+ *   depth      frames in flight, 2..16; 0 = by frame size: 3 for frames of 8 MiB and more (4K), 6 below (measured: a thread that
+ *              submits and waits on 4K frames is fastest with three in flight, 1080p frames want six; a pool whose worker is fed
+ *              by another thread runs 4K best with four -- cxx/mi_pool.hpp passes its own)
  * mi_pipe_submit returns MI_ERR_BUSY when `depth` frames are pending.  mi_pipe_wait blocks for the OLDEST pending
  * frame and returns its tag and output pointer.  A pipe uses its context's scratch and lock: ONE pipe per context (a
  * second mi_pipe_create answers MI_ERR_BUSY), destroy it before the context; the context's other compute entry points may

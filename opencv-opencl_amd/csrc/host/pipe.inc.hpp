@@ -164,8 +164,11 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
     mi_pipe* p = new (std::nothrow) mi_pipe();
     if (!p) return fail(c, MI_ERR_OOM, "pipe allocation failed");
     p->c = c; p->cfg = *cfg;
-    p->cfg.depth = std::max(2, std::min(16, cfg->depth > 0 ? cfg->depth : 4));
     p->ybytes = (size_t)cfg->width * cfg->height; p->uvbytes = p->ybytes / 2;
+    // Default depth by frame size (profiles/r04_t_*, r04_u_*): one thread that submits and waits on 4K frames is fastest with THREE in
+    // flight (5.44-5.59 k frames/s; four: 4.74-4.81 k, two: 3.8-4.3 k -- a fourth frame only deepens the copy lanes' queues), while
+    // 1080p frames, bound by their per-frame launch sequence, want more (six: 17.2 k, four: 15.8 k, three: 13.0 k through the pool)
+    p->cfg.depth = cfg->depth > 0 ? std::max(2, std::min(16, cfg->depth)) : (p->ybytes + p->uvbytes >= ((size_t)8 << 20) ? 3 : 6);
     // the channel op needs chroma on the device; otherwise the UV half stays on the host unless asked for
     p->uv_dev = cfg->op == MI_OP_CHANNELS || cfg->uv_policy == MI_PIPE_UV_DEVICE;
     p->xfer_in = p->ybytes + ((p->uv_dev && (cfg->op == MI_OP_CHANNELS || cfg->uv_mode == MI_UV_COPY)) ? p->uvbytes : 0);

@@ -40,7 +40,7 @@ static bool kv(const char* arg, const char* key, std::string& v, int& i, int arg
 int main(int argc, char** argv)
 {
     using namespace micv;
-    int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8, depth = 4, per_gpu = 2;
+    int workers = 1, width = 1920, height = 1080, fps = 60, frames = 600, tile = 8, depth = 0, per_gpu = 2;
     double clip = 2.0;
     bool paced = false, pin = true, loop = false, numa_bind = true;
     int dump_every = 1;
@@ -70,6 +70,7 @@ int main(int argc, char** argv)
     }
     if (width <= 0 || height <= 0 || frames <= 0) { fprintf(stderr, "bad size\n"); return 1; }
     const size_t fb = (size_t)width * height + (size_t)width * height / 2;
+    if (depth <= 0) depth = fb >= ((size_t)8 << 20) ? 4 : 6;      // a pool worker (fed by the submitting thread): four 4K frames in flight, six of 1080p or less (profiles/r04_t_*)
     const int ring = 32;                                            // frames in flight (input + output ring)
     // every worker on one GPU (one worker, or a one-GPU process -- how bench.py runs one streamer per GPU): the submitting thread
     // and the frame ring it first-touches below belong next to that GPU as well

@@ -542,7 +542,7 @@ class Pipe:
     The arrays handed to submit() are kept alive until wait() returns them."""
 
     def __init__(self, ctx: Context, width: int, height: int, op: int = OP_EQUALIZE, uv_mode: int = UV_FILL128,
-                 clip_limit: float = 2.0, tiles_x: int = 8, tiles_y: int = 8, depth: int = 4, uv_policy: int = PIPE_UV_AUTO):
+                 clip_limit: float = 2.0, tiles_x: int = 8, tiles_y: int = 8, depth: int = 0, uv_policy: int = PIPE_UV_AUTO):
         self._ctx = ctx
         self._h = C.c_void_p()
         self._held = {}

@@ -557,3 +557,23 @@ def test_a_plane_is_only_dmad_directly_when_it_lies_in_one_pinned_allocation(ctx
     d1 = ctx.get_stat("host_planes_direct")
     got = ctx.equalize_hist(pin_in.numpy(), pin_out.numpy())
     assert np.array_equal(got, want) and ctx.get_stat("host_planes_direct") == d1 + 2
+
+
+def test_pipe_default_depth_follows_the_frame_size():
+    """depth = 0 asks for the library's default: three 4K frames in flight (what one submitting-and-waiting thread drives fastest),
+    six frames of 1080p and below; an explicit depth is kept (clamped to 2..16).  Frames still come back in order with the oracle's bytes."""
+    with mi_lumaeq.Context(0) as c:
+        for (w, h, want) in ((3840, 2160, 3), (1920, 1080, 6), (640, 360, 6)):
+            with mi_lumaeq.Pipe(c, w, h) as pipe:
+                assert pipe.depth == want, (w, h, pipe.depth)
+                f = synth.nv12_frame(w, h, "D2", 5)
+                outs = [np.zeros_like(f) for _ in range(want)]
+                for k in range(want):
+                    assert pipe.submit(f, outs[k], k)
+                assert not pipe.submit(f, np.zeros_like(f), 99)          # full at its depth: MI_ERR_BUSY
+                assert [pipe.wait()[0] for _ in range(want)] == list(range(want))
+                ref = oracle.nv12_frame(f, w, h, uv_mode=0, op=0)
+                assert all(np.array_equal(o, ref) for o in outs)
+        for asked, got in ((1, 2), (5, 5), (40, 16)):
+            with mi_lumaeq.Pipe(c, 640, 360, depth=asked) as pipe:
+                assert pipe.depth == got
