@@ -54,12 +54,15 @@ public:
     enum Op { EQUALIZE, CLAHE_OP, CHANNELS_EQ };   // CHANNELS_EQ: NV12 -> BGR -> equalizeHist on B, G, R -> NV12 (BASELINE config 5 read literally; ignores uv)
     using Sink = std::function<void(const FrameJob&)>;   // called in frame order, from a pool thread
 
-    // depth: frames a worker keeps in flight on its GPU (2..16); uv_policy: MI_PIPE_UV_AUTO / _HOST / _DEVICE (mi_lumaeq.h)
+    // depth: frames a worker keeps in flight on its GPU (2..16; 0 = by frame size: 4 at 4K, 6 at 1080p and below);
+    // uv_policy: MI_PIPE_UV_AUTO / _HOST / _DEVICE (mi_lumaeq.h)
     FramePool(int workers, int width, int height, Op op, UVMode uv, Sink sink,
-              double clip = 2.0, Size tiles = Size(8, 8), size_t max_queue = 16, int depth = 4, int uv_policy = MI_PIPE_UV_AUTO,
+              double clip = 2.0, Size tiles = Size(8, 8), size_t max_queue = 16, int depth = 0, int uv_policy = MI_PIPE_UV_AUTO,
               bool numa_bind = true, int max_workers_per_gpu = 2)
         : width_(width), height_(height), op_(op), uv_(uv), clip_(clip), tiles_(tiles), sink_(std::move(sink)), max_queue_(max_queue),
-          depth_(depth < 2 ? 2 : (depth > 16 ? 16 : depth)), uv_policy_(uv_policy), numa_bind_(numa_bind)
+          depth_(depth <= 0 ? ((size_t)width * height * 3 / 2 >= ((size_t)8 << 20) ? 4 : 6)      // a worker fed by the submitting thread: four 4K
+                            : (depth < 2 ? 2 : (depth > 16 ? 16 : depth))),                      // frames, six of 1080p and below (docs/experiments.md R4.9)
+          uv_policy_(uv_policy), numa_bind_(numa_bind)
     {
         if (workers < 1) workers = 1;
         if (workers > 64) workers = 64;
