@@ -27,12 +27,19 @@ struct ColorJob {
 // wrong bytes for the V plane here (tools/dbg_color.hip reproduces it: neighbouring bytes get OR-ed together).
 __device__ __forceinline__ int yuv_descale(int x) { int r = (x + (1 << 13)) >> 14; asm volatile("" : "+v"(r)); return r; }
 __device__ __forceinline__ uint32_t sat_u8(int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+// (r - y) and (b - y) lie in [-255, 255] -- the three luma weights add up to 1 << 14, so y is a weighted mean of three bytes -- but the
+// opaque descale hides that from the compiler, which then multiplies with v_mul_lo_u32 (quarter rate).  __mul24 says it: v_mad_i32_i24.
 __device__ __forceinline__ void px_bgr2yuv(uint32_t b, uint32_t g, uint32_t r, uint32_t& Y, uint32_t& U, uint32_t& V)
 {
     const int y = yuv_descale((int)b * 1868 + (int)g * 9617 + (int)r * 4899);
-    V = sat_u8(yuv_descale(((int)r - y) * 14369 + (128 << 14)));
-    U = sat_u8(yuv_descale(((int)b - y) * 8061 + (128 << 14)));
+    V = sat_u8(yuv_descale(__mul24((int)r - y, 14369) + (128 << 14)));
+    U = sat_u8(yuv_descale(__mul24((int)b - y, 8061) + (128 << 14)));
     Y = sat_u8(y);
+}
+// luma alone (the histogram pass needs nothing else; the descales above are volatile to the optimiser and would not be dropped)
+__device__ __forceinline__ uint32_t px_bgr2y(uint32_t b, uint32_t g, uint32_t r)
+{
+    return sat_u8(yuv_descale((int)b * 1868 + (int)g * 9617 + (int)r * 4899));
 }
 __device__ __forceinline__ void px_yuv2bgr(uint32_t Y, uint32_t U, uint32_t V, uint32_t& b, uint32_t& g, uint32_t& r)
 {
@@ -162,17 +169,10 @@ __global__ __launch_bounds__(kBgrThreads) void bgr_luma_hist_kernel(ColorJob j, 
             uint32_t c0[16], c1[16], c2[16];
             load_bgr16(s3 + gidx * 48, c0, c1, c2);
 #pragma unroll
-            for (int px = 0; px < 16; ++px) {
-                uint32_t Y, U, V;
-                px_bgr2yuv(c0[px], c1[px], c2[px], Y, U, V);
-                lds_inc(h, (Y << kCopyShift) + copy);
-            }
+            for (int px = 0; px < 16; ++px) lds_inc(h, (px_bgr2y(c0[px], c1[px], c2[px]) << kCopyShift) + copy);
         }
-        for (long long x = (groups << 4) + (long long)blockIdx.x * kBgrThreads + t; x < j.row_px; x += (long long)gridDim.x * kBgrThreads) {
-            uint32_t Y, U, V;
-            px_bgr2yuv(s3[3 * x], s3[3 * x + 1], s3[3 * x + 2], Y, U, V);
-            lds_inc(h, (Y << kCopyShift) + copy);
-        }
+        for (long long x = (groups << 4) + (long long)blockIdx.x * kBgrThreads + t; x < j.row_px; x += (long long)gridDim.x * kBgrThreads)
+            lds_inc(h, (px_bgr2y(s3[3 * x], s3[3 * x + 1], s3[3 * x + 2]) << kCopyShift) + copy);
     }
     __syncthreads();
     if (t < 256) partial[((size_t)f * gridDim.x + blockIdx.x) * 256 + t] = lds_hist_bin(h, t);

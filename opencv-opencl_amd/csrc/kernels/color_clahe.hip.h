@@ -23,10 +23,14 @@ __device__ __forceinline__ u32x4 bgr16_to_y(const uint8_t* p, u32x4* up, u32x4* 
     uint32_t wy[4] = {0, 0, 0, 0}, wu[4] = {0, 0, 0, 0}, wv[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int px = 0; px < 16; ++px) {
-        uint32_t Y, U, V;
-        px_bgr2yuv(c0[px], c1[px], c2[px], Y, U, V);
-        wy[px >> 2] |= Y << (8 * (px & 3));
-        if (WANT_UV) { wu[px >> 2] |= U << (8 * (px & 3)); wv[px >> 2] |= V << (8 * (px & 3)); }
+        if (WANT_UV) {
+            uint32_t Y, U, V;
+            px_bgr2yuv(c0[px], c1[px], c2[px], Y, U, V);
+            wy[px >> 2] |= Y << (8 * (px & 3));
+            wu[px >> 2] |= U << (8 * (px & 3)); wv[px >> 2] |= V << (8 * (px & 3));
+        } else {
+            wy[px >> 2] |= px_bgr2y(c0[px], c1[px], c2[px]) << (8 * (px & 3));      // luma alone: the opaque descales of U and V would not be dropped
+        }
     }
     if (WANT_UV) {
         u32x4 u = {wu[0], wu[1], wu[2], wu[3]}, v = {wv[0], wv[1], wv[2], wv[3]};
