@@ -72,8 +72,9 @@ struct mi_pipe {
     int wait_mode = 0;                                            // how mi_pipe_wait waits (MI_LUMAEQ_PIPE_WAIT, read once at mi_pipe_create):
                                                                   // 0 poll with back-off (default), 1 hipEventSynchronize, 2 poll without sleeping
     int wait_spin_us = 0;                                         // mode 0: how long it polls before the first sleep when frames are queued behind
-                                                                  // (MI_LUMAEQ_PIPE_WAIT_SPIN_US; 0 / 5 / 20 / 50 us: 1.51 / 1.58 / 1.63 / 1.80 host cores
-                                                                  // per unpaced 4K worker at the same 5.44 k frames/s, profiles/r04_d_*)
+                                                                  // (MI_LUMAEQ_PIPE_WAIT_SPIN_US; 4K: 0 / 5 / 20 / 50 us = 1.51 / 1.58 / 1.63 / 1.80 host cores
+                                                                  // per unpaced worker at the same 5.44 k frames/s, profiles/r04_d_*; set by frame size in
+                                                                  // mi_pipe_create: frames below 8 MiB are only polled)
     uint64_t submitted = 0, completed = 0;
 };
 
@@ -178,7 +179,10 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
     p->private_streams = c->pipe_private_streams != 0;
     if (const char* e = getenv("MI_LUMAEQ_PIPE_WAIT")) p->wait_mode = !strcmp(e, "sync") ? 1 : (!strcmp(e, "spin") ? 2 : 0);
     if (getenv("MI_LUMAEQ_PIPE_WAIT_SYNC")) p->wait_mode = 1;     // (round-3 spelling)
-    if (const char* e = getenv("MI_LUMAEQ_PIPE_WAIT_SPIN_US")) p->wait_spin_us = std::max(0, std::min(100000, atoi(e)));
+    // frames below 8 MiB (1080p: ~58 us per frame, 720p: ~43 us) are polled without sleeping: one sleep is ~55 us with the kernel's
+    // default timer slack -- a whole frame -- and cost 4-5 % of the throughput for 0.1-0.3 of a core (profiles/r04_z_*)
+    p->wait_spin_us = p->ybytes + p->uvbytes >= ((size_t)8 << 20) ? 0 : 1000000;
+    if (const char* e = getenv("MI_LUMAEQ_PIPE_WAIT_SPIN_US")) p->wait_spin_us = std::max(0, std::min(1000000, atoi(e)));
     if (p->private_streams) {
         PipeStreams own;
         for (int i = 0; i < 5; ++i) {
