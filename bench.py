@@ -40,6 +40,8 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0  # same guide: float4 copy ceiling
+DEADLINE_DEFAULT_S = 480.0      # launcher deadline; a torchrun rank's own watchdog fires RANK_WATCHDOG_SLACK_S later: 510 s < the driver's 600 s
+RANK_WATCHDOG_SLACK_S = 30.0
 
 
 def parse_args(argv=None):
@@ -63,9 +65,14 @@ def parse_args(argv=None):
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="rehearsal only: every rank uses this GPU index instead of LOCAL_RANK")
     ap.add_argument("--no-numa-bind", action="store_true", help="do not bind each rank to the CPUs of its GPU's NUMA node")
-    ap.add_argument("--deadline-s", type=float, default=900.0,
+    ap.add_argument("--force-dist", action="store_true",
+                    help="bring the process group up even with ONE rank (RANK=0, WORLD_SIZE=1 on 127.0.0.1 when the environment sets "
+                         "none): init_process_group on the chosen backend, every all_reduce / barrier of the N>1 path on that backend's "
+                         "tensors, the all-ranks stream leg, destroy_process_group -- the statements an N-GPU run executes, on one GPU")
+    ap.add_argument("--deadline-s", type=float, default=DEADLINE_DEFAULT_S,
                     help="whole-job deadline: the launcher ends its children by PID, says which phase each rank was in and exits 124; "
-                         "a rank started by torchrun ends itself 30 s later (0 = none)")
+                         "a rank started by torchrun ends itself 30 s later (0 = none).  The default keeps both inside the 600 s the "
+                         "driver gives a bench run, so a stuck job names its ranks' phases before it is killed from outside")
     return ap.parse_args(argv)
 
 
@@ -93,7 +100,7 @@ def arm_rank_watchdog(deadline_s):
         print(f"{HB_TAG} rank={_PHASE['rank']} DEADLINE of {deadline_s:.0f} s passed in phase={_PHASE['name']}: leaving with 124",
               file=sys.stderr, flush=True)
         os._exit(124)
-    t = threading.Timer(deadline_s + 30.0, fire)
+    t = threading.Timer(deadline_s + RANK_WATCHDOG_SLACK_S, fire)
     t.daemon = True
     t.start()
     return t
@@ -107,7 +114,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_children(n, argv, child_cmd=None, grace_s=30.0, env_extra=None, deadline_s=900.0):
+def launch_children(n, argv, child_cmd=None, grace_s=30.0, env_extra=None, deadline_s=DEADLINE_DEFAULT_S):
     """Start n fresh processes of this script, one per GPU (RANK / LOCAL_RANK = 0..n-1, WORLD_SIZE = n, rendezvous on 127.0.0.1),
     relay rank 0's JSON line(s) to stdout and everything else to stderr, return the worst exit code.  The calling process must
     not have touched the GPU: nothing here does, and nothing is exec'd in place -- the children are ordinary child processes.
@@ -311,6 +318,12 @@ def main():
         # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (no torch import yet).
         sys.exit(launch_children(args.gpus, sys.argv[1:], deadline_s=args.deadline_s))
     arm_rank_watchdog(args.deadline_s)
+    # stdout carries ONE JSON line and nothing else.  Native libraries write to file descriptor 1 behind Python's back (RCCL prints a
+    # five-line version banner there when the first communicator comes up -- seen in round 5's first one-rank RCCL run), so from here on
+    # fd 1 IS stderr, and the line goes out through a private duplicate of the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     hb("import")
     import torch
     import torch.distributed as dist
@@ -323,7 +336,13 @@ def main():
     if args.all_ranks_on_device is not None:
         local_rank = args.all_ranks_on_device
     _PHASE["rank"] = rank
-    if world > 1:
+    # --force-dist: a one-rank world on the real backend.  Decided here, before the first GPU call; the rendezvous is given to
+    # torch.distributed through the environment of THIS process (nothing is re-executed).
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist and "MASTER_PORT" not in os.environ:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # what launch_children gives its ranks
+    if use_dist:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs HIP devices (no CPU fallback)")
         hb(f"dist_init({args.dist_backend})")
@@ -343,6 +362,7 @@ def main():
             raise SystemExit(f"dist backend check failed: asked {args.dist_backend} x {world}, got {backend_used} x {world_seen}")
     else:
         backend_used, world_seen = None, 1
+    dgroup = dist if use_dist else None                              # what the reductions below go through
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -381,7 +401,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -409,7 +429,7 @@ def main():
     except mi_lumaeq.MiError as e:
         run_ok, run_err, fused_fallbacks = False, str(e), -1
     prof = ctx.profile_read(reset=True)
-    elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None)
+    elapsed = shard.max_over_ranks(elapsed, dgroup)
 
     # parity spot check of the measured configuration (rank 0; first, middle and last frame of the last step) -- checker only
     parity = None
@@ -424,9 +444,9 @@ def main():
             parity = parity and bool(np.array_equal(got, want))
     # one verdict for the whole job, shared BEFORE anybody exits, so no rank is left blocked in a barrier
     ok_local = 1.0 if (run_ok and parity is not False) else 0.0
-    ok_all = -shard.max_over_ranks(-ok_local, dist if world > 1 else None)
+    ok_all = -shard.max_over_ranks(-ok_local, dgroup)
     if ok_all < 1.0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         raise SystemExit("REFUSING TO REPORT: " + (run_err or ("PARITY FAILURE: GPU output differs from the oracle" if parity is False
                                                                  else "another rank failed its run or parity check")))
@@ -454,7 +474,7 @@ def main():
         for _ in range(steps2):
             step2()
         barrier()
-        el2 = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
+        el2 = shard.max_over_ranks(time.perf_counter() - t0, dgroup)
         second = {"workload": f"{hb2} x {hw}x{hh} NV12 frames per GPU per step, same op", "value": round(hb2 * world * steps2 / el2, 1), "unit": "frames/s",
                   "steps": steps2, "ms_per_step": round(el2 / steps2 * 1e3, 4),
                   "whole_path_frac_of_8TBs": round((3 * hw * hh + (hw * hh // 2) * (2 if args.uv == "copy" else 1)) * hb2 * steps2 / el2 / 1e9 / HBM_PEAK_GBS, 4)}        # per GPU
@@ -466,7 +486,7 @@ def main():
     # nv12_stream child per rank, which doubles the processes on the GPUs (four ranks rehearsed on one GPU = 8 GPU processes, more than
     # a gpurun box allows -- docs/experiments.md R4.1).  Every rank takes part in the reductions whatever happened to its own leg.
     stream_all = None
-    if world > 1 and not args.no_extras and (w, h) == (3840, 2160):
+    if use_dist and not args.no_extras and (w, h) == (3840, 2160):
         barrier()
         hb("stream_all_ranks")
         try:
@@ -508,13 +528,12 @@ def main():
     # all ranks run the same configuration; a rank without timings contributes a negative value and voids the mean)
     hb("reduce")
     dom_ms_mine = kinfo[dom]["avg_ms"] if dom else -1.0
-    dgroup = dist if world > 1 else None
     dom_ms_sum = shard.reduce_over_ranks(dom_ms_mine, dgroup, "sum")
     dom_ms_max = shard.reduce_over_ranks(dom_ms_mine, dgroup, "max")
     dom_ms_min = -shard.reduce_over_ranks(-dom_ms_mine, dgroup, "max")
     fallbacks_all = int(shard.reduce_over_ranks(float(max(fused_fallbacks, 0)), dgroup, "sum"))
     ranks_bound = int(shard.reduce_over_ranks(1.0 if placement.get("cpus", 0) > 0 else 0.0, dgroup, "sum"))
-    if world > 1:
+    if use_dist:
         dist.barrier()                           # every reduction is done: the ranks leave together, rank 0 goes on alone
         dist.destroy_process_group()
     if rank != 0:
@@ -593,13 +612,16 @@ def main():
         out["stream_4k60_512_all_gpus"] = stream_all
     if world == 1:
         out["opencv_cross_check"] = guarded(opencv_cross_check, ctx, w, h, args.dist)
-    if world == 1 and not args.no_extras:
+    if world == 1 and not use_dist and not args.no_extras:       # (--force-dist behaves like a rank of an N>1 job: no N=1 extras)
         hb("extras")
         out["extras"] = guarded(extras, ctx, args, torch, mi_lumaeq, synth)
     if not args.no_cpu_baseline:
         hb("cpu_baseline")                                   # N > 1 as well: rank 0 alone by now, the other ranks have exited
         out["cpu_baseline"] = guarded(cpu_baseline, args, w, h)
-    print(json.dumps(out), flush=True)
+    line = (json.dumps(out) + "\n").encode()
+    while line:
+        line = line[os.write(json_fd, line):]
+    os.close(json_fd)
     hb("done")
 
 

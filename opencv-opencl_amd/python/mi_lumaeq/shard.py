@@ -35,8 +35,10 @@ def merge_in_order(per_rank: Sequence[Sequence], n_frames: int) -> list:
 
 
 def reduce_over_ranks(value: float, dist=None, op: str = "max") -> float:
-    """One scalar reduced over the ranks ("max" or "sum") through the job's own backend; the value itself without a process group."""
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    """One scalar reduced over the ranks ("max" or "sum") through the job's own backend; the value itself without a process group.
+    A one-rank process group is NOT short-cut: `bench.py --force-dist` brings one up on RCCL precisely so that these statements run
+    on one GPU the way they run on eight."""
+    if dist is None or not dist.is_available() or not dist.is_initialized():
         return float(value)
     import torch
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -48,7 +50,7 @@ def reduce_over_ranks(value: float, dist=None, op: str = "max") -> float:
 def max_over_ranks(seconds: float, dist=None) -> float:
     """Whole-job time of a sharded step = the slowest rank's time (no collective on the data path;
     this single scalar all-reduce only aggregates the measurement)."""
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_available() or not dist.is_initialized():
         return float(seconds)
     import torch
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"

@@ -180,6 +180,44 @@ def test_bench_four_ranks_contract_on_gpu():
     assert "nv12_stream" not in r.stderr
 
 
+def test_deadlines_fit_inside_the_drivers_limit():
+    """The driver ends a bench run after 600 s.  The launcher's deadline and a torchrun rank's own watchdog (deadline + slack) must
+    both fire before that, or a stuck N-rank job is killed from outside without a single "rank r was in phase p" line."""
+    import bench
+    assert bench.parse_args([]).deadline_s == bench.DEADLINE_DEFAULT_S <= 480.0
+    assert bench.DEADLINE_DEFAULT_S + bench.RANK_WATCHDOG_SLACK_S < 600.0 - 60.0
+    assert bench.launch_children.__defaults__[-1] == bench.DEADLINE_DEFAULT_S
+
+
+@pytest.mark.gpu
+def test_bench_nccl_world1_contract_on_gpu():
+    """The RCCL branch on ONE GPU: `--force-dist` brings up a one-rank process group on the real backend, so init_process_group("nccl",
+    device_id=...), the world_seen all-reduce, every shard.reduce_over_ranks / max_over_ranks on a CUDA tensor, barrier() on RCCL, the
+    all-ranks stream leg beside a live communicator and destroy_process_group() execute exactly as on the driver's 8-GPU node
+    (the reference's 1..8 workers, OpenCVequalHist.cpp:274, :397-402).  The headline must not move because of it."""
+    import json
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    common = ["--steps", "20", "--warmup", "5", "--cpu-seconds", "1.5"]
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--force-dist"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert r.stdout.strip() == lines[0].strip(), r.stdout[:600]      # nothing but the line: RCCL's version banner (fd 1) must land on stderr
+    assert d["dist_backend_used"] == "nccl" and d["world_seen_by_backend"] == 1 and d["n_gpus"] == 1
+    assert d["parity_spot_check"] is True and d["fused_fallbacks_in_run"] == 0 and d["roofline"]["ranks"] == 1
+    sa = d["stream_4k60_512_all_gpus"]                               # the leg that only runs beside a process group
+    assert sa["ranks_ok"] == 1 and sa["errors_total"] == 0 and sa["parity_rank0"] is True and sa["unpaced_frames_per_s_total"] > 0, sa
+    assert "extras" not in d                                         # behaves like a rank of an N > 1 job
+    for phase in ("dist_init(nccl)", "timed", "stream_all_ranks", "reduce", "done"):
+        assert f"[bench hb] rank=0 phase={phase}" in r.stderr, phase
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-extras"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    plain = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert plain["dist_backend_used"] is None
+    assert abs(d["value"] - plain["value"]) / plain["value"] < 0.03, (d["value"], plain["value"])
+
+
 @pytest.mark.gpu
 def test_bench_line_contract_on_gpu():
     """`python bench.py` prints ONE JSON line with the fields the driver reads, the roofline and cpu_baseline objects, and the
@@ -191,6 +229,7 @@ def test_bench_line_contract_on_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
+    assert r.stdout.strip() == lines[0].strip(), r.stdout[:600]      # stdout is the line and nothing else
     assert d["metric"] == "frames/sec, 3840x2160 NV12 Y equalizeHist" and d["unit"] == "frames/s"
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "u8" and d["data"] == "synthetic"

@@ -78,3 +78,36 @@ def test_shard_helpers():
         shard.frames_for_rank(4, 2, 2)
     assert shard.max_over_ranks(1.5) == 1.5
     assert shard.reduce_over_ranks(2.5, None, "sum") == 2.5
+
+
+def _one_rank_worker(port, q):
+    sys.path.insert(0, str(ROOT / "opencv-opencl_amd" / "python"))
+    from mi_lumaeq import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **kw):
+        calls.append(t.device.type)
+        return real(t, *a, **kw)
+    dist.all_reduce = counting
+    try:
+        got = (shard.max_over_ranks(0.75, dist), shard.reduce_over_ranks(4.0, dist, "sum"), shard.reduce_over_ranks(-2.0, dist, "max"))
+    finally:
+        dist.all_reduce = real
+        dist.destroy_process_group()
+    q.put((got, calls))
+
+
+def test_one_rank_group_still_goes_through_the_backend():
+    """`bench.py --force-dist` (world size 1 on RCCL) exists so that the reductions of the N > 1 path execute on one GPU: a one-rank
+    group must really call all_reduce, not return early."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(29500 + (os.getpid() % 2000) + 31, q))
+    p.start()
+    got, calls = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert got == (0.75, 4.0, -2.0) and calls == ["cpu", "cpu", "cpu"]
