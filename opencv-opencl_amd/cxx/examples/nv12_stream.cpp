@@ -83,7 +83,7 @@ int main(int argc, char** argv)
     // Workers on SEVERAL GPUs in this one process: frame k goes to worker k mod N and lives in ring slot k mod 32, so when N divides 32
     // slot s always feeds the same worker -- its two frames are first-touched from a thread bound next to that worker's GPU.
     const int ndev = std::max(1, getDeviceCount());
-    const int eff_workers = per_gpu >= 1 ? std::min(workers, ndev * per_gpu) : workers;
+    const int eff_workers = FramePool::workers_started(workers, ndev, per_gpu);
     std::vector<std::vector<unsigned char>> in(ring), out(ring);
     if (numa_bind && eff_workers > 1 && ndev > 1 && ring % eff_workers == 0) {
         cpu_set_t all;
@@ -91,7 +91,7 @@ int main(int argc, char** argv)
         const bool have_all = sched_getaffinity(0, sizeof all, &all) == 0;
         for (int s = 0; s < ring; ++s) {
             mi_numa_binding nb{};
-            (void)mi_thread_bind_near_device((s % eff_workers) % ndev, &nb);
+            (void)mi_thread_bind_near_device(FramePool::device_of_frame((uint64_t)s, eff_workers, ndev), &nb);     // ring % workers == 0: slot s only ever carries frames of that worker
             in[s].assign(fb, 0); out[s].assign(fb, 0);                                   // value-initialisation = first touch
             if (have_all) (void)sched_setaffinity(0, sizeof all, &all);
         }
@@ -201,8 +201,11 @@ int main(int argc, char** argv)
                    paced ? "" : "  (unpaced: latency includes queueing)");
         }
         if (pin)                                                  // every frame was delivered (pool.finish()): nothing is pending on the ring
-            for (int k = 0; k < ring; ++k)
-                if (!unregisterHostBuffer(in[k].data()) || !unregisterHostBuffer(out[k].data())) fprintf(stderr, "frame ring slot %d still has a transfer pending\n", k);
+            for (int k = 0; k < ring; ++k) {
+                const mi_status si = tryUnregisterHostBuffer(in[k].data());     // both halves of the slot, whatever the first one answers;
+                const mi_status so = tryUnregisterHostBuffer(out[k].data());    // clean-up path: the non-throwing form
+                if (si != MI_OK || so != MI_OK) fprintf(stderr, "frame ring slot %d not unpinned: in %s, out %s\n", k, mi_status_str(si), mi_status_str(so));
+            }
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

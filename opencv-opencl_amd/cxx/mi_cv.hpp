@@ -402,12 +402,15 @@ inline void registerHostBuffer(void* ptr, size_t bytes)
         MI_CV_ERROR(st == MI_ERR_NO_DEVICE ? GpuNotSupported : GpuApiCallError,
                     std::string("mi_host_register: ") + mi_status_str(st) + (st == MI_ERR_NO_DEVICE ? " (no HIP device: this backend has no CPU fallback)" : ""));
 }
-// Unpin it again BEFORE its memory is released.  Returns false -- and the buffer stays registered -- while a pipe still has a transfer
-// queued on it (MI_ERR_BUSY: wait for the pending frames or destroy the pool first, then ask again); any other failure throws.
-// (Non-throwing on the busy case on purpose: it is called from destructors and clean-up paths.)
+// Unpin it again BEFORE its memory is released.  Two forms:
+//   tryUnregisterHostBuffer  never throws (destructors, clean-up paths): MI_OK = unpinned; MI_ERR_BUSY = a pipe still has a transfer queued on
+//                            it, the buffer STAYS registered (wait for the pending frames or destroy the pool first, then ask again);
+//                            MI_ERR_BAD_ARG = not the start of a registered range; MI_ERR_HIP = the runtime refused, still registered.
+//   unregisterHostBuffer     returns false on the busy case and THROWS on every other failure -- not for destructors.
+inline mi_status tryUnregisterHostBuffer(void* ptr) noexcept { return mi_host_unregister(ptr); }
 inline bool unregisterHostBuffer(void* ptr)
 {
-    const mi_status st = mi_host_unregister(ptr);
+    const mi_status st = tryUnregisterHostBuffer(ptr);
     if (st == MI_ERR_BUSY) return false;
     if (st != MI_OK) MI_CV_ERROR(st == MI_ERR_BAD_ARG ? StsBadArg : GpuApiCallError, std::string("mi_host_unregister: ") + mi_status_str(st));
     return true;

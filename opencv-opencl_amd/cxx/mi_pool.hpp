@@ -73,16 +73,27 @@ public:
         // run at 4.9-5.05 k (profiles/r03_c_nv12_stream_crowd.txt).  So at most `max_workers_per_gpu` workers are started per GPU;
         // requested() still reports what was asked for.
         requested_ = workers;
-        if (max_workers_per_gpu >= 1 && workers > ndev * max_workers_per_gpu) workers = ndev * max_workers_per_gpu;
+        workers = workers_started(workers, ndev, max_workers_per_gpu);
         queues_.resize(workers);
         placement_.resize(workers);
-        for (int w = 0; w < workers; ++w) threads_.emplace_back([this, w, ndev] { run(w, w % ndev); });
+        for (int w = 0; w < workers; ++w) threads_.emplace_back([this, w, ndev] { run(w, device_of_worker(w, ndev)); });
         // wait until every worker has created its context and sized its staging/scratch for W x H, so the first real
         // frame does not pay ~100 ms of one-time allocation (it would blow a 16.7 ms frame budget)
         std::unique_lock<std::mutex> lk(mu_);
         cv_done_.wait(lk, [&] { return ready_ == (int)threads_.size(); });
     }
     ~FramePool() { finish(); }
+
+    // The sharding rule, in one place (frame k -> GPU k mod N): frame k -> worker k mod workers -> GPU worker mod GPUs.
+    // Static, so a caller can place per-frame resources (nv12_stream first-touches ring slots next to the GPU they feed).
+    static int workers_started(int requested, int ndev, int max_workers_per_gpu)
+    {
+        if (requested < 1) requested = 1;
+        if (requested > 64) requested = 64;
+        return (max_workers_per_gpu >= 1 && requested > ndev * max_workers_per_gpu) ? ndev * max_workers_per_gpu : requested;
+    }
+    static int device_of_worker(int worker, int ndev) { return worker % ndev; }
+    static int device_of_frame(uint64_t frame, int workers, int ndev) { return device_of_worker((int)(frame % (uint64_t)workers), ndev); }
 
     int workers() const { return (int)threads_.size(); }        // workers actually started (<= max_workers_per_gpu per GPU)
     int requested() const { return requested_; }
@@ -96,7 +107,7 @@ public:
     {
         std::unique_lock<std::mutex> lk(mu_);
         const uint64_t idx = next_index_++;
-        auto& q = queues_[idx % queues_.size()];             // frame k -> worker k mod N
+        auto& q = queues_[idx % queues_.size()];             // frame k -> worker k mod N (device_of_frame())
         cv_space_.wait(lk, [&] { return q.size() < max_queue_ || stop_; });
         FrameJob j; j.index = idx; j.in = in; j.out = out;
         q.push_back(j);

@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -49,6 +50,15 @@ struct World {
     std::map<int, uint64_t> frames_by_device;
     int live_pipes = 0, peak_pipes = 0;
     uint64_t submit_failures = 0, wait_failures = 0;
+    std::map<void*, size_t> registered;                    // mi_host_register
+    std::vector<std::pair<std::thread::id, int>> bind_log; // every mi_thread_bind_near_device call, in order
+
+    World()
+    {   // a program built against the stub (nv12_stream in tests/test_pool_multidev.py) is configured through the environment
+        if (const char* e = std::getenv("MI_STUB_DEVICES")) devices = std::atoi(e);
+        if (const char* e = std::getenv("MI_STUB_SUBMIT_FAILS")) submit_fails.insert(std::atoi(e));
+        if (const char* e = std::getenv("MI_STUB_CTX_FAILS")) ctx_fails.insert(std::atoi(e));
+    }
 
     void reset(int ndev)
     {
@@ -58,6 +68,7 @@ struct World {
         wait_fail_every = 3; max_delay_us = 1500;
         live_ctx.clear(); peak_ctx.clear(); ctx_created.clear(); bound.clear(); ctx_by_thread.clear(); completions.clear();
         frames_by_device.clear(); live_pipes = peak_pipes = 0; submit_failures = wait_failures = 0;
+        registered.clear(); bind_log.clear();
     }
 };
 inline World& world() { static World w; return w; }
@@ -142,12 +153,31 @@ inline mi_status mi_thread_bind_near_device(int device, mi_numa_binding* out)
     auto& w = stub::world();
     std::lock_guard<std::mutex> lk(w.mu);
     w.bound[std::this_thread::get_id()] = device;
+    w.bind_log.emplace_back(std::this_thread::get_id(), device);
+    if (std::getenv("MI_STUB_TRACE")) std::fprintf(stderr, "STUBTRACE bind device=%d\n", device);
     if (out) {
         out->node = device / 4;                          // two "sockets" of four devices
         out->cpus = 16;
         std::snprintf(out->why, sizeof out->why, "stub: GPU %d -> NUMA node %d, bound to 16 CPUs", device, device / 4);
     }
     return MI_OK;
+}
+
+inline mi_status mi_host_register(void* ptr, size_t bytes)
+{
+    auto& w = stub::world();
+    std::lock_guard<std::mutex> lk(w.mu);
+    if (!ptr || !bytes || w.registered.count(ptr)) return MI_ERR_BAD_ARG;
+    if (w.devices <= 0) return MI_ERR_NO_DEVICE;
+    w.registered[ptr] = bytes;
+    return MI_OK;
+}
+
+inline mi_status mi_host_unregister(void* ptr)
+{
+    auto& w = stub::world();
+    std::lock_guard<std::mutex> lk(w.mu);
+    return w.registered.erase(ptr) ? MI_OK : MI_ERR_BAD_ARG;
 }
 
 inline mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
