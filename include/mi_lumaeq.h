@@ -198,8 +198,9 @@ mi_status mi_analyze_diff_u8_batch_dev(mi_ctx* ctx, const void* d_a, size_t a_st
  * a single table; wider content is walked in windows of the value range.
  * Speed (never bytes) also depends on the context's HISTORY: tiles that could go with several shifts -- a flat letterbox bar of a
  * P010 frame -- take the shift the frames of the context's PREVIOUS call settled on (a video stream keeps its format), so the first
- * call after a change of sample format may run its frames through the slower per-frame LUT pass once.  Every tile of a call
- * sees the same hint: it is read-only while the call's tile kernels run and rolled over by the call's last kernel. */
+ * call after a change of sample format may run its frames through the slower per-frame LUT pass once.  Every tile of one
+ * LAUNCH sees the same hint (a call on many frames is cut into chunks, one launch sequence per chunk): it is read-only while the
+ * chunk's tile kernels run and rolled over by the chunk's first interpolation launch.  The hint affects speed only, never bytes. */
 mi_status mi_clahe_u16(mi_ctx* ctx, const uint16_t* src, size_t src_step, uint16_t* dst, size_t dst_step,
                        int width, int height, double clip_limit, int tiles_x, int tiles_y);
 mi_status mi_clahe_u16_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step, size_t src_frame_stride,
@@ -217,6 +218,9 @@ mi_status mi_clahe_u16_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step
  * (between the mi_pipe_submit that took the frame and the mi_pipe_wait that returns it, or the pipe's destruction): unpinning
  * pages under the copy engine is a GPU access to an ordinary heap address, which ends the process.  The reference's accelerator
  * path has the same window and no guard (OpenCLequalHist.cpp:356-367).  MI_ERR_BAD_ARG: `ptr` is not the start of a registered range.
+ * MI_ERR_HIP: the runtime refused to unpin; the buffer is STILL registered (and still pinned) -- ask again, do not free it yet.
+ * mi_host_unregister may wait for the device; it does not hold up other threads' mi_pipe_submit / host-form calls meanwhile (the
+ * range being unpinned is simply not treated as pinned any more).  A second thread unregistering the same buffer at that moment gets BUSY.
  * Memory the caller pinned by other means (hipHostMalloc, hipHostRegister) is recognised as pinned when the whole plane lies in ONE
  * such allocation; releasing it while frames are pending is the caller's responsibility. */
 mi_status mi_host_register(void* ptr, size_t bytes);
@@ -248,7 +252,15 @@ mi_status mi_host_unregister(void* ptr);
  * be used while no frame is pending and answer MI_ERR_BUSY otherwise.
  * Errors keep caller and pipe in step: a failed mi_pipe_submit occupies no slot and leaves no copy in flight on in / out;
  * a failed mi_pipe_wait has still retired the oldest frame (its tag is returned, its buffers are idle) -- one mi_pipe_wait
- * call, one frame gone, whatever the status. */
+ * call, one frame gone, whatever the status.
+ * mi_pipe_destroy with frames still pending (submitted, never waited for): the pipe's streams are drained first, so on return NO
+ * transfer touches any `in` / `out` buffer any more and registered buffers may be unregistered -- but the CONTENT of those frames'
+ * `out` buffers is UNDEFINED: the work mi_pipe_wait does for a frame never happened.  Concretely: under MI_PIPE_UV_HOST the UV half
+ * was not written (stale bytes), a registered `out` may or may not hold the finished Y plane, an unpinned `out` received nothing
+ * (its result sits in staging that is freed).  Ownership follows the reference's rule for a buffer that was pushed and then dropped
+ * (OpenCVequalHist.cpp:183-187: ownership passes on push, a failed push is unref'd, never read): discard such outputs.  A caller
+ * that wants every frame calls mi_pipe_wait until mi_pipe_pending() is 0 before destroying the pipe; micv::FramePool::finish()
+ * and nv12_stream do exactly that and never rely on destroy to complete a frame. */
 typedef struct mi_pipe mi_pipe;
 enum { MI_OP_EQUALIZE = 0, MI_OP_CLAHE = 1, MI_OP_CHANNELS = 2 };
 enum { MI_PIPE_UV_AUTO = 0, MI_PIPE_UV_HOST = 1, MI_PIPE_UV_DEVICE = 2 };

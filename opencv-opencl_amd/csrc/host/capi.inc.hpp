@@ -233,26 +233,25 @@ mi_status mi_host_register(void* ptr, size_t bytes)
     if (mi_device_count() <= 0) return MI_ERR_NO_DEVICE;
     const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
     if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP; }
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    g_pinned.push_back({(uintptr_t)ptr, (uintptr_t)ptr + bytes});
-    g_pin_generation.fetch_add(1, std::memory_order_relaxed);
+    g_pins.add(ptr, bytes);
     return MI_OK;
 }
 
 mi_status mi_host_unregister(void* ptr)
 {
     if (!ptr) return MI_ERR_BAD_ARG;
-    // one critical section from the pending-DMA check to the end of hipHostUnregister (host_range_pinned judges under the same lock)
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    auto it = std::find_if(g_pinned.begin(), g_pinned.end(), [&](const PinnedRange& r) { return r.lo == (uintptr_t)ptr; });
-    if (it == g_pinned.end()) return MI_ERR_BAD_ARG;
-    // a pipe still has a transfer queued on this buffer (submitted, not yet retired by mi_pipe_wait): unpinning it now would leave the
-    // copy engine with an ordinary heap address.  The caller waits for its frames (or destroys the pipe) and asks again.
-    if (g_pending_dma.overlaps(it->lo, it->hi)) return MI_ERR_BUSY;
-    g_pinned.erase(it);
-    g_pin_generation.fetch_add(1, std::memory_order_relaxed);
-    if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return MI_ERR_HIP; }
-    return MI_OK;
+    // hipHostUnregister may wait for the device: the registry calls it WITHOUT its lock (the range sits on the "being unpinned" list
+    // meanwhile, so nobody judges it pinned), and keeps the range registered when the runtime refuses -- the caller can ask again.
+    switch (g_pins.remove(ptr, g_pending_dma, [](void* q) {
+                if (hipHostUnregister(q) == hipSuccess) return true;
+                (void)hipGetLastError();
+                return false;
+            })) {
+        case mi_host::PinRegistry::REMOVED: return MI_OK;
+        case mi_host::PinRegistry::NOT_REGISTERED: return MI_ERR_BAD_ARG;
+        case mi_host::PinRegistry::BUSY: return MI_ERR_BUSY;
+        default: return MI_ERR_HIP;
+    }
 }
 
 // Options: include/mi_lumaeq.h documents the ones that change behaviour, include/mi_lumaeq_tuning.h the speed-only ones; the

@@ -7,46 +7,18 @@ struct PendingEvent { hipEvent_t a, b; int kernel; };
 
 }  // namespace
 
-// process-wide registry of caller-pinned host ranges (mi_host_register)
-struct PinnedRange { uintptr_t lo, hi; };
-static std::mutex g_pin_mu;
-static std::vector<PinnedRange> g_pinned;
-static std::atomic<uint64_t> g_pin_generation{1};                // bumped by mi_host_register / mi_host_unregister
+// process-wide registry of caller-pinned host ranges (mi_host_register): host/pin_registry.hpp holds the rules and the locking
+static mi_host::PinRegistry g_pins;
 // caller memory that a pipe's queued DMA still reads or writes (pending_ranges.hpp): mi_host_unregister answers MI_ERR_BUSY for it
 static mi_host::PendingRanges g_pending_dma;
+using PinnedNegCache = mi_host::PinnedNegCache;
 
-// Per-context memory of ranges the runtime was asked about and did NOT know as pinned.  Only the negative verdict is remembered:
-// "not pinned" is always safe (the plane is packed through the library's own staging), while a remembered "pinned" could outlive
-// the caller's hipHostUnregister and hand the runtime pageable memory.  Entries expire with every (un)registration and after
-// kNegLife look-ups, so memory the caller pins later on is noticed again.
-struct PinnedNegCache {
-    static constexpr int kSlots = 8;
-    static constexpr uint32_t kNegLife = 4096;
-    struct Entry { uintptr_t lo = 0; size_t bytes = 0; uint32_t left = 0; } e[kSlots];
-    uint64_t generation = 0;
-    int next = 0;
-    bool hit(uintptr_t lo, size_t bytes)
-    {
-        const uint64_t g = g_pin_generation.load(std::memory_order_relaxed);
-        if (g != generation) { for (auto& x : e) x.left = 0; generation = g; return false; }
-        for (auto& x : e) if (x.left && x.lo == lo && x.bytes == bytes) { --x.left; return true; }
-        return false;
-    }
-    void remember(uintptr_t lo, size_t bytes) { e[next] = Entry{lo, bytes, kNegLife}; next = (next + 1) % kSlots; }
-};
-
-static bool host_range_pinned(const void* p, size_t bytes, PinnedNegCache* neg = nullptr)
+// What the HIP runtime says about memory the caller pinned itself (hipHostMalloc / hipHostRegister, a pinned torch tensor): both ends
+// of the range are host-pinned AND lie in ONE allocation.  Called by the registry WITHOUT its lock.
+static bool runtime_says_pinned(const void* p, size_t bytes)
 {
-    if (!p || bytes == 0) return false;
-    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
-    // the whole verdict under the registry's lock: mi_host_unregister holds it from its pending-DMA check to the end of
-    // hipHostUnregister, so a range is never judged "pinned" while it is being unpinned
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    for (const auto& r : g_pinned) if (lo >= r.lo && hi <= r.hi) return true;
-    if (neg && neg->hit(lo, bytes)) return false;
-    // not registered through mi_host_register: memory the caller pinned itself (hipHostMalloc / hipHostRegister, a pinned torch
-    // tensor) is recognised by asking the runtime about both ends of the range.  An unknown pointer is not an error worth keeping:
-    // only the error THIS query raised is cleared (a pending error of an earlier asynchronous call is left for its own check).
+    // An unknown pointer is not an error worth keeping: only the error THIS query raised is cleared (a pending error of an earlier
+    // asynchronous call is left for its own check).
     auto quiet = [](hipError_t before, hipError_t e) { if (e != hipSuccess && before == hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
     auto pinned_at = [&](const void* q) {
         hipPointerAttribute_t at{};
@@ -60,14 +32,15 @@ static bool host_range_pinned(const void* p, size_t bytes, PinnedNegCache* neg =
         const hipError_t before = hipPeekAtLastError();
         return quiet(before, hipMemGetAddressRange((hipDeviceptr_t*)base, size, (hipDeviceptr_t)const_cast<void*>(q)));
     };
-    bool pinned = pinned_at(p) && pinned_at((const uint8_t*)p + bytes - 1);
-    if (pinned) {
-        void *b0 = nullptr, *b1 = nullptr;
-        size_t s0 = 0, s1 = 0;
-        pinned = allocation_of(p, &b0, &s0) && allocation_of((const uint8_t*)p + bytes - 1, &b1, &s1) && b0 == b1 && s0 == s1 && s0 >= bytes;
-    }
-    if (!pinned && neg) neg->remember(lo, bytes);
-    return pinned;
+    if (!(pinned_at(p) && pinned_at((const uint8_t*)p + bytes - 1))) return false;
+    void *b0 = nullptr, *b1 = nullptr;
+    size_t s0 = 0, s1 = 0;
+    return allocation_of(p, &b0, &s0) && allocation_of((const uint8_t*)p + bytes - 1, &b1, &s1) && b0 == b1 && s0 == s1 && s0 >= bytes;
+}
+
+static bool host_range_pinned(const void* p, size_t bytes, PinnedNegCache* neg = nullptr)
+{
+    return g_pins.pinned(p, bytes, neg, runtime_says_pinned);
 }
 
 // Concurrency guard for the fused kernel.  Its workgroups wait for each other, so every slice of a frame (T

@@ -177,11 +177,17 @@ mi_status mi_pipe_create(mi_ctx* c, const mi_pipe_config* cfg, mi_pipe** out)
     auto bail = [&](mi_status st) { pipe_free(p); return st; };
     if (c->device >= kMaxDevices) { fail(c, MI_ERR_UNSUPPORTED, "pipe: device index too large"); return bail(MI_ERR_UNSUPPORTED); }
     p->private_streams = c->pipe_private_streams != 0;
-    if (const char* e = getenv("MI_LUMAEQ_PIPE_WAIT")) p->wait_mode = !strcmp(e, "sync") ? 1 : (!strcmp(e, "spin") ? 2 : 0);
+    const char* wait_env = getenv("MI_LUMAEQ_PIPE_WAIT");
+    if (wait_env) p->wait_mode = !strcmp(wait_env, "sync") ? 1 : (!strcmp(wait_env, "spin") ? 2 : 0);
     if (getenv("MI_LUMAEQ_PIPE_WAIT_SYNC")) p->wait_mode = 1;     // (round-3 spelling)
-    // frames below 8 MiB (1080p: ~58 us per frame, 720p: ~43 us) are polled without sleeping: one sleep is ~55 us with the kernel's
-    // default timer slack -- a whole frame -- and cost 4-5 % of the throughput for 0.1-0.3 of a core (profiles/r04_z_*)
-    p->wait_spin_us = p->ybytes + p->uvbytes >= ((size_t)8 << 20) ? 0 : 1000000;
+    // frames below 8 MiB (1080p: ~58 us per frame, 720p: ~43 us) are polled for a few frame times before the first sleep: one sleep is
+    // ~55 us with the kernel's default timer slack -- a whole frame -- and cost 4-5 % of the throughput for 0.1-0.3 of a core
+    // (profiles/r04_z_*).  The poll is BOUNDED (kSmallFrameSpinUs, about five 1080p frames): a wait that lasts longer is a stalled or
+    // shared GPU, and from then on the thread sleeps between polls like a 4K worker instead of keeping a core busy for as long as the
+    // stall lasts (round 4 polled for up to a second: ADVICE r4).  MI_LUMAEQ_PIPE_WAIT=backoff sleeps from the first poll at any size.
+    constexpr int kSmallFrameSpinUs = 300;
+    p->wait_spin_us = p->ybytes + p->uvbytes >= ((size_t)8 << 20) ? 0 : kSmallFrameSpinUs;
+    if (wait_env && !strcmp(wait_env, "backoff")) p->wait_spin_us = 0;
     if (const char* e = getenv("MI_LUMAEQ_PIPE_WAIT_SPIN_US")) p->wait_spin_us = std::max(0, std::min(1000000, atoi(e)));
     if (p->private_streams) {
         PipeStreams own;

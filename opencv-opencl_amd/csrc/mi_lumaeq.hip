@@ -24,6 +24,7 @@
 #include "host/drain_guard.hpp"           // stand-alone helpers (CPU-testable: tests/cxx/test_host_helpers.cpp)
 #include "host/copy_crew.hpp"
 #include "host/pending_ranges.hpp"
+#include "host/pin_registry.hpp"
 #include "host/numa_affinity.hpp"
 
 using namespace mi;

@@ -4,6 +4,7 @@
 //   host/copy_crew.hpp    the calling thread + one helper copying a plane into / out of pinned staging
 //   host/numa_affinity.hpp  GPU PCI address -> NUMA node -> CPU list -> thread affinity, against a FAKE sysfs tree
 //   host/pending_ranges.hpp  caller memory a pipe's queued DMA still owns: what mi_host_unregister consults before it unpins
+//   host/pin_registry.hpp  which caller memory may be DMA'd as it is; an unregister that waits for the device must not stall judges
 // No GPU, no HIP: both headers are written against injected / standard facilities so that their exit paths can be checked here.
 #include <algorithm>
 #include <cstdio>
@@ -16,6 +17,7 @@
 #include "../../opencv-opencl_amd/csrc/host/drain_guard.hpp"
 #include "../../opencv-opencl_amd/csrc/host/numa_affinity.hpp"
 #include "../../opencv-opencl_amd/csrc/host/pending_ranges.hpp"
+#include "../../opencv-opencl_amd/csrc/host/pin_registry.hpp"
 
 #include <thread>
 
@@ -316,8 +318,116 @@ static void test_pending_ranges()
     (void)seen;
 }
 
+// ---- pin registry ---------------------------------------------------------------------------------------------------
+// The runtime is two callables here: `ask` (what hipPointerGetAttributes + hipMemGetAddressRange would say) and `unpin`
+// (hipHostUnregister, which may wait for the device).
+static void test_pin_registry()
+{
+    using mi_host::PinRegistry;
+    PinRegistry reg;
+    mi_host::PendingRanges pending;
+    mi_host::PinnedNegCache neg;
+    std::vector<unsigned char> a(4096), b(4096), c(4096);
+    std::atomic<int> asked{0};
+    std::atomic<bool> runtime_knows_c{false};
+    auto ask = [&](const void* p, size_t) { ++asked; return runtime_knows_c.load() && p >= c.data() && p < c.data() + c.size(); };
+    auto unpin_ok = [](void*) { return true; };
+
+    // registered ranges are pinned without asking the runtime; sub-ranges too; a range that sticks out is not
+    reg.add(a.data(), a.size());
+    CHECK(reg.pinned(a.data(), a.size(), &neg, ask) && reg.pinned(a.data() + 100, 1000, &neg, ask) && asked == 0);
+    CHECK(!reg.pinned(a.data() + 100, a.size(), &neg, ask) && asked == 1);
+    CHECK(!reg.pinned(nullptr, 10, &neg, ask) && !reg.pinned(a.data(), 0, &neg, ask));
+    // unknown memory: the runtime is asked once, the negative verdict is remembered (per context) until something is (un)registered
+    CHECK(!reg.pinned(b.data(), b.size(), &neg, ask) && asked == 2);
+    CHECK(!reg.pinned(b.data(), b.size(), &neg, ask) && asked == 2);
+    reg.add(b.data(), 16);                                   // generation moves: remembered verdicts are dropped
+    CHECK(!reg.pinned(b.data(), b.size(), &neg, ask) && asked == 3);
+    // memory the caller pinned itself: the runtime's word counts, and is never cached
+    runtime_knows_c = true;
+    CHECK(reg.pinned(c.data(), c.size(), &neg, ask) && reg.pinned(c.data(), c.size(), &neg, ask) && asked == 5);
+    // removal: unknown pointer, interior pointer, pending DMA, success
+    CHECK(reg.remove(c.data(), pending, unpin_ok) == PinRegistry::NOT_REGISTERED);
+    CHECK(reg.remove(a.data() + 1, pending, unpin_ok) == PinRegistry::NOT_REGISTERED);
+    int owner = 0;
+    pending.add(&owner, 7, a.data() + 512, 64);
+    CHECK(reg.remove(a.data(), pending, unpin_ok) == PinRegistry::BUSY && reg.pinned(a.data(), a.size(), &neg, ask));
+    pending.retire(&owner, 7);
+    // the runtime refuses: the range STAYS registered and can be removed later (it used to be forgotten: ADVICE r4)
+    CHECK(reg.remove(a.data(), pending, [](void*) { return false; }) == PinRegistry::RUNTIME_REFUSED);
+    CHECK(reg.pinned(a.data(), a.size(), &neg, ask) && reg.size() == 2);
+    CHECK(reg.remove(a.data(), pending, unpin_ok) == PinRegistry::REMOVED && reg.size() == 1);
+    runtime_knows_c = false;
+    CHECK(!reg.pinned(a.data(), a.size(), &neg, ask));
+    CHECK(reg.remove(a.data(), pending, unpin_ok) == PinRegistry::NOT_REGISTERED);
+
+    // an unregister that waits for the device (unpin sleeps 300 ms) must not stall anybody who judges a range meanwhile, the range
+    // being unpinned must not be judged pinned in that window -- not even if the runtime still says so -- and a second remover of
+    // the same pointer is told BUSY
+    reg.add(a.data(), a.size());
+    std::atomic<bool> in_unpin{false}, release{false};
+    std::thread remover([&] {
+        CHECK(reg.remove(a.data(), pending, [&](void*) {
+            in_unpin = true;
+            while (!release) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            return true;
+        }) == PinRegistry::REMOVED);
+    });
+    while (!in_unpin) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    const auto t0 = std::chrono::steady_clock::now();
+    mi_host::PinnedNegCache neg2;
+    bool any_pinned = false;
+    for (int k = 0; k < 1000; ++k) {
+        any_pinned = any_pinned || reg.pinned(a.data(), a.size(), &neg2, [](const void*, size_t) { return true; });    // "still pinned" says the runtime
+        any_pinned = any_pinned || reg.pinned(a.data() + 64, 128, nullptr, [](const void*, size_t) { return true; });
+    }
+    CHECK(reg.pinned(b.data(), 16, &neg2, ask));             // other registered ranges are judged as ever
+    CHECK(reg.remove(a.data(), pending, unpin_ok) == PinRegistry::BUSY);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(!any_pinned);
+    CHECK(ms < 250.0);                                       // 2000 verdicts while the unpin call is stuck: nobody waited for it
+    release = true;
+    remover.join();
+    CHECK(!reg.pinned(a.data(), a.size(), &neg2, ask));
+
+    // a runtime answer that straddles an (un)registration is not trusted: the plane is staged this once
+    {
+        const uint64_t g = reg.generation();
+        const bool verdict = reg.pinned(c.data(), c.size(), nullptr, [&](const void*, size_t) { reg.add(c.data() + 8, 8); return true; });
+        CHECK(!verdict && reg.generation() == g + 1);
+        CHECK(reg.pinned(c.data(), c.size(), nullptr, [](const void*, size_t) { return true; }));           // quiet again: trusted
+        CHECK(reg.remove(c.data() + 8, pending, unpin_ok) == PinRegistry::REMOVED);
+    }
+
+    // hammer: judges, registrations and removals of disjoint and shared ranges from several threads (meant for ThreadSanitizer)
+    {
+        std::vector<std::vector<unsigned char>> bufs(8, std::vector<unsigned char>(1024));
+        std::atomic<bool> stop{false};
+        std::atomic<long> verdicts{0};
+        std::vector<std::thread> ts;
+        for (int t = 0; t < 3; ++t)
+            ts.emplace_back([&, t] {
+                mi_host::PinnedNegCache n;
+                while (!stop) {
+                    for (auto& v : bufs) verdicts += reg.pinned(v.data(), v.size(), &n, [](const void*, size_t) { return false; });
+                    (void)t;
+                }
+            });
+        for (int round = 0; round < 200; ++round)
+            for (auto& v : bufs) {
+                reg.add(v.data(), v.size());
+                CHECK(reg.remove(v.data(), pending, [](void*) { std::this_thread::yield(); return true; }) == PinRegistry::REMOVED);
+            }
+        stop = true;
+        for (auto& t : ts) t.join();
+        CHECK(reg.size() == 1);                              // b's 16 bytes from above
+        CHECK(reg.remove(b.data(), pending, unpin_ok) == PinRegistry::REMOVED && reg.size() == 0);
+    }
+}
+
 int main()
 {
+    test_pin_registry();
     test_drain_guard();
     test_pending_ranges();
     test_copy_crew();

@@ -295,6 +295,44 @@ def test_clahe_kats(ctx):
     assert (o[a == 1] == 126).all() and (o[a == 2] == 255).all()
 
 
+def test_derived_kats_one_per_quirk(ctx):
+    """The round-5 known answers (kat.json "derived": one per quirk of SURVEY App. A, answers derived in exact arithmetic by
+    tests/golden/derive_kats.py, each killing a named mutant in tests/test_kat_kill_matrix.py) through the HIP kernels: host form and
+    a device-resident NV12-style batch of the same plane.  With clahe_fp_contract = 1 (GCC's FMA contraction, an OPTION) the two
+    FMA known answers must FAIL -- the kernels' default arithmetic is the uncontracted one."""
+    import json
+    from pathlib import Path
+    kats = json.loads((Path(__file__).parent / "golden" / "kat.json").read_text())["derived"]
+    assert len(kats) >= 15
+    for k in kats:
+        h, w = k["shape"]
+        src = np.array(k["src"], np.uint8).reshape(h, w)
+        want = np.array(k["dst"], np.uint8).reshape(h, w)
+        got = ctx.equalize_hist(src) if k["op"] == "equalize" else ctx.clahe(src, k["clip"], *k["tiles"])
+        assert np.array_equal(got, want), (k["id"], got.reshape(-1).tolist(), k["dst"])
+        # the batched device form: three copies of the plane, every one must come out the same
+        d_in = dev(np.stack([src] * 3))
+        d_out = torch.zeros_like(d_in)
+        if k["op"] == "equalize":
+            ctx.equalize_hist_batch_dev(d_in, d_out, w, h, 3)
+        else:
+            ctx.clahe_batch_dev(d_in, d_out, w, h, 3, k["clip"], *k["tiles"])
+        torch.cuda.synchronize()
+        assert all(np.array_equal(o, want) for o in host(d_out)), k["id"]
+    ctx.set_option("clahe_fp_contract", 1)
+    try:
+        flipped = []
+        for k in kats:
+            if k["op"] == "clahe":
+                h, w = k["shape"]
+                src = np.array(k["src"], np.uint8).reshape(h, w)
+                if ctx.clahe(src, k["clip"], *k["tiles"]).reshape(-1).tolist() != k["dst"]:
+                    flipped.append(k["guards"][0])
+        assert "cl_blend_fma" in flipped and "cl_coord_fma" in flipped, flipped
+    finally:
+        ctx.set_option("clahe_fp_contract", 0)
+
+
 def test_clahe_tile_luts_stage(ctx):
     for (w, h, tx, ty, clip) in [(640, 360, 8, 8, 2.0), (16, 15, 8, 8, 2.0), (241, 135, 4, 4, 3.0), (1919, 1079, 4, 4, 3.0)]:
         src = synth.y_plane(w, h, "D2", 50)

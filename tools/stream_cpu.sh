@@ -25,6 +25,12 @@ done
 run --width 3840 --height 2160 --frames 600 --workers 1 --paced --fps 60 --no-pin
 run --width 3840 --height 2160 --frames 2000 --workers 1 --no-pin
 run --width 3840 --height 2160 --frames 2000 --workers 2 --no-pin
+# 1080p: the default (300 us of polling, then sleeps), sleeping from the first poll, and never sleeping
 run --width 1920 --height 1080 --frames 6000 --workers 1
+MI_LUMAEQ_PIPE_WAIT=backoff run --width 1920 --height 1080 --frames 6000 --workers 1
+MI_LUMAEQ_PIPE_WAIT=spin run --width 1920 --height 1080 --frames 6000 --workers 1
+MI_LUMAEQ_PIPE_WAIT_SPIN_US=1000000 run --width 1920 --height 1080 --frames 6000 --workers 1
+run --width 1280 --height 720 --frames 8000 --workers 1
+MI_LUMAEQ_PIPE_WAIT_SPIN_US=1000000 run --width 1280 --height 720 --frames 8000 --workers 1
 run --width 3840 --height 2160 --frames 600 --workers 1 --paced --fps 60 --op clahe
 cat "$OUT"
