@@ -272,6 +272,8 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "fused_demote_after")) { if (value < 0 || value > 32) return fail(c, MI_ERR_BAD_ARG, "fused_demote_after must be 0..32"); c->fused_demote_after = value; return MI_OK; }
     if (!strcmp(name, "fused_reprobe_ms")) { c->fused_reprobe_ms = c->fused_reprobe_ms_now = std::max(1, value); return MI_OK; }
     if (!strcmp(name, "clahe_fp_contract")) { c->clahe_fp_contract = value != 0; return MI_OK; }
+    if (!strcmp(name, "clahe_single_read")) { c->clahe_single_read = value; return MI_OK; }
+    if (!strcmp(name, "clahe_cell_variant")) { c->clahe_cell_variant = value; return MI_OK; }
     // ---- speed only (mi_lumaeq_tuning.h)
     if (!strcmp(name, "two_kernel_max_frames")) { if (value < 0 || value > 64) return fail(c, MI_ERR_BAD_ARG, "two_kernel_max_frames must be 0..64"); c->two_kernel_max_frames = value; return MI_OK; }
     if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }

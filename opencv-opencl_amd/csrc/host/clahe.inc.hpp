@@ -148,12 +148,88 @@ mi_status launch_interp(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const Clah
     return MI_OK;
 }
 
+// ---- single-read CLAHE by cells (kernels/clahe_cell.hip.h, docs/experiments.md R5.4) ------------------------------------------
+// The cell kernel only runs on REGULAR geometries: no padding, tile_w a multiple of 32, planes and pitches on 16-byte boundaries, and
+// the band / pair boundaries -- decided by the reference's own float expressions, evaluated here exactly as the kernels evaluate them
+// (this file is built with -ffp-contract=off) -- at the same offset inside every tile: columns at tile_w / 2, rows at `ysplit`.
+static inline int host_tile_index(int p, float inv, int contract)
+{
+    const float v = contract ? fmaf((float)p, inv, -0.5f) : (float)p * inv - 0.5f;
+    const int i = (int)v;
+    return i - ((float)i > v);                                   // cvFloor
+}
+
+bool clahe_cell_geometry(const mi_ctx* c, const PlaneArgs& a, const ClaheGeom& g, CellGeom* cg)
+{
+    if (a.width % g.tiles_x != 0 || a.height % g.tiles_y != 0) return false;               // padded: reflection inside the histogram pass
+    if (g.tile_w % 32 != 0 || g.tiles_x > 64 || g.tiles_y > 64) return false;
+    if (((uintptr_t)a.src | (uintptr_t)a.dst | a.src_step | a.dst_step | a.src_frame | a.dst_frame) & 15) return false;
+    const int cw = g.tile_w / 2;
+    cg->cells_x = 2 * g.tiles_x; cg->cells_y = 2 * g.tiles_y;
+    cg->groups = cw / 16;
+    if (cg->groups < 1 || cg->groups > kThreads) return false;
+    cg->phases = kThreads / cg->groups;
+    for (int tx = 0; tx < g.tiles_x; ++tx) {                     // columns [tx*tw, tx*tw + cw) -> pair tx, the rest -> pair tx + 1
+        const int x = tx * g.tile_w;
+        if (host_tile_index(x, g.inv_tw, g.contract) != tx - 1 || host_tile_index(x + cw - 1, g.inv_tw, g.contract) != tx - 1 ||
+            host_tile_index(x + cw, g.inv_tw, g.contract) != tx || host_tile_index(x + g.tile_w - 1, g.inv_tw, g.contract) != tx) return false;
+    }
+    int ys = 0;
+    while (ys < g.tile_h && host_tile_index(ys, g.inv_th, g.contract) < 0) ++ys;
+    if (ys <= 0 || ys >= g.tile_h) return false;
+    for (int ty = 0; ty < g.tiles_y; ++ty) {                     // rows [ty*th, ty*th + ys) -> band ty, the rest -> band ty + 1
+        const int y = ty * g.tile_h;
+        if (host_tile_index(y, g.inv_th, g.contract) != ty - 1 || host_tile_index(y + ys - 1, g.inv_th, g.contract) != ty - 1 ||
+            host_tile_index(y + ys, g.inv_th, g.contract) != ty || host_tile_index(y + g.tile_h - 1, g.inv_th, g.contract) != ty) return false;
+    }
+    cg->ysplit = ys;
+    cg->variant = c->clahe_cell_variant;
+    if (std::max(ys, g.tile_h - ys) > cg->phases * kCellVPT) return false;                  // a lane keeps kCellVPT rows
+    if ((long long)(std::max(ys, g.tile_h - ys) - 1) * (long long)std::max(a.src_step, a.dst_step) + cw > 0x3fffffffLL) return false;
+    if ((long long)cg->cells_x * cg->cells_y > 0x7fffffffLL) return false;
+    (void)c;
+    return true;
+}
+
+mi_status launch_cells(mi_ctx* c, hipStream_t s, const PlaneArgs& a, const ClaheGeom& g, const CellGeom& cg, int f0, int nf,
+                       const uint8_t* d_luts, const UVJob* uv_all)
+{
+    PlaneBatch p;
+    p.src = a.src + (size_t)f0 * a.src_frame; p.dst = a.dst + (size_t)f0 * a.dst_frame;
+    p.src_step = (long long)a.src_step; p.dst_step = (long long)a.dst_step;
+    p.src_frame = (long long)a.src_frame; p.dst_frame = (long long)a.dst_frame;
+    p.row_bytes = a.width; p.rows = a.height;
+    UVJob uv{};
+    if (uv_all && uv_all->bytes > 0) {
+        uv = *uv_all;
+        uv.src = uv_all->src ? uv_all->src + (long long)f0 * uv_all->src_frame : nullptr;
+        uv.dst = uv_all->dst + (long long)f0 * uv_all->dst_frame;
+    }
+    const int cells = cg.cells_x * cg.cells_y;
+    mi_status st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)nf * cells * 256 * sizeof(uint32_t));
+    if (st) return st;
+    if (g.contract) LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_cell_kernel<true>, dim3(cells, nf), dim3(kThreads), 0, p, g, cg, d_luts, c->d_partial, uv);
+    else            LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_cell_kernel<false>, dim3(cells, nf), dim3(kThreads), 0, p, g, cg, d_luts, c->d_partial, uv);
+    return MI_OK;
+}
+
 mi_status clahe_dev(mi_ctx* c, hipStream_t s, const PlaneArgs& a, double clip_limit, int tiles_x, int tiles_y, const UVJob* uv)
 {
     ClaheGeom g;
     mi_status st = clahe_geometry(c, a.width, a.height, clip_limit, tiles_x, tiles_y, &g);
     if (st) return st;
     const int tiles = tiles_x * tiles_y;
+    CellGeom cg{};
+    if (c->clahe_single_read && a.n_frames <= kMaxGridY && clahe_cell_geometry(c, a, g, &cg)) {
+        // stage 1 (R5.4): the tile LUTs still come from the tile-histogram pass; the cell kernel does a fused kernel's per-workgroup work
+        st = grow_dev(c, &c->d_partial, &c->partial_bytes, (size_t)a.n_frames * cg.cells_x * cg.cells_y * 256 * sizeof(uint32_t));   // before the LUT pass: no reallocation between the two launches
+        if (st) return st;
+        st = grow_dev(c, &c->d_luts, &c->luts_bytes, (size_t)a.n_frames * tiles * 256);
+        if (st) return st;
+        st = launch_tile_luts(c, s, a, g, 0, a.n_frames, c->d_luts);
+        if (st) return st;
+        return launch_cells(c, s, a, g, cg, 0, a.n_frames, c->d_luts, uv);
+    }
     const int chunk = std::min(kMaxGridY, 65535);
     for (int f0 = 0; f0 < a.n_frames; f0 += chunk) {
         const int nf = std::min(chunk, a.n_frames - f0);

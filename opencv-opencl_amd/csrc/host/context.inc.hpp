@@ -138,6 +138,8 @@ struct mi_ctx {
     int clahe_seg_pairs = 9;                                     // option "clahe_seg_pairs": pairs per float table when a wide grid is cut into column segments (4..15)
     int clahe_xcd_map = 1;                                       // option "clahe_xcd_map": XCD-aware tile order of the tile histogram pass
     int clahe_float_tables = 1;                                  // option "clahe_float_tables": f32 pair tables in LDS (tiles_x <= 14)
+    int clahe_cell_variant = 0;                                  // stage-1 ablations of the cell kernel (measurement only)
+    int clahe_single_read = 0;                                   // option "clahe_single_read": cell kernel (kernels/clahe_cell.hip.h) where the geometry is regular
     uint8_t*  d_stage_in = nullptr;  size_t stage_in_bytes = 0;  // device frame for the host-pointer forms
     uint8_t*  d_stage_out = nullptr; size_t stage_out_bytes = 0;
     uint8_t*  d_c16 = nullptr;     size_t c16_bytes = 0;         // 16-bit CLAHE: tile histograms + ushort LUTs (N4)
