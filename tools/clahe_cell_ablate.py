@@ -7,8 +7,14 @@ a = mi_lumaeq.Context(0)
 w, h, B = 3840, 2160, 64
 d_in = synth.nv12_batch_torch(w, h, B, "D2", "cuda", seed=1)
 d_out = torch.empty_like(d_in)
-a.set_option("clahe_single_read", 1)
-names = {0: "full", 8: "full, XCD-aware", 7: "loads + stores only", 15: "loads + stores only, XCD-aware", 23: "loads only", 31: "loads only, XCD-aware",
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+a.set_option("clahe_single_read", mode)
+a.set_option("clahe_single_read_min_frames", 1)
+a.set_option("clahe_cell_wgs_per_cu", int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+if mode == 1:
+    names = {0: "fused, full hand-off", 64: "fused, LUTs from a tile-histogram pass (no waits; partials still published, tiles still computed)", 192: "fused, no hand-off at all"}
+else:
+  names = {0: "full", 8: "full, XCD-aware", 7: "loads + stores only", 15: "loads + stores only, XCD-aware", 23: "loads only", 31: "loads only, XCD-aware",
          39: "stores only", 47: "stores only, XCD-aware", 9: "no histogram, XCD-aware", 10: "no blend, XCD-aware"}
 res = {v: [] for v in names}
 for rnd in range(5):

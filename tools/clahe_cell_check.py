@@ -7,7 +7,8 @@ sys.path.insert(0, "opencv-opencl_amd/python"); sys.path.insert(0, ".")
 import mi_lumaeq, oracle
 from mi_lumaeq import synth, xfer
 ctx = mi_lumaeq.Context(0)
-ctx.set_option("clahe_single_read", 1)
+ctx.set_option("clahe_single_read", int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+ctx.set_option("clahe_single_read_min_frames", 1)
 bad = 0
 for (w, h, tx, ty, clip, B, uvm) in [(3840, 2160, 8, 8, 2.0, 5, 0), (3840, 2160, 8, 8, 40.0, 3, 1), (1920, 1080, 4, 4, 3.0, 6, 0), (1280, 720, 4, 4, 2.0, 4, 0),
                                      (3840, 2160, 4, 8, 2.0, 2, 0), (1920, 1080, 8, 8, 2.0, 3, 0), (640, 360, 2, 2, 0.0, 3, 1), (256, 64, 4, 4, 2.0, 7, 0)]:
@@ -29,4 +30,6 @@ for (w, h, tx, ty, clip, B, uvm) in [(3840, 2160, 8, 8, 2.0, 5, 0), (3840, 2160,
     ok = np.array_equal(xfer.to_host(d_io), out)
     bad += not ok
     print(f"    in place: {'same bytes' if ok else 'MISMATCH'}", flush=True)
+print({k: ctx.get_stat(k) for k in ("clahe_fused_fallbacks", "clahe_cells_repaired", "clahe_fused_last_status", "clahe_fused_demotions")})
+bad += ctx.get_stat("clahe_fused_fallbacks") != 0
 sys.exit(1 if bad else 0)
