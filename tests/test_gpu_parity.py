@@ -1629,84 +1629,6 @@ def test_clahe_tuning_options_do_not_change_bytes(ctx):
         ctx.set_option("clahe_hist_threads", 512)
 
 
-CELL_CASES = [
-    # (width, height, frames, (clip, tiles_x, tiles_y), uv_mode)         cell = tile quadrant; tile_w % 32 == 0, no padding
-    (3840, 2160, 6, (2.0, 8, 8), 0),            # BASELINE config 3: tiles 480 x 270, cells 240 x 135, 256 cells per frame
-    (3840, 2160, 4, (40.0, 8, 8), 1),           # clip limit that never clips, UV copied
-    (1920, 1080, 9, (3.0, 4, 4), 0),            # clahe1frame.cpp's defaults on a divisible frame: the same tile shape, 64 cells per frame
-    (1280, 720, 5, (2.0, 4, 4), 1),             # tiles 320 x 180: cells 160 x 90
-    (1920, 1088, 4, (2.0, 6, 8), 0),            # tiles 320 x 136; cells_y = 16, six tiles across: twelve cells per cell row
-    (640, 360, 7, (0.0, 2, 2), 1),              # no clipping at all; cells_y = 4 (dispensers 4..7 own nothing)
-    (256, 64, 11, (2.0, 4, 4), 0),              # tiny: cells 32 x 8, two column groups per cell
-    (768, 300, 5, (2.0, 4, 10), 0),             # tile_h = 30, cells_y = 20: a dispenser's third cell row exists for some and not for others
-]
-
-
-@pytest.mark.parametrize("case", CELL_CASES, ids=str)
-def test_clahe_single_read_cell_kernel(ctx, case):
-    """The fused single-read CLAHE (kernels/clahe_cell.hip.h: tile quadrants in registers, per-tile hand-off) against the oracle and
-    against the two-pass kernels on the same batch, out of place and IN PLACE, and the proof that it was the fused kernel that ran:
-    no tile-histogram launch, one finish kernel per call, no repaired launch.  Reference call: clahevideo.cpp:195, clahe1frame.cpp:92-95."""
-    w, h, n, cfg, uvm = case
-    frames = np.stack([synth.nv12_frame(w, h, synth.DISTS[k % 5], 5100 + k) for k in range(n)])
-    want = np.stack([oracle.nv12_frame(frames[k], w, h, uv_mode=uvm, op=1, clip_limit=cfg[0], tiles_x=cfg[1], tiles_y=cfg[2]) for k in range(n)])
-    d_in = dev(frames)
-    try:
-        ctx.set_option("clahe_single_read_min_frames", 1)
-        for mode in (1, 0, 1):
-            ctx.set_option("clahe_single_read", mode)
-            d_out = torch.zeros_like(d_in)
-            ctx.profile_read(reset=True)
-            ctx.set_profiling(True)
-            ctx.clahe_nv12_batch_dev(d_in, d_out, w, h, n, uvm, *cfg)
-            ctx.synchronize()
-            ctx.set_profiling(False)
-            ran = {k for k, v in ctx.profile_read(reset=True).items() if v["launches"]}
-            assert np.array_equal(host(d_out), want), (case, mode)
-            if mode == 1:
-                assert "tile_hist_kernel" not in ran and "fused_finish_kernel" in ran and "clahe_interp_kernel" in ran, ran
-            else:
-                assert "tile_hist_kernel" in ran and "fused_finish_kernel" not in ran, ran
-        d_io = d_in.clone()                                        # in place: a cell is overwritten only after its own tile's LUT is out
-        ctx.clahe_nv12_batch_dev(d_io, d_io, w, h, n, uvm, *cfg)
-        ctx.synchronize()
-        assert np.array_equal(host(d_io), want), case
-        # the Y planes alone, with a row pitch (ROI view of a wider buffer; pitch a multiple of 16 keeps the cell path)
-        pitch = w + 64
-        big = np.zeros((n, h, pitch), np.uint8)
-        big[:, :, :w] = frames[:, : w * h].reshape(n, h, w)
-        d_big = dev(big)
-        d_big_out = torch.zeros_like(d_big)
-        ctx.clahe_batch_dev(d_big, d_big_out, w, h, n, *cfg, src_step=pitch, src_frame=h * pitch, dst_step=pitch, dst_frame=h * pitch)
-        ctx.synchronize()
-        got = host(d_big_out)
-        assert np.array_equal(got[:, :, :w].reshape(n, -1), want[:, : w * h]) and not got[:, :, w:].any(), case
-        assert ctx.get_stat("clahe_fused_fallbacks") == 0 and ctx.get_stat("clahe_fused_demoted") == 0
-    finally:
-        ctx.set_option("clahe_single_read", 1)
-        ctx.set_option("clahe_single_read_min_frames", 4)
-
-
-def test_clahe_single_read_applies_only_to_regular_geometries(ctx):
-    """Padded frames, tiles whose half width is not a multiple of 16, misaligned pitches and small calls keep the two-pass kernels --
-    and give the oracle's bytes."""
-    for (w, h, n, cfg, why) in ((1919, 1079, 4, (3.0, 4, 4), "padded"), (1920, 1080, 5, (2.0, 8, 8), "tile_w / 2 = 120"),
-                                (3840, 2160, 2, (2.0, 8, 8), "two frames"), (3840, 2160, 4, (2.0, 4, 8), "270 rows per cell > 8 x 8 phases")):
-        ys = np.stack([synth.y_plane(w, h, "D2", 60 + k) for k in range(n)])
-        d_in, d_out = dev(ys), None
-        d_out = torch.zeros_like(d_in)
-        ctx.profile_read(reset=True)
-        ctx.set_profiling(True)
-        ctx.clahe_batch_dev(d_in, d_out, w, h, n, *cfg)
-        ctx.synchronize()
-        ctx.set_profiling(False)
-        ran = {k for k, v in ctx.profile_read(reset=True).items() if v["launches"]}
-        assert "tile_hist_kernel" in ran and "fused_finish_kernel" not in ran, (why, ran)
-        out = host(d_out)
-        for k in range(n):
-            assert np.array_equal(out[k], oracle.clahe(ys[k], *cfg)), (why, k)
-
-
 @pytest.mark.parametrize("case", [(640, 360, 96, (2.0, 8, 8), 0), (638, 358, 96, (3.0, 8, 8), 0), (320, 180, 200, (2.0, 6, 4), 0),
                                   (640, 360, 140, (2.0, 8, 8), 4), (640, 360, 300, (2.0, 8, 8), 8), (1280, 720, 70, (2.0, 8, 8), 2),
                                   (1920, 1080, 40, (2.0, 8, 8), 2)], ids=str)
