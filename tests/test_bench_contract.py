@@ -153,6 +153,33 @@ def test_bench_two_ranks_contract_on_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_under_torchrun_as_the_driver_launches_it():
+    """The driver does not use bench.py's own launcher for N > 1: it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (WORLD_SIZE set: every process is a rank).  Rehearsed here in exactly
+    that form with two ranks on the one GPU over gloo: torchrun's stdout must carry rank 0's JSON line and NOTHING else from any rank
+    (a rank writes the line through a private duplicate of fd 1 and points fd 1 at stderr), and the line must say two ranks."""
+    import json
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--all-ranks-on-device", "0",
+                        "--steps", "5", "--warmup", "2", "--cpu-seconds", "1.5", "--batch", "16"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), r.stdout[:1500]
+    d = json.loads(out_lines[0])
+    assert d["n_gpus"] == 2 and d["dist_backend_used"] == "gloo" and d["world_seen_by_backend"] == 2 and d["parity_spot_check"] is True
+    assert abs(d["value"] - 2 * 16 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 0.01
+    assert d["stream_4k60_512_all_gpus"]["ranks_ok"] == 2 and d["roofline"]["ranks"] == 2 and d["cpu_baseline"]["value"] > 0
+    for rank in (0, 1):
+        assert f"[bench hb] rank={rank} phase=done" in r.stderr
+
+
+@pytest.mark.gpu
 def test_bench_four_ranks_contract_on_gpu():
     """Four ranks rehearsed on ONE GPU over gloo, extras ON so that the all-ranks stream leg and its reductions run -- the code that
     only exists for world > 1 and that the driver's 4- and 8-GPU runs execute.  The job must end by itself with one line, every rank
