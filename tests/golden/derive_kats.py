@@ -179,3 +179,67 @@ if __name__ == "__main__":
         print(f"{k['id']}: {'matches kat.json' if flat == k['dst'] else 'DIFFERS FROM kat.json'}")
         for line in tr:
             print("    " + line)
+
+
+# ---- colour neighbours: plain integers, one pixel at a time, constants as oracle/color_oracle.c's header states them ----
+def _descale14(x: int) -> int:
+    return (x + (1 << 13)) >> 14                    # CV_DESCALE(x, 14); Python's >> floors like C's arithmetic shift
+
+
+def bgr2yuv_px(b: int, g: int, r: int):
+    """cv::cvtColor(COLOR_BGR2YUV) on one 8-bit pixel: RGB2YCrCb_i<uchar>, yuv order."""
+    y = _descale14(b * 1868 + g * 9617 + r * 4899)
+    u = _descale14((b - y) * 8061 + (128 << 14))
+    v = _descale14((r - y) * 14369 + (128 << 14))
+    return [sat_u8(y), sat_u8(u), sat_u8(v)]
+
+
+def yuv2bgr_px(y: int, u: int, v: int):
+    """cv::cvtColor(COLOR_YUV2BGR) on one 8-bit pixel: YCrCb2RGB_i<uchar>, yuv order."""
+    b = y + _descale14((u - 128) * 33292)
+    g = y + _descale14((u - 128) * -6472 + (v - 128) * -9519)
+    r = y + _descale14((v - 128) * 18678)
+    return [sat_u8(b), sat_u8(g), sat_u8(r)]
+
+
+def nv12_to_bgr(nv12, width: int, height: int):
+    """COLOR_YUV2BGR_NV12 (ITUR_BT_601_SHIFT = 20): the four pixels of a 2x2 block share one (U, V)."""
+    out = []
+    for yy in range(height):
+        for xx in range(width):
+            base = width * height + (yy // 2) * width + (xx & ~1)
+            u, v = nv12[base] - 128, nv12[base + 1] - 128
+            luma = max(0, nv12[yy * width + xx] - 16) * 1220542
+            out += [sat_u8((luma + (1 << 19) + 2116026 * u) >> 20),
+                    sat_u8((luma + (1 << 19) - 852492 * v - 409993 * u) >> 20),
+                    sat_u8((luma + (1 << 19) + 1673527 * v) >> 20)]
+    return out
+
+
+def bgr_to_nv12(bgr, width: int, height: int):
+    """COLOR_BGR2YUV_I420 arithmetic with U, V interleaved: luma of every pixel, chroma of the TOP-LEFT pixel of each 2x2 block."""
+    px = lambda yy, xx: bgr[3 * (yy * width + xx): 3 * (yy * width + xx) + 3]
+    ys, uv = [], []
+    for yy in range(height):
+        for xx in range(width):
+            b, g, r = px(yy, xx)
+            ys.append(sat_u8((269484 * r + 528482 * g + 102760 * b + (1 << 19) + (16 << 20)) >> 20))
+    for yy in range(0, height, 2):
+        for xx in range(0, width, 2):
+            b, g, r = px(yy, xx)
+            uv += [sat_u8((-155188 * r - 305135 * g + 460324 * b + (1 << 19) + (128 << 20)) >> 20),
+                   sat_u8((460324 * r - 385875 * g - 74448 * b + (1 << 19) + (128 << 20)) >> 20)]
+    return ys + uv
+
+
+def color_answer(k):
+    """The answer of one entry of kat.json's "color" list."""
+    if k["op"] == "bgr2yuv":
+        return [c for p in k["src"] for c in bgr2yuv_px(*p)]
+    if k["op"] == "yuv2bgr":
+        return [c for p in k["src"] for c in yuv2bgr_px(*p)]
+    if k["op"] == "nv12_to_bgr":
+        return nv12_to_bgr(k["src"], *k["shape"])
+    if k["op"] == "bgr_to_nv12":
+        return bgr_to_nv12(k["src"], *k["shape"])
+    raise KeyError(k["op"])

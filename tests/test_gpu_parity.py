@@ -1359,6 +1359,30 @@ def test_cvt_color_420_codes(ctx, size):
         assert np.array_equal(host(d_out[k]), oracle.nv12_to_bgr(host(d_nv[k]), w, h)), k
 
 
+def test_colour_known_answers_on_gpu(ctx):
+    """kat.json's "color" list (COL-1..8: one per family of tests/color_mutants.py, all 26 mutants killed on the CPU) through the HIP
+    colour kernels: cvtColor BGR2YUV / YUV2BGR on a one-row image, NV12 -> BGR and BGR -> I420 (the NV12 encode with planar chroma)."""
+    import json
+    from pathlib import Path
+    kats = json.loads((Path(__file__).parent / "golden" / "kat.json").read_text())["color"]
+    assert len(kats) >= 8
+    for k in kats:
+        if k["op"] in ("bgr2yuv", "yuv2bgr"):
+            px = np.array(k["src"], np.uint8).reshape(1, -1, 3).copy()
+            got = ctx.cvt_color(px, mi_lumaeq.COLOR_BGR2YUV if k["op"] == "bgr2yuv" else mi_lumaeq.COLOR_YUV2BGR)
+            assert got.reshape(-1).tolist() == k["dst"], k["id"]
+            continue
+        w, h = k["shape"]
+        if k["op"] == "nv12_to_bgr":
+            nv = np.array(k["src"], np.uint8).reshape(h * 3 // 2, w).copy()
+            assert ctx.cvt_color_420(nv, mi_lumaeq.COLOR_YUV2BGR_NV12).reshape(-1).tolist() == k["dst"], k["id"]
+        else:
+            bgr = np.array(k["src"], np.uint8).reshape(h, w, 3).copy()
+            i420 = ctx.cvt_color_420(bgr, mi_lumaeq.COLOR_BGR2YUV_I420).reshape(-1).tolist()
+            n = w * h
+            assert i420[:n] == k["dst"][:n] and i420[n:n + n // 4] == k["dst"][n::2] and i420[n + n // 4:] == k["dst"][n + 1::2], k["id"]
+
+
 def test_cvt_color_420_errors(ctx):
     with pytest.raises(mi_lumaeq.MiError):
         ctx.cvt_color_420(np.zeros((3, 4, 3), np.uint8), mi_lumaeq.COLOR_BGR2YUV_I420)          # odd height
