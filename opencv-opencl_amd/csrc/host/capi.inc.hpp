@@ -117,7 +117,7 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
     // context never does, and every stream a process creates competes for the runtime's few hardware queues, see pipe_stream_create)
     {   // one line of pinned, device-writable host memory: the finish kernel of the fused path reports repaired launches into it
         void* q = nullptr;
-        if (hipHostMalloc(&q, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        if (hipHostMalloc(&q, 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
             || hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (q) (void)hipHostFree(q);
@@ -126,7 +126,7 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
             return MI_ERR_HIP;
         }
         c->h_mirror = (uint32_t*)q;
-        memset(c->h_mirror, 0, 256);                              // words 0..31: fused equalizeHist, 32..47: fused CLAHE cells
+        memset(c->h_mirror, 0, 128);
     }
     // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
@@ -168,7 +168,6 @@ void mi_ctx_destroy(mi_ctx* c)
     if (c->d_ghist) (void)hipFree(c->d_ghist);
     if (c->d_sync16) (void)hipFree(c->d_sync16);
     if (c->d_fused) (void)hipFree(c->d_fused);
-    if (c->d_cell) (void)hipFree(c->d_cell);
     for (void* q : c->retired) (void)hipFree(q);
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_c16) (void)hipFree(c->d_c16);
@@ -273,9 +272,6 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "fused_demote_after")) { if (value < 0 || value > 32) return fail(c, MI_ERR_BAD_ARG, "fused_demote_after must be 0..32"); c->fused_demote_after = value; return MI_OK; }
     if (!strcmp(name, "fused_reprobe_ms")) { c->fused_reprobe_ms = c->fused_reprobe_ms_now = std::max(1, value); return MI_OK; }
     if (!strcmp(name, "clahe_fp_contract")) { c->clahe_fp_contract = value != 0; return MI_OK; }
-    if (!strcmp(name, "clahe_single_read")) { c->clahe_single_read = value; return MI_OK; }
-    if (!strcmp(name, "clahe_cell_variant")) { c->clahe_cell_variant = value; return MI_OK; }
-    if (!strcmp(name, "clahe_single_read_min_frames")) { c->clahe_single_read_min_frames = std::max(1, value); return MI_OK; }
     // ---- speed only (mi_lumaeq_tuning.h)
     if (!strcmp(name, "two_kernel_max_frames")) { if (value < 0 || value > 64) return fail(c, MI_ERR_BAD_ARG, "two_kernel_max_frames must be 0..64"); c->two_kernel_max_frames = value; return MI_OK; }
     if (!strcmp(name, "fused_wgs_per_cu")) { c->fused_wgs_per_cu = std::max(1, std::min(8, value)); return MI_OK; }
@@ -323,9 +319,7 @@ mi_status mi_ctx_synchronize(mi_ctx* c, void* stream)
     return MI_OK;
 }
 
-// Statistics: "clahe_fused_fallbacks" / "clahe_cells_repaired" / "clahe_fused_last_status" / "clahe_fused_demotions" / "clahe_fused_demoted":
-// the same for the fused CLAHE cell kernel (kernels/clahe_cell.hip.h).
-// "fused_fallbacks" (fused launches in which a bounded wait expired and the finish kernel redid the missing tickets),
+// Statistics: "fused_fallbacks" (fused launches in which a bounded wait expired and the finish kernel redid the missing tickets),
 // "fused_frames_repaired", "fused_hard_errors" (frames the repair refused), "fused_last_status" (1 = wait on a frame's LUT
 // flag / histogram total, 2 = LUT checksum) -- these read device words with a blocking copy on the context's stream: call after the
 // stream the work ran on has been synchronised.  Host-side counters: "fused_demotions" (times the context gave the fused path up
@@ -341,18 +335,6 @@ mi_status mi_ctx_get_stat(mi_ctx* c, const char* name, uint64_t* out)
     if (!strcmp(name, "host_planes_staged")) { *out = c->planes_staged; return MI_OK; }
     if (!strcmp(name, "host_planes_direct")) { *out = c->planes_direct; return MI_OK; }
     if (!strcmp(name, "host_copies_shared")) { *out = c->crew ? c->crew->shared_jobs() : 0; return MI_OK; }
-    if (!strcmp(name, "clahe_fused_demotions")) { *out = c->cell_demotions; return MI_OK; }
-    if (!strcmp(name, "clahe_fused_demoted")) { *out = c->cell_demoted ? 1 : 0; return MI_OK; }
-    static const char* cnames[3] = {"clahe_fused_fallbacks", "clahe_cells_repaired", "clahe_fused_last_status"};
-    for (int k = 0; k < 3; ++k)
-        if (!strcmp(name, cnames[k])) {
-            uint64_t st3[3];
-            mi_status st = ensure_stream(c);
-            if (st) return st;
-            if ((st = cell_read_stats(c, c->stream, st3))) return st;
-            *out = st3[k];
-            return MI_OK;
-        }
     static const char* names[4] = {"fused_fallbacks", "fused_frames_repaired", "fused_hard_errors", "fused_last_status"};
     for (int k = 0; k < 4; ++k)
         if (!strcmp(name, names[k])) {

@@ -138,23 +138,6 @@ struct mi_ctx {
     int clahe_seg_pairs = 9;                                     // option "clahe_seg_pairs": pairs per float table when a wide grid is cut into column segments (4..15)
     int clahe_xcd_map = 1;                                       // option "clahe_xcd_map": XCD-aware tile order of the tile histogram pass
     int clahe_float_tables = 1;                                  // option "clahe_float_tables": f32 pair tables in LDS (tiles_x <= 14)
-    int clahe_cell_variant = 0;                                  // measurement switches of the stage-1 cell kernel (option "clahe_cell_variant")
-    int clahe_single_read = 1;                                   // option "clahe_single_read": 1 = the fused cell kernel (kernels/clahe_cell.hip.h) where the
-                                                                 // geometry is regular and the batch large enough, 0 = always two passes, 2 = the stage-1
-                                                                 // measurement kernel (tile LUTs from the tile-histogram pass)
-    int clahe_single_read_min_frames = 4;                        // option "clahe_single_read_min_frames": smaller calls take the two-pass path
-    // hand-off block of the fused cell kernel (clahe.inc.hpp): ctl | tcnt | tready | lutpub | part | sflag, laid out by capacity
-    uint32_t* d_cell = nullptr;    size_t cell_bytes = 0;
-    size_t cell_cap_tiles = 0, cell_cap_cells = 0;               // frames x tiles / frames x cells the block is laid out for
-    uint32_t cell_generation = 0;                                // blocks allocated so far (selects the host mirror word)
-    uint64_t cell_stat_base[3] = {};                             // statistics of blocks since replaced: launches repaired, cells repaired, last status
-    uint64_t cell_repaired_base = 0, cell_repaired_last = 0;     // mirror words of blocks since replaced; repaired launches the admission rule has seen
-    bool cell_pair_open = false;                                 // fused kernel launched, finish kernel not (a failed launch in between)
-    bool cell_demoted = false, cell_probing = false;             // the context gave the cell path up for a while after a repaired launch
-    uint32_t cell_clean_launches = 0;
-    uint64_t cell_demotions = 0;                                 // statistic "clahe_fused_demotions"
-    int cell_reprobe_ms_now = 1000;
-    std::chrono::steady_clock::time_point cell_reprobe_at{};
     uint8_t*  d_stage_in = nullptr;  size_t stage_in_bytes = 0;  // device frame for the host-pointer forms
     uint8_t*  d_stage_out = nullptr; size_t stage_out_bytes = 0;
     uint8_t*  d_c16 = nullptr;     size_t c16_bytes = 0;         // 16-bit CLAHE: tile histograms + ushort LUTs (N4)

@@ -25,7 +25,6 @@
 //   kernels/equalize.hip.h        K1 hist partials, K2 CDF->LUT, K3 LUT apply (+UV)
 //   kernels/equalize_fused.hip.h  KF fused single-read equalizeHist
 //   kernels/clahe.hip.h           K4 tile hist, K5 clip/redistribute/LUT, K6 interpolation
-//   kernels/clahe_cell.hip.h      KC single-read CLAHE by cells (tile quadrants; docs/experiments.md R5.4)
 //   kernels/clahe16.hip.h         CLAHE on CV_16UC1 (N4)
 //   kernels/color.hip.h           cvtColor BGR2YUV / YUV2BGR + fused split/merge, 4:2:0 codes, NV12 per-channel equalize (N3)
 //   kernels/color_clahe.hip.h     CLAHE on the luma of interleaved BGR in two passes (N3)
@@ -35,7 +34,6 @@
 #include "kernels/equalize.hip.h"
 #include "kernels/equalize_fused.hip.h"
 #include "kernels/clahe.hip.h"
-#include "kernels/clahe_cell.hip.h"
 #include "kernels/clahe16.hip.h"
 #include "kernels/color.hip.h"
 #include "kernels/color_clahe.hip.h"
