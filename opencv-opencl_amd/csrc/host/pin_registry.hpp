@@ -113,7 +113,8 @@ public:
         }
         const bool ok = unpin(ptr);
         std::lock_guard<std::mutex> lk(mu_);
-        unpinning_.erase(std::find_if(unpinning_.begin(), unpinning_.end(), [&](const Range& x) { return x.lo == r.lo && x.hi == r.hi; }));
+        const auto it = std::find_if(unpinning_.begin(), unpinning_.end(), [&](const Range& x) { return x.lo == r.lo && x.hi == r.hi; });
+        if (it != unpinning_.end()) unpinning_.erase(it);    // (always there: a second remover of the same range was told BUSY above)
         if (!ok) pinned_.push_back(r);                       // still pinned as far as anybody knows: keep it, the caller may retry
         ++generation_;
         return ok ? REMOVED : RUNTIME_REFUSED;
