@@ -485,6 +485,88 @@ def test_pipe_randomized_sessions():
                 mi_lumaeq.host_unregister(a)
 
 
+def test_registering_and_unregistering_while_two_pipes_stream():
+    """The pin registry under real traffic (host/pin_registry.hpp, round 5): two threads stream frames through their own pipes on
+    registered rings while a third keeps registering and unregistering OTHER buffers (each unregister may wait for the device, and
+    since round 5 does so without the registry's lock) and keeps asking to unregister the ring buffers that are in flight.  Every such
+    request must be answered BUSY or, between two frames, succeed and be re-registered -- never crash, never corrupt a frame: every
+    delivered frame is compared with the oracle.  (The reference's accelerator worker maps, enqueues on and unmaps caller buffers with
+    no guard at all: OpenCLequalHist.cpp:307-367.)"""
+    import threading
+    w, h, n = 1280, 720, 120
+    fb = w * h * 3 // 2
+    base = [synth.nv12_frame(w, h, synth.DISTS[k % 5], 8800 + k) for k in range(4)]
+    want = [oracle.nv12_frame(f, w, h, uv_mode=0, op=0) for f in base]
+    errors, busy_answers, churned = [], [0], [0]
+    stop = threading.Event()
+    rings = []
+
+    def streamer(idx):
+        try:
+            ins = [base[k % 4].copy() for k in range(6)]
+            outs = [np.zeros(fb, np.uint8) for _ in range(6)]
+            for a in ins + outs:
+                mi_lumaeq.host_register(a)
+            rings.append(ins + outs)
+            with mi_lumaeq.Context(0) as c:
+                with mi_lumaeq.Pipe(c, w, h, depth=3) as pipe:
+                    sub = done = 0
+                    while done < n:
+                        while sub < n and sub - done < 3:
+                            assert pipe.submit(ins[sub % 6], outs[sub % 6], sub)
+                            sub += 1
+                        tag, out = pipe.wait()
+                        assert tag == done
+                        if not np.array_equal(out, want[(done % 6) % 4]):
+                            errors.append(f"streamer {idx}: frame {done} differs from the oracle")
+                        out[:64] = 0                               # the slot's next frame must write it again
+                        done += 1
+        except Exception as e:                                     # noqa: BLE001 -- reported by the main thread
+            errors.append(f"streamer {idx}: {e!r}")
+
+    def churner():
+        try:
+            scratch = [np.zeros(1 << 20, np.uint8) for _ in range(3)]
+            while not stop.is_set():
+                for a in scratch:
+                    mi_lumaeq.host_register(a)
+                for a in scratch:
+                    mi_lumaeq.host_unregister(a)
+                churned[0] += 1
+                for ring in list(rings):
+                    for a in ring[::5]:
+                        try:
+                            mi_lumaeq.host_unregister(a)
+                        except mi_lumaeq.MiError as e:
+                            assert e.status == mi_lumaeq.ERR_BUSY, e
+                            busy_answers[0] += 1
+                        else:
+                            mi_lumaeq.host_register(a)             # it was idle at that instant: pin it again for its next frame
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(f"churner: {e!r}")
+
+    ts = [threading.Thread(target=streamer, args=(i,)) for i in range(2)]
+    ch = threading.Thread(target=churner)
+    for t in ts:
+        t.start()
+    ch.start()
+    for t in ts:
+        t.join(timeout=300)
+    stop.set()
+    ch.join(timeout=60)
+    try:
+        assert not errors, errors[:5]
+        assert not any(t.is_alive() for t in ts) and not ch.is_alive()
+        assert churned[0] >= 3, churned                            # the third thread really ran beside the streams
+    finally:
+        for ring in rings:
+            for a in ring:
+                try:
+                    mi_lumaeq.host_unregister(a)
+                except mi_lumaeq.MiError:
+                    pass
+
+
 def test_host_unregister_is_refused_while_a_pipe_dma_is_pending():
     """A frame the caller registered is DMA'd as it is, asynchronously: between mi_pipe_submit and the mi_pipe_wait that retires it the
     copy engines own its pages, and unpinning them then is a GPU access to an ordinary heap address (the round-3 memory fault was one).
