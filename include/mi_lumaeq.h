@@ -218,9 +218,13 @@ mi_status mi_clahe_u16_batch_dev(mi_ctx* ctx, const void* d_src, size_t src_step
  * (between the mi_pipe_submit that took the frame and the mi_pipe_wait that returns it, or the pipe's destruction): unpinning
  * pages under the copy engine is a GPU access to an ordinary heap address, which ends the process.  The reference's accelerator
  * path has the same window and no guard (OpenCLequalHist.cpp:356-367).  MI_ERR_BAD_ARG: `ptr` is not the start of a registered range.
- * MI_ERR_HIP: the runtime refused to unpin; the buffer is STILL registered (and still pinned) -- ask again, do not free it yet.
+ * MI_ERR_HIP: the runtime refused to unpin although the pages are still pinned; the buffer is STILL registered -- ask again, do not
+ * free it yet.  If the runtime refuses because it no longer knows the pages as pinned (the caller unpinned them itself with
+ * hipHostUnregister, a runtime teardown did), the entry is dropped and MI_OK returned: nothing is left to undo.
  * mi_host_unregister may wait for the device; it does not hold up other threads' mi_pipe_submit / host-form calls meanwhile (the
- * range being unpinned is simply not treated as pinned any more).  A second thread unregistering the same buffer at that moment gets BUSY.
+ * range being unpinned is simply not treated as pinned any more).  A second thread unregistering the same buffer (same `ptr`) at that
+ * moment gets BUSY; when it asks again after the first thread is through it gets MI_ERR_BAD_ARG, which then means "already
+ * unregistered" -- only the thread that received MI_OK may free the memory on the strength of its own call.
  * Memory the caller pinned by other means (hipHostMalloc, hipHostRegister) is recognised as pinned when the whole plane lies in ONE
  * such allocation; releasing it while frames are pending is the caller's responsibility. */
 mi_status mi_host_register(void* ptr, size_t bytes);

@@ -241,15 +241,22 @@ mi_status mi_host_unregister(void* ptr)
 {
     if (!ptr) return MI_ERR_BAD_ARG;
     // hipHostUnregister may wait for the device: the registry calls it WITHOUT its lock (the range sits on the "being unpinned" list
-    // meanwhile, so nobody judges it pinned), and keeps the range registered when the runtime refuses -- the caller can ask again.
+    // meanwhile, so nobody judges it pinned), and keeps the range registered when the runtime refuses although the pages are still
+    // pinned -- the caller can ask again.  A refusal because the runtime does not know the pages as pinned any more (the caller
+    // unpinned them itself, a teardown did) drops the entry instead: kept, it could never be removed, and after the address was
+    // freed and reused the registry would call memory pinned that nobody pinned.
+    using R = mi_host::PinRegistry;
     switch (g_pins.remove(ptr, g_pending_dma, [](void* q) {
-                if (hipHostUnregister(q) == hipSuccess) return true;
+                const hipError_t e = hipHostUnregister(q);
+                if (e == hipSuccess) return R::UNPINNED;
                 (void)hipGetLastError();
-                return false;
+                if (e == hipErrorHostMemoryNotRegistered) return R::NOT_PINNED_ANY_MORE;
+                return runtime_says_pinned(q, 1) ? R::REFUSED : R::NOT_PINNED_ANY_MORE;      // any other error: ask what is true now
             })) {
-        case mi_host::PinRegistry::REMOVED: return MI_OK;
-        case mi_host::PinRegistry::NOT_REGISTERED: return MI_ERR_BAD_ARG;
-        case mi_host::PinRegistry::BUSY: return MI_ERR_BUSY;
+        case R::REMOVED: return MI_OK;
+        case R::ALREADY_UNPINNED: return MI_OK;      // the entry is gone and the pages are not pinned: what the caller asked for
+        case R::NOT_REGISTERED: return MI_ERR_BAD_ARG;
+        case R::BUSY: return MI_ERR_BUSY;
         default: return MI_ERR_HIP;
     }
 }

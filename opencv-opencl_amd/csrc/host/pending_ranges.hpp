@@ -8,9 +8,11 @@
 // table first and answers MI_ERR_BUSY while any pending transfer overlaps the range.
 //
 // Order that closes the race with a concurrent mi_host_unregister: a submit path add()s its ranges BEFORE it decides
-// whether they are pinned, and drops them again if the frame ends up staged; the unregister path checks and unregisters
-// under the registry's lock.  Either the unregister sees the pending entry (BUSY), or it completed first and the submit
-// path finds the range unpinned and stages the frame.
+// whether they are pinned, and drops them again if the frame ends up staged.  The unregister path (pin_registry.hpp, which holds
+// the whole protocol) looks at this table in its FIRST critical section, moves the range to its "being unpinned" list there, and
+// calls hipHostUnregister WITHOUT the registry's lock; a judge never calls a range on that list pinned and distrusts a runtime
+// answer that straddles an (un)registration (generation re-check).  Either the unregister sees the pending entry (BUSY), or its
+// first critical section came first and the submit path finds the range "being unpinned" / gone and stages the frame.
 //
 // Stand-alone on purpose (no HIP header): tests/cxx/test_host_helpers.cpp exercises it on a machine without a GPU.
 #ifndef MI_PENDING_RANGES_HPP_

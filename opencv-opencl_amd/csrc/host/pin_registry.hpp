@@ -13,8 +13,11 @@
 //             plane is staged this once -- slower, never wrong.
 //   remove    lock: find; a queued DMA still uses it -> busy; move the range to the "being unpinned" list; generation++.  unlock.
 //             unpin through the runtime (no lock held -- this is the call that may wait for the device).
-//             lock: drop it from "being unpinned"; if the runtime REFUSED, put it back among the registered ranges (the caller can
-//             retry and is still owed an MI_OK before freeing the memory -- ADVICE r4: it used to be forgotten); generation++.
+//             lock: drop it from "being unpinned"; if the runtime REFUSED and the pages are still pinned, put it back among the
+//             registered ranges (the caller can retry and is still owed an MI_OK before freeing the memory -- ADVICE r4: it used to be
+//             forgotten); if the runtime refused because it does not know the pages as pinned ANY MORE (the caller or a teardown
+//             unpinned them behind the library's back), the entry is dropped: put back, it could never be removed again, and once the
+//             address was freed and reused the registry would answer "pinned" for memory nobody pinned; generation++.
 //
 // Why a judge can never bless a range whose pages are about to be unpinned: a pipe add()s a frame's ranges to the pending-DMA table
 // BEFORE it judges them (pending_ranges.hpp).  A remove() whose first critical section comes after that add() answers busy; one
@@ -59,7 +62,9 @@ struct PinnedNegCache {
 
 class PinRegistry {
 public:
-    enum Removal { REMOVED = 0, NOT_REGISTERED = 1, BUSY = 2, RUNTIME_REFUSED = 3 };
+    enum Removal { REMOVED = 0, NOT_REGISTERED = 1, BUSY = 2, RUNTIME_REFUSED = 3, ALREADY_UNPINNED = 4 };
+    // what the unpin callable of remove() answers (a plain bool works too: false = REFUSED, true = UNPINNED)
+    enum Unpin { REFUSED = 0, UNPINNED = 1, NOT_PINNED_ANY_MORE = 2 };
 
     // [p, p + bytes) was pinned through the runtime on the library's behalf (mi_host_register, after hipHostRegister succeeded)
     void add(const void* p, size_t bytes)
@@ -93,16 +98,21 @@ public:
         return generation_ == g0 && !overlaps(unpinning_, lo, hi);
     }
 
-    // mi_host_unregister.  unpin(ptr) -> bool is called WITHOUT the lock; it may wait for the device.
-    template <class Unpin>
-    Removal remove(void* ptr, const PendingRanges& pending, Unpin&& unpin)
+    // mi_host_unregister.  unpin(ptr) -> Unpin (or bool) is called WITHOUT the lock; it may wait for the device.
+    template <class UnpinFn>
+    Removal remove(void* ptr, const PendingRanges& pending, UnpinFn&& unpin)
     {
         Range r{};
         {
             std::lock_guard<std::mutex> lk(mu_);
             auto it = std::find_if(pinned_.begin(), pinned_.end(), [&](const Range& x) { return x.lo == (uintptr_t)ptr; });
-            if (it == pinned_.end())
-                return overlaps(unpinning_, (uintptr_t)ptr, (uintptr_t)ptr + 1) ? BUSY : NOT_REGISTERED;     // a second thread is unpinning it right now
+            if (it == pinned_.end()) {
+                // a second thread is unpinning this very range right now: BUSY -- and once that thread is through, the retry the header
+                // asks for finds nothing and gets NOT_REGISTERED, which then means "already removed".  Interior pointers of such a range
+                // are NOT_REGISTERED at once, as they are for any registered range.
+                for (const Range& x : unpinning_) if (x.lo == (uintptr_t)ptr) return BUSY;
+                return NOT_REGISTERED;
+            }
             // a pipe still has a transfer queued on this buffer (submitted, not yet retired by mi_pipe_wait): unpinning it now would
             // leave the copy engine with an ordinary heap address.  The caller waits for its frames (or destroys the pipe) and asks again.
             if (pending.overlaps(it->lo, it->hi)) return BUSY;
@@ -111,13 +121,13 @@ public:
             unpinning_.push_back(r);
             ++generation_;
         }
-        const bool ok = unpin(ptr);
+        const int verdict = (int)unpin(ptr);
         std::lock_guard<std::mutex> lk(mu_);
         const auto it = std::find_if(unpinning_.begin(), unpinning_.end(), [&](const Range& x) { return x.lo == r.lo && x.hi == r.hi; });
         if (it != unpinning_.end()) unpinning_.erase(it);    // (always there: a second remover of the same range was told BUSY above)
-        if (!ok) pinned_.push_back(r);                       // still pinned as far as anybody knows: keep it, the caller may retry
+        if (verdict == REFUSED) pinned_.push_back(r);        // still pinned: keep it, the caller may retry
         ++generation_;
-        return ok ? REMOVED : RUNTIME_REFUSED;
+        return verdict == UNPINNED ? REMOVED : verdict == REFUSED ? RUNTIME_REFUSED : ALREADY_UNPINNED;
     }
 
     size_t size() const { std::lock_guard<std::mutex> lk(mu_); return pinned_.size(); }

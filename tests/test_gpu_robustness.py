@@ -493,13 +493,17 @@ def test_registering_and_unregistering_while_two_pipes_stream():
     delivered frame is compared with the oracle.  (The reference's accelerator worker maps, enqueues on and unmaps caller buffers with
     no guard at all: OpenCLequalHist.cpp:307-367.)"""
     import threading
-    w, h, n = 1280, 720, 120
+    import time
+    w, h = 1280, 720
+    stream_s, min_frames = 3.0, 600                                # a fixed wall time of streaming, not a frame count (ADVICE r5)
     fb = w * h * 3 // 2
     base = [synth.nv12_frame(w, h, synth.DISTS[k % 5], 8800 + k) for k in range(4)]
     want = [oracle.nv12_frame(f, w, h, uv_mode=0, op=0) for f in base]
-    errors, busy_answers, churned = [], [0], [0]
+    errors, busy_answers, reregistered, churned, streamed = [], [0], [0], [0], [0, 0]
     stop = threading.Event()
-    rings = []
+    rings = [None, None]
+    first_submit = [threading.Event(), threading.Event()]
+    go = threading.Event()                                         # set by the churner once BOTH streams have a frame in flight
 
     def streamer(idx):
         try:
@@ -507,25 +511,39 @@ def test_registering_and_unregistering_while_two_pipes_stream():
             outs = [np.zeros(fb, np.uint8) for _ in range(6)]
             for a in ins + outs:
                 mi_lumaeq.host_register(a)
-            rings.append(ins + outs)
+            rings[idx] = ins + outs
             with mi_lumaeq.Context(0) as c:
                 with mi_lumaeq.Pipe(c, w, h, depth=3) as pipe:
                     sub = done = 0
-                    while done < n:
-                        while sub < n and sub - done < 3:
+                    t_end = None
+                    while True:
+                        if t_end is None and go.is_set():
+                            t_end = time.monotonic() + stream_s    # the clock starts when the churner starts asking
+                        more = t_end is None or time.monotonic() < t_end or done < min_frames
+                        while more and sub - done < 3:
                             assert pipe.submit(ins[sub % 6], outs[sub % 6], sub)
                             sub += 1
+                            first_submit[idx].set()
+                        if sub == done:
+                            break
                         tag, out = pipe.wait()
                         assert tag == done
                         if not np.array_equal(out, want[(done % 6) % 4]):
                             errors.append(f"streamer {idx}: frame {done} differs from the oracle")
                         out[:64] = 0                               # the slot's next frame must write it again
                         done += 1
+                    streamed[idx] = done
         except Exception as e:                                     # noqa: BLE001 -- reported by the main thread
             errors.append(f"streamer {idx}: {e!r}")
+        finally:
+            first_submit[idx].set()                                # never leave the churner waiting for a stream that died
 
     def churner():
         try:
+            for ev in first_submit:                                # both rings published, both streams have submitted a frame
+                ev.wait(timeout=120)
+            assert all(r is not None for r in rings), "a streamer never published its ring"
+            go.set()
             scratch = [np.zeros(1 << 20, np.uint8) for _ in range(3)]
             while not stop.is_set():
                 for a in scratch:
@@ -533,8 +551,10 @@ def test_registering_and_unregistering_while_two_pipes_stream():
                 for a in scratch:
                     mi_lumaeq.host_unregister(a)
                 churned[0] += 1
-                for ring in list(rings):
+                for ring in rings:
                     for a in ring[::5]:
+                        if stop.is_set():
+                            break
                         try:
                             mi_lumaeq.host_unregister(a)
                         except mi_lumaeq.MiError as e:
@@ -542,8 +562,10 @@ def test_registering_and_unregistering_while_two_pipes_stream():
                             busy_answers[0] += 1
                         else:
                             mi_lumaeq.host_register(a)             # it was idle at that instant: pin it again for its next frame
+                            reregistered[0] += 1
         except Exception as e:                                     # noqa: BLE001
             errors.append(f"churner: {e!r}")
+            go.set()
 
     ts = [threading.Thread(target=streamer, args=(i,)) for i in range(2)]
     ch = threading.Thread(target=churner)
@@ -557,10 +579,16 @@ def test_registering_and_unregistering_while_two_pipes_stream():
     try:
         assert not errors, errors[:5]
         assert not any(t.is_alive() for t in ts) and not ch.is_alive()
-        assert churned[0] >= 3, churned                            # the third thread really ran beside the streams
+        # the scenario of the docstring really ran: the third thread worked beside the streams, requests hit ring buffers with a DMA in
+        # flight (BUSY) AND idle ones (unregistered and pinned again, while frames kept flowing through them)
+        assert min(streamed) >= min_frames, streamed
+        assert churned[0] >= 3, churned
+        assert busy_answers[0] > 0, (busy_answers, reregistered, churned, streamed)
+        assert reregistered[0] > 0, (busy_answers, reregistered, churned, streamed)
+        print(f"two pipes x {streamed} frames; churner rounds {churned[0]}, BUSY {busy_answers[0]}, unregistered + re-registered {reregistered[0]}")
     finally:
         for ring in rings:
-            for a in ring:
+            for a in ring or []:
                 try:
                     mi_lumaeq.host_unregister(a)
                 except mi_lumaeq.MiError:

@@ -15,6 +15,16 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parents[1]
 
 
+
+def _free_port():
+    """A rendezvous port the kernel hands out (bind to port 0), as bench._free_port does: a port derived from the pid can collide with the
+    other gloo tests of this file or with a torchrun default on a busy box."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _worker(rank, world, port, n_frames, q):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "opencv-opencl_amd" / "python"))
@@ -48,7 +58,7 @@ def test_two_rank_sharding_matches_serial(n_frames):
     from mi_lumaeq import shard, synth
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + n_frames
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -105,7 +115,7 @@ def test_one_rank_group_still_goes_through_the_backend():
     group must really call all_reduce, not return early."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_one_rank_worker, args=(29500 + (os.getpid() % 2000) + 31, q))
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
     p.start()
     got, calls = q.get(timeout=120)
     p.join(timeout=60)

@@ -9,7 +9,7 @@ MODES = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 a = mi_lumaeq.Context(0)
 import os
-for kv in os.environ.get("MI_AB_SET", "").split(","):            # further options for every mode, e.g. MI_AB_SET=clahe_cell_variant=8
+for kv in os.environ.get("MI_AB_SET", "").split(","):            # further options for every mode, e.g. MI_AB_SET=clahe_fp_contract=1
     if "=" in kv:
         a.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 CASES = [(3840, 2160, 8, B), (1920, 1080, 8, B), (3840, 2160, 16, B)]
