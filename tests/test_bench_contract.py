@@ -79,6 +79,64 @@ def test_self_launcher_starts_one_fresh_child_per_gpu(tmp_path, capfd):
     assert bench.launch_children(2, ["no_line"], child_cmd=cmd) == 1     # all ranks fine but no result: still a failure
 
 
+_STUB8 = r'''
+import json, os, sys
+rank = int(os.environ["RANK"])
+rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                       "HSA_ENABLE_IPC_MODE_LEGACY")}
+rec["pid"], rec["ppid"], rec["argv"] = os.getpid(), os.getppid(), sys.argv[1:]
+with open(os.path.join(os.environ["STUB_OUT"], f"rank{rank}.{os.getpid()}.json"), "w") as f:
+    json.dump(rec, f)
+print(f"[bench hb] rank={rank} phase=done t=+0.0s", file=sys.stderr, flush=True)
+if rank == 0:
+    print(json.dumps({"metric": "stub", "n_gpus": int(os.environ["WORLD_SIZE"])}), flush=True)
+'''
+
+
+def test_self_launcher_with_eight_gpus_one_child_per_rank(tmp_path, capfd, monkeypatch):
+    """The shape of the driver's 8-GPU node (the reference's 1..8 workers: OpenCVequalHist.cpp:274, :397-402), with stub children: exactly
+    one child per rank, LOCAL_RANK 0..7 = RANK (rank r takes GPU r), WORLD_SIZE 8, one rendezvous on 127.0.0.1 shared by all,
+    HSA_ENABLE_IPC_MODE_LEGACY=0 in EVERY child's environment whether or not the launcher's own environment has it (RCCL's peers on this
+    pool speak dmabuf IPC only) -- and a value the caller set on purpose is not overwritten -- the caller's arguments handed on unchanged,
+    and the deadline a plain `python bench.py --gpus 8` runs under: 480 s, inside the driver's 600."""
+    import json
+    import os
+    import bench
+    stub = tmp_path / "stub8.py"
+    stub.write_text(_STUB8)
+    for legacy_in_parent, want in ((None, "0"), ("0", "0"), ("1", "1")):
+        out_dir = tmp_path / f"out_{legacy_in_parent}"
+        out_dir.mkdir()
+        monkeypatch.setenv("STUB_OUT", str(out_dir))
+        if legacy_in_parent is None:
+            monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+        else:
+            monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", legacy_in_parent)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            monkeypatch.delenv(k, raising=False)
+        rc = bench.launch_children(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], child_cmd=[sys.executable, str(stub)])
+        out, err = capfd.readouterr()
+        assert rc == 0, err[-2000:]
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 8            # rank 0's line, once
+        recs = [json.loads(f.read_text()) for f in sorted(out_dir.iterdir())]
+        assert len(recs) == 8                                                     # one child per rank: no rank twice, none missing
+        assert sorted(int(r["RANK"]) for r in recs) == list(range(8))
+        assert len({r["pid"] for r in recs}) == 8 and {r["ppid"] for r in recs} == {os.getpid()}      # fresh processes of THIS launcher
+        assert len({r["MASTER_PORT"] for r in recs}) == 1 and int(recs[0]["MASTER_PORT"]) > 0
+        for r in recs:
+            assert r["LOCAL_RANK"] == r["RANK"] and r["WORLD_SIZE"] == "8" and r["LOCAL_WORLD_SIZE"] == "8"
+            assert r["MASTER_ADDR"] == "127.0.0.1"
+            assert r["HSA_ENABLE_IPC_MODE_LEGACY"] == want, (legacy_in_parent, r)
+            assert r["argv"] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+        for rank in range(8):
+            assert f"[bench hb] rank={rank} phase=done" in err
+    # what a plain `python bench.py --gpus 8` hands launch_children: the parsed default deadline (480 s) -- and that is also the default
+    # of launch_children itself, for callers that pass none
+    args = bench.parse_args(["--gpus", "8"])
+    assert args.gpus == 8 and args.deadline_s == 480.0 == bench.DEADLINE_DEFAULT_S == bench.launch_children.__defaults__[-1]
+
+
 def test_launcher_deadline_reports_each_ranks_phase(tmp_path, capfd):
     """A job that stops making progress must not end in silence (round 3's four-rank rehearsal left an empty record): at the
     deadline the launcher ends the children by PID, says which phase each rank last announced, and returns 124."""
