@@ -993,9 +993,18 @@ def extras(ctx, args, torch, mi_lumaeq, synth):
     res["strided_roi_equalize_frames_per_s"] = round(Br / (ms * 1e-3), 1)
     # 12-bit content (what 16-bit video carries: the range fits the LDS pair tables) and full-range 16-bit content (L2 gathers)
     # ... and 10-bit samples in the HIGH bits of the word, as P010 video stores them: full 16-bit span, 1024 populated values
-    for name, hi, nb, shift in (("clahe16_8x8_12bit_frames_per_s", 4096, 16, 0), ("clahe16_8x8_12bit_32_per_call_frames_per_s", 4096, 32, 0),
-                                ("clahe16_8x8_p010_10bit_msb_frames_per_s", 1024, 16, 6), ("clahe16_8x8_fullrange_frames_per_s", 65536, 4, 0)):
+    # Wider content is on the record too (round 6): 14-bit sensors (thermal / medical: four windows of 4096 values), a 12-bit frame
+    # with ONE hot pixel at 65535 (its tile loses the 12-bit bet, the rectangles around it see the whole 16-bit range), and content
+    # that fills the 16-bit range, at the 16 frames per call the other rows use (the 4-per-call key is kept for continuity).
+    for name, hi, nb, shift, hot in (("clahe16_8x8_12bit_frames_per_s", 4096, 16, 0, False), ("clahe16_8x8_12bit_32_per_call_frames_per_s", 4096, 32, 0, False),
+                                     ("clahe16_8x8_p010_10bit_msb_frames_per_s", 1024, 16, 6, False),
+                                     ("clahe16_8x8_14bit_frames_per_s", 16384, 16, 0, False),
+                                     ("clahe16_8x8_12bit_one_hot_pixel_frames_per_s", 4096, 16, 0, True),
+                                     ("clahe16_8x8_fullrange_16_per_call_frames_per_s", 65536, 16, 0, False),
+                                     ("clahe16_8x8_fullrange_frames_per_s", 65536, 4, 0, False)):
         s16 = (torch.randint(0, hi, (nb, h, w), dtype=torch.int32, device="cuda") << shift).to(torch.int16)     # bit pattern of the ushort
+        if hot:
+            s16[:, 1000, 2000] = -1                                # 65535
         o16 = torch.empty_like(s16)
         ms = timeit(lambda: ctx.clahe16_batch_dev(s16, o16, w, h, nb, 2.0, 8, 8, stream=stream), 5)
         res[name] = round(nb / (ms * 1e-3), 1)

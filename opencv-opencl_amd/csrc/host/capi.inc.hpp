@@ -293,6 +293,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe16_fast12")) { c->clahe16_fast12 = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe16_transposed")) { c->clahe16_transposed = value != 0; return MI_OK; }
+    if (!strcmp(name, "clahe16_wide")) { c->clahe16_wide = value != 0; return MI_OK; }
     if (!strcmp(name, "pipe_copy_streams")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "pipe_copy_streams must be 1 or 2"); c->pipe_copy_streams = value; return MI_OK; }
     if (!strcmp(name, "host_copy_streams")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "host_copy_streams must be 1 or 2"); c->host_copy_streams = value; return MI_OK; }
     if (!strcmp(name, "host_copy_threads")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "host_copy_threads must be 1 or 2"); c->host_copy_threads = value; return MI_OK; }

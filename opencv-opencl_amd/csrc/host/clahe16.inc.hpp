@@ -42,16 +42,27 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         Range16* franges = ranges + (size_t)nf * tiles;
         uint32_t* fdone = reinterpret_cast<uint32_t*>(franges + nf);
         const bool bet12 = vec && c->clahe16_fast12;
+        // Content wider than 8192 values (round 6, kernels/clahe16_wide.hip.h): tiles that lose the 12-bit bet are left to a one-sweep
+        // kernel with 65536 packed counters, and the interpolation's wide rectangles to a kernel that holds its pixels in registers
+        // over all table windows.  Both need 16-byte aligned planes and pitches (what `vec` asks of the source; the interpolation
+        // also of the destination); option "clahe16_wide" = 0 keeps the round-3 paths (careful sweeps, pixel re-reads per window).
+        const bool wide_hist = bet12 && c->clahe16_wide;
+        const bool wide_interp = c->clahe16_wide && !(tiles <= 64 && c->clahe16_transposed) &&
+                                 (((uintptr_t)src | (uintptr_t)dst | src_step | dst_step | src_frame | dst_frame) & 15) == 0;
         // the context's shift hint: two words at the end of the arrival scratch (read / collect, rolled over by the interpolation kernel)
         uint32_t* hint = bet12 ? c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 4 : nullptr;
         // 12-bit bet (kernels/clahe16.hip.h): vector geometry only; a tile that loses it is redone the careful way in the same workgroup
         if (bet12)
             LAUNCH(c, s, MI_K_TILE_HIST, (tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
-                   c->d_sync16, franges, fdone, hint);
+                   c->d_sync16, franges, fdone, hint, wide_hist ? 1 : 0);
         else
             LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, vec);
+        if (wide_hist)
+            LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16p_kernel, dim3(tiles, nf), dim3(kWideThreads), kWideWords * sizeof(uint32_t),
+                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
+                   c->d_sync16, franges, fdone, hint);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, (const Range16*)ranges, g,
                lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr), hint);
         if (tiles <= 64 && c->clahe16_transposed) {
@@ -80,14 +91,35 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
             if (g.contract)
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<true>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint);
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint,
+                       wide_interp ? 1 : 0);
             else
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<false>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint);
+                       dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint,
+                       wide_interp ? 1 : 0);
+            if (wide_interp) {
+                // rectangles whose four tiles populate 8192 values or more: a lane holds kAccRows rows of one 8-pixel group, so a
+                // workgroup of kAccThreads lanes holds kAccRows * (kAccThreads / groups per pair) rows -- enough sub-bands that one block of rows
+                // is all a workgroup has (it walks further blocks, re-staging its table, if it is given more)
+                const int groups = (g.tile_w + 2 * kBandMargin + 7) / 8 + 1;
+                const int rows_held = kAccRows * std::max(1, kAccThreads / groups);
+                const int subs_acc = std::max(1, std::min(64, (g.tile_h + 2 * kBandMargin + rows_held - 1) / rows_held));
+                const long long rows_acc = (long long)bands * subs_acc * nf;
+                const long long grid_acc = (rows_acc + 7) / 8 * 8 * npairs;
+                if (grid_acc > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "16-bit CLAHE: tile grid too large");
+                if (g.contract)
+                    LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_acc_kernel<true>, dim3((unsigned)grid_acc), dim3(kAccThreads),
+                           (size_t)kAccEntries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
+                           dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs_acc, nf, (const Range16*)ranges);
+                else
+                    LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_acc_kernel<false>, dim3((unsigned)grid_acc), dim3(kAccThreads),
+                           (size_t)kAccEntries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
+                           dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs_acc, nf, (const Range16*)ranges);
+            }
             // IN-PLACE frames whose range does not fit the LDS table (their workgroups above returned at once); the launch is a no-op for
             // every other frame, and is left out altogether when the call is not in place (it cost 8 us per call)
-            if (sp == dp) {
+            if (sp == dp && !wide_interp) {
                 const long long wide_items = (long long)((width + kThreads - 1) / kThreads) * height;
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_wide_kernel, dim3((unsigned)std::min<long long>(wide_items, std::max(512, 2048 / nf)), 1, nf), dim3(kThreads), 0,
                        sp, (long long)src_step, (long long)src_frame, dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges);

@@ -306,6 +306,8 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
 // tile_hist16_careful (as many counters per sweep as fit the same LDS: 8192 with two copies, up to eight sweeps) in the same workgroup.  ranges[tile].hi carries bit 31 when the tile's LUT was written here.
 constexpr uint32_t kLutDone = 0x80000000u;
 constexpr uint32_t kHistCompressed = 0x40000000u;   // Range16.hi of a tile: its histogram is stored at index value >> shift (tile_hist12_kernel with a shift)
+constexpr uint32_t kWideTodo = 0x20000000u;         // Range16.hi of a tile: it lost tile_hist12_kernel's bet and was LEFT to tile_hist16p_kernel (clahe16_wide.hip.h)
+constexpr uint32_t kLutFull = 0x10000000u;          // Range16.hi of a tile: tile_hist16p_kernel wrote its LUT over all 65536 values, raw domain (shift 0)
 constexpr int kBins12 = 4096;
 // Shipped shape: 1024 threads, 4 copies = 64 KiB of LDS, two workgroups per CU.  512 threads x 2 copies (32 KiB, four workgroups per
 // CU) measured the same on 12-bit content (16 4K frames: 59.6 us alone either way; the sweep on its own 45 us either way,
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
                                                         ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
                                                         float lut_scale16, int clip16, uint16_t* __restrict__ luts,
                                                         uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done,
-                                                        uint32_t* __restrict__ shift_hint)
+                                                        uint32_t* __restrict__ shift_hint, int defer_wide)
 {
     static_assert(COPIES == 2 || COPIES == 4, "copies");
     constexpr int NW = NT / 64, BPT = kBins12 / NT;                // waves; bins per thread
@@ -498,9 +500,16 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
             r.hi = min(((((31u - (uint32_t)__builtin_clz(buckets)) << 8) | 255u) << fs), 0xffffu) | (fs << 16);
         }
         frame_ranges[f] = r;
-        frame_done[f] = done ? 1u : 0u;
+        // 2: EVERY tile of the frame lost its bet and was left to tile_hist16p_kernel, whose last tile then settles the frame
+        frame_done[f] = done ? 1u : (defer_wide && nd == 0u ? 2u : 0u);
         if (done) hint_out(shift_hint, (uint32_t)__builtin_ctz(shifts));
     };
+    if (lost && defer_wide) {
+        // uniform over the workgroup: the tile holds values that do not fit 4096 bins at any shift.  It is left, marked, to
+        // tile_hist16p_kernel, which follows on the same grid with 128 KiB of LDS: one sweep over 65536 packed counters, LUT folded in
+        if (t == 0) { Range16 r; r.lo = 0u; r.hi = kWideTodo; ranges[tile_id] = r; arrive(false, 0u, 0u); settle_frame(); }
+        return;
+    }
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
         __syncthreads();
         tile_hist16_careful<kCarefulBits, NT>(h16, s_lo, s_hi, s_or, src_base, step, frame_stride, g, hist, ranges, 1);   // its counters fill the same LDS
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
                                                          const uint32_t* __restrict__ frame_done, uint32_t* __restrict__ shift_hint)
 {
     // tile_hist12_kernel has written every LUT of this frame (bins 0..4095: all anybody reads) and the frame's range: one scalar load
-    if (frame_done && frame_done[blockIdx.y]) return;
+    if (frame_done && frame_done[blockIdx.y] == 1u) return;
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_flo, s_fhi, s_fs;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -681,6 +690,8 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     // tile_hist12_kernel has already written this tile's LUT for bins 0..4095 of ITS domain: that is all anybody reads if that domain
     // is the frame's and the neighbourhood stayed inside it
     if ((own_r.hi & kLutDone) && ((own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u) == sft && (need_hi >> sft) < (uint32_t)kBins12) return;
+    // tile_hist16p_kernel has written this tile's LUT over all 65536 values (raw domain; such a tile reports shift 0, so the frame's is 0)
+    if ((own_r.hi & kLutFull) && sft == 0u) return;
     const uint32_t own_lo = range_lo(own_r.lo), own_hi = range_hi(own_r.hi);
     // where this tile's counts are: at index value (careful sweeps, unshifted bets) or at index value >> own shift (shifted bets)
     const uint32_t own_store = (own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u;      // >= sft: sft is the minimum over the tiles
@@ -784,7 +795,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                                                                          uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                          ClaheGeom g, const uint16_t* __restrict__ luts,
                                                                          const Range16* __restrict__ frame_ranges, int subs, int n_frames,
-                                                                         const Range16* __restrict__ tile_ranges, uint32_t* shift_hint)
+                                                                         const Range16* __restrict__ tile_ranges, uint32_t* shift_hint, int skip_multi)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 tab[];      // [kInterp16Entries] {a | b << 16, c | d << 16}
     const int t = threadIdx.x;
@@ -818,7 +829,9 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     // A range wider than the table is walked in WINDOWS of kInterp16Entries values: the table is staged once per window and a pixel is
     // finished in the window its value falls into (2-byte stores).  That re-reads the workgroup's pixels once per window, so it
     // cannot be done in place: in-place calls on a FRAME with a wide range are left to clahe_interp16_wide_kernel, whole.
-    if (fr.hi - (fr.lo & ~3u) >= (uint32_t)kInterp16Entries && src_base == dst_base) return;
+    // (skip_multi: clahe_interp16_acc_kernel runs beside this one and takes every rectangle whose OWN range needs more than one
+    // window, in place or not; this kernel then keeps the single-window rectangles of such frames, which are safe in place)
+    if (!skip_multi && fr.hi - (fr.lo & ~3u) >= (uint32_t)kInterp16Entries && src_base == dst_base) return;
     // The table only has to cover the values this workgroup's pixels can have: they lie in (at most) the four tiles whose LUTs it blends,
     // so the union of THOSE tiles' ranges replaces the frame's (a hot pixel, a bright corner widen the table of their own rectangles
     // only; tile_lut16_kernel writes every LUT over its tile's 3 x 3 neighbourhood, which contains these four).
@@ -830,6 +843,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     }
     const uint32_t start = fr.lo & ~3u;
     const bool multi = fr.hi - start >= (uint32_t)kInterp16Entries;
+    if (multi && skip_multi) return;                                // uniform: clahe_interp16_acc_kernel's rectangle
     // A range of at most kInterp16F32Entries values (every 12-bit source) gets the table as FLOATS, {a, c, b, d} in 16 bytes: one
     // ds_read_b128 per pixel feeds v_pk_mul / v_pk_add directly and the four ushort -> float conversions per pixel are gone
     // (the blend was VALU-bound: ~25 instructions per pixel, now ~12).  Same 64 KiB of LDS either way.

@@ -56,7 +56,7 @@ def test_product_library_contains_no_test_hook(built_lib):
     tuning = (ROOT / "include" / "mi_lumaeq_tuning.h").read_text()
     main = (ROOT / "include" / "mi_lumaeq.h").read_text()
     for name in ("fused_wgs_per_cu", "fused_vpt", "clahe_xcd_map", "clahe_hist_threads", "clahe_seg_pairs", "clahe_tiles_per_wg",
-                 "clahe_float_tables", "clahe16_transposed", "bgr_fused", "host_copy_threads", "host_copy_streams", "pipe_copy_streams",
+                 "clahe_float_tables", "clahe16_transposed", "clahe16_wide", "bgr_fused", "host_copy_threads", "host_copy_streams", "pipe_copy_streams",
                  "two_kernel_max_frames", "clahe16_fast12"):
         assert f'"{name}"' in tuning and f'"{name}"' not in main, name
         assert name.encode() in prod

@@ -1147,6 +1147,72 @@ def test_clahe16_tables_follow_the_local_range(ctx):
                 assert np.array_equal(got[k], want[k]), (w, h, cfg, "in place", k)
 
 
+def test_clahe16_wide_content_one_sweep_and_register_held_interpolation(ctx):
+    """Round 6 (kernels/clahe16_wide.hip.h): content wider than 8192 values.  Tiles that lose the 12-bit bet are swept ONCE into 65 536
+    packed 16-bit counters with the LUT folded in, and the interpolation holds its pixels in registers over all table windows.  Full-size
+    4K frames, 8x8 tiles of 129 600 pixels: full-range noise, 14-bit, 15-bit, a smooth full-range ramp (few windows per rectangle), a
+    12-bit frame with one hot pixel (ONE deferred tile, its neighbours' LUTs extended), a frame whose tile (3, 2) holds 70 000 pixels of
+    one value among full-range noise (a 16-bit counter WRAPS: the tile must fall back to the careful sweeps -- and the frame, all of
+    whose tiles were deferred, must not be declared done), a half 12-bit / half full-range frame (mixed frame: tile_lut16_kernel
+    extends the 12-bit tiles next to wide ones), and 14-bit samples in the high bits of the word.  Out of place and IN PLACE, with the
+    option on (default) and off (the round-3 paths): every frame bit-exact against the oracle."""
+    w, h = 3840, 2160
+    rng = np.random.default_rng(606)
+    def noise(lo, hi): return rng.integers(lo, hi, (h, w), dtype=np.uint16)
+    full = noise(0, 65536)
+    f14 = noise(0, 16384)
+    f15 = noise(0, 32768)
+    ramp = ((np.arange(h, dtype=np.uint32)[:, None] * 12 + np.arange(w, dtype=np.uint32)[None, :] * 10
+             + rng.integers(0, 512, (h, w), dtype=np.uint32)) % 65536).astype(np.uint16)
+    hot = noise(0, 4096); hot[1000, 2000] = 65535
+    wrap = full.copy()
+    ty0, tx0 = 2 * 270, 3 * 480
+    blk = wrap[ty0: ty0 + 270, tx0: tx0 + 480].reshape(-1).copy()
+    blk[rng.choice(blk.size, 70000, replace=False)] = 31337       # 70 000 > 65 535 pixels of one value, scattered (no flat vectors to speak of)
+    wrap[ty0: ty0 + 270, tx0: tx0 + 480] = blk.reshape(270, 480)
+    halves = noise(0, 4096); halves[:, w // 2:] = rng.integers(0, 65536, (h, w - w // 2), dtype=np.uint16)
+    msb14 = (rng.integers(0, 16384, (h, w), dtype=np.uint32) << 2).astype(np.uint16)
+    frames = [full, f14, f15, ramp, hot, wrap, halves, msb14]
+    names = ["full", "14-bit", "15-bit", "ramp", "hot pixel", "counter wrap", "halves", "14-bit << 2"]
+    for cfg in ((2.0, 8, 8), (40.0, 8, 8)):
+        want = [oracle.clahe16(f, *cfg) for f in frames]
+        try:
+            for wide in (1, 0):
+                ctx.set_option("clahe16_wide", wide)
+                d_in = dev(np.stack(frames).view(np.int16))
+                d_out = torch.zeros_like(d_in)
+                ctx.clahe16_batch_dev(d_in, d_out, w, h, len(frames), *cfg)
+                ctx.synchronize()
+                out = host(d_out).view(np.uint16)
+                bad = [names[k] for k in range(len(frames)) if not np.array_equal(out[k], want[k])]
+                assert not bad, (cfg, wide, "batch", bad)
+                del d_out
+                ctx.clahe16_batch_dev(d_in, d_in, w, h, len(frames), *cfg)            # in place
+                ctx.synchronize()
+                got = host(d_in).view(np.uint16)
+                bad = [names[k] for k in range(len(frames)) if not np.array_equal(got[k], want[k])]
+                assert not bad, (cfg, wide, "in place", bad)
+                del d_in
+        finally:
+            ctx.set_option("clahe16_wide", 1)
+    # other tile grids: tiles too small to wrap a counter, a grid with more pairs than a workgroup has row phases, one tile
+    for (cw, chh, tx, ty) in [(640, 368, 8, 8), (1280, 96, 16, 2), (512, 512, 1, 1), (1024, 64, 2, 4)]:
+        fs = [rng.integers(0, 65536, (chh, cw), dtype=np.uint16), rng.integers(0, 16384, (chh, cw), dtype=np.uint16),
+              rng.integers(20000, 45000, (chh, cw), dtype=np.uint16)]
+        fs.append(fs[0].copy()); fs[-1][: chh // 2] = 4242                                 # flat half: wave-uniform vectors
+        for clip in (2.0, 0.0):
+            d_in = dev(np.stack(fs).view(np.int16))
+            d_out = torch.zeros_like(d_in)
+            ctx.clahe16_batch_dev(d_in, d_out, cw, chh, len(fs), clip, tx, ty)
+            ctx.synchronize()
+            out = host(d_out).view(np.uint16)
+            for k, f in enumerate(fs):
+                assert np.array_equal(out[k], oracle.clahe16(f, clip, tx, ty)), (cw, chh, tx, ty, clip, k)
+            ctx.clahe16_batch_dev(d_in, d_in, cw, chh, len(fs), clip, tx, ty)
+            ctx.synchronize()
+            assert np.array_equal(host(d_in).view(np.uint16), out), (cw, chh, tx, ty, clip, "in place")
+
+
 def test_clahe16_frame_done_flags_over_many_frames(ctx):
     """The last tile workgroup of each FRAME settles the frame's range and whether every tile wrote its LUT in the histogram kernel
     (the LUT kernel then leaves on one scalar load); the per-frame arrival words must come back to zero after every launch.  150

@@ -9,7 +9,8 @@ only = sys.argv[2] if len(sys.argv) > 2 else ""            # "12bit": just the 1
 for kv in sys.argv[3:]:                                      # name=value options, e.g. clahe16_fast12=0
     k, v = kv.split("="); ctx.set_option(k, int(v)); print("option", k, "=", v)
 def u16(lo, hi): return torch.randint(lo, hi, (n, h, w), dtype=torch.int32, device="cuda").to(torch.int16)   # bit pattern of the ushort
-cases = (("12-bit 0..4095", u16(0, 4096)), ("10-bit 0..1023", u16(0, 1024)), ("narrow 1000..1399", u16(1000, 1400)), ("13-bit 0..8191", u16(0, 8192)),
+cases = (("12-bit 0..4095", u16(0, 4096)), ("10-bit 0..1023", u16(0, 1024)), ("narrow 1000..1399", u16(1000, 1400)), ("13-bit 0..8191", u16(0, 8192)), ("14-bit 0..16383", u16(0, 16384)),
+         ("14-bit << 2 (MSB-aligned)", (torch.randint(0, 16384, (n, h, w), dtype=torch.int32, device="cuda") << 2).to(torch.int16)),
          ("10-bit << 6 (P010)", (torch.randint(0, 1024, (n, h, w), dtype=torch.int32, device="cuda") << 6).to(torch.int16)),
          ("12-bit << 4 (MSB-aligned)", (torch.randint(0, 4096, (n, h, w), dtype=torch.int32, device="cuda") << 4).to(torch.int16)),
          ("12-bit, black bars at level 256", "bars"),
