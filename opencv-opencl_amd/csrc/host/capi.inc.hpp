@@ -117,7 +117,7 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
     // context never does, and every stream a process creates competes for the runtime's few hardware queues, see pipe_stream_create)
     {   // one line of pinned, device-writable host memory: the finish kernel of the fused path reports repaired launches into it
         void* q = nullptr;
-        if (hipHostMalloc(&q, 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+        if (hipHostMalloc(&q, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
             || hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (q) (void)hipHostFree(q);
@@ -126,7 +126,7 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
             return MI_ERR_HIP;
         }
         c->h_mirror = (uint32_t*)q;
-        memset(c->h_mirror, 0, 128);
+        memset(c->h_mirror, 0, 256);                             // [0..31] the fused path's words, [32..33] the 16-bit CLAHE's wide-content hint
     }
     // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
@@ -293,7 +293,7 @@ mi_status mi_ctx_set_option(mi_ctx* c, const char* name, int value)
     if (!strcmp(name, "clahe_float_tables")) { c->clahe_float_tables = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe16_fast12")) { c->clahe16_fast12 = value != 0; return MI_OK; }
     if (!strcmp(name, "clahe16_transposed")) { c->clahe16_transposed = value != 0; return MI_OK; }
-    if (!strcmp(name, "clahe16_wide")) { c->clahe16_wide = value != 0; return MI_OK; }
+    if (!strcmp(name, "clahe16_wide")) { c->clahe16_wide = value < 0 ? 0 : (value > 2 ? 2 : value); return MI_OK; }
     if (!strcmp(name, "pipe_copy_streams")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "pipe_copy_streams must be 1 or 2"); c->pipe_copy_streams = value; return MI_OK; }
     if (!strcmp(name, "host_copy_streams")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "host_copy_streams must be 1 or 2"); c->host_copy_streams = value; return MI_OK; }
     if (!strcmp(name, "host_copy_threads")) { if (value < 1 || value > 2) return fail(c, MI_ERR_BAD_ARG, "host_copy_threads must be 1 or 2"); c->host_copy_threads = value; return MI_OK; }

@@ -148,14 +148,16 @@ __device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u
 template <int kWinBits, int NT = 1024>
 __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinBits] LDS */, uint32_t& s_lo, uint32_t& s_hi, uint32_t& s_or,
                                                     const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                    const ClaheGeom& g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
+                                                    const ClaheGeom& g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec,
+                                                    int tile_of_item = -1, int frame_of_item = 0, int tiles_of_grid = 0)
 {
     constexpr int kWin = 1 << kWinBits;
     const int t = threadIdx.x;
-    const int tile = blockIdx.x, f = blockIdx.y;
+    // (tile, frame) = the workgroup's position in a (tiles, frames) grid, or given by a persistent caller (tile_hist16p_kernel)
+    const int tile = tile_of_item >= 0 ? tile_of_item : (int)blockIdx.x, f = tile_of_item >= 0 ? frame_of_item : (int)blockIdx.y;
     const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const uint8_t* src = src_base + (long long)f * frame_stride;
-    const size_t tile_id = (size_t)f * gridDim.x + tile;
+    const size_t tile_id = (size_t)f * (tile_of_item >= 0 ? (unsigned)tiles_of_grid : gridDim.x) + tile;
     uint32_t* out = hist + tile_id * kHist16;
     const long long items = (long long)g.tile_h * g.tile_w;
     const int drow = NT / g.tile_w, dcol = NT - drow * g.tile_w;
@@ -309,6 +311,32 @@ constexpr uint32_t kHistCompressed = 0x40000000u;   // Range16.hi of a tile: its
 constexpr uint32_t kWideTodo = 0x20000000u;         // Range16.hi of a tile: it lost tile_hist12_kernel's bet and was LEFT to tile_hist16p_kernel (clahe16_wide.hip.h)
 constexpr uint32_t kLutFull = 0x10000000u;          // Range16.hi of a tile: tile_hist16p_kernel wrote its LUT over all 65536 values, raw domain (shift 0)
 constexpr int kBins12 = 4096;
+// "Wide content was seen": what lets the HOST decide, without waiting for anything, whether a call should launch round 6's two
+// kernels for content wider than 8192 values (clahe16_wide.hip.h) -- on 12-bit content each of those launches, 256 workgroups with
+// 128 KiB of LDS that look at a few words and leave, cost 7 us of a 190 us call.  A kernel that meets such content (word 0: a tile
+// that lost the 12-bit bet at once on values of more than 14 bits; word 1: a rectangle whose range needs more than one window of
+// the small table) stamps the call's sequence number into a device word, and the first workgroup of the call to do so also into a
+// word of pinned host memory, which the next calls read.  A hint: what a call launches never changes a byte of its result.
+struct WideHint { uint32_t* dev; uint32_t* host; uint32_t seq; };
+__device__ __forceinline__ void wide_seen(const WideHint& h, int which)      // one lane
+{
+    if (!h.dev) return;
+    if (__hip_atomic_exchange(h.dev + which, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != h.seq)
+        __hip_atomic_store(h.host + which, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Which interpolation kernel does a rectangle belong to when clahe_interp16_acc_kernel runs beside clahe_interp16_kernel (both ask
+// this, with the same numbers)?  [lo4, hi]: the range of the rectangle's four tiles in the frame's domain, lo4 rounded down to a
+// multiple of four.  Up to 8192 values: the small table, one window.  Up to 16384: ONE window of the large table.  Beyond: the large
+// table's windows if one of the four tiles was written by tile_hist16p_kernel (dense wide content), or if the call is in place (the
+// small table's several windows re-read their pixels); a 12-bit rectangle with a hot pixel keeps the small table's windows, which
+// skip the empty ones.
+constexpr int kInterp16AccEntries = 16384;
+__device__ __forceinline__ bool rect_goes_wide(uint32_t lo4, uint32_t hi, bool any_lut_full, bool in_place)
+{
+    const uint32_t span = hi - lo4;
+    if (span < 8192u) return false;
+    return span < (uint32_t)kInterp16AccEntries || any_lut_full || in_place;
+}
 // Shipped shape: 1024 threads, 4 copies = 64 KiB of LDS, two workgroups per CU.  512 threads x 2 copies (32 KiB, four workgroups per
 // CU) measured the same on 12-bit content (16 4K frames: 59.6 us alone either way; the sweep on its own 45 us either way,
 // tools/hist12_probe.hip) and leaves the careful path half the counters per sweep, so the larger shape stays.
@@ -368,7 +396,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
                                                         ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
                                                         float lut_scale16, int clip16, uint16_t* __restrict__ luts,
                                                         uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done,
-                                                        uint32_t* __restrict__ shift_hint, int defer_wide)
+                                                        uint32_t* __restrict__ shift_hint, int defer_wide, WideHint wide_hint)
 {
     static_assert(COPIES == 2 || COPIES == 4, "copies");
     constexpr int NW = NT / 64, BPT = kBins12 / NT;                // waves; bins per thread
@@ -442,6 +470,12 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
     const uint32_t sft = (uint32_t)__builtin_amdgcn_readfirstlane((int)sft_v);       // in SGPRs: the sweep has no VGPR to spare
     const uint32_t wl = min(12u, 16u - sft);
     bool lost = (o16 >> sft) >= (uint32_t)kBins12;                  // uniform
+    // Lost at once, on values of more than 14 bits that are not all even: dense wide content in the raw domain, what tile_hist16p_kernel
+    // is for (one sweep instead of two to four).  Up to 14 bits the careful path needs ONE sweep and runs two workgroups per CU; samples
+    // in the high bits of the word (even values) keep its compressed domain; a tile that loses LATE holds an outlier (a hot pixel), and
+    // the careful path sweeps only the windows that hold something.
+    const bool early_wide = lost && o16 >= 16384u && (o16 & 1u);
+    if (early_wide && t == 0) wide_seen(wide_hint, 0);
     if (!lost) {
         uint32_t por = 0;
         for (int it = t; it < vitems; it += 4 * NT) {
@@ -501,10 +535,11 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
         }
         frame_ranges[f] = r;
         // 2: EVERY tile of the frame lost its bet and was left to tile_hist16p_kernel, whose last tile then settles the frame
-        frame_done[f] = done ? 1u : (defer_wide && nd == 0u ? 2u : 0u);
+        // ... 3: SOME tiles were; 0: none was (bets held with different shifts, or nothing is deferred)
+        frame_done[f] = done ? 1u : (defer_wide && nd < gridDim.x ? (nd == 0u ? 2u : 3u) : 0u);
         if (done) hint_out(shift_hint, (uint32_t)__builtin_ctz(shifts));
     };
-    if (lost && defer_wide) {
+    if (early_wide && defer_wide) {
         // uniform over the workgroup: the tile holds values that do not fit 4096 bins at any shift.  It is left, marked, to
         // tile_hist16p_kernel, which follows on the same grid with 128 KiB of LDS: one sweep over 65536 packed counters, LUT folded in
         if (t == 0) { Range16 r; r.lo = 0u; r.hi = kWideTodo; ranges[tile_id] = r; arrive(false, 0u, 0u); settle_frame(); }
@@ -795,7 +830,8 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                                                                          uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                          ClaheGeom g, const uint16_t* __restrict__ luts,
                                                                          const Range16* __restrict__ frame_ranges, int subs, int n_frames,
-                                                                         const Range16* __restrict__ tile_ranges, uint32_t* shift_hint, int skip_multi)
+                                                                         const Range16* __restrict__ tile_ranges, uint32_t* shift_hint, int skip_multi,
+                                                                         WideHint wide_hint)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 tab[];      // [kInterp16Entries] {a | b << 16, c | d << 16}
     const int t = threadIdx.x;
@@ -831,19 +867,22 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     // cannot be done in place: in-place calls on a FRAME with a wide range are left to clahe_interp16_wide_kernel, whole.
     // (skip_multi: clahe_interp16_acc_kernel runs beside this one and takes every rectangle whose OWN range needs more than one
     // window, in place or not; this kernel then keeps the single-window rectangles of such frames, which are safe in place)
-    if (!skip_multi && fr.hi - (fr.lo & ~3u) >= (uint32_t)kInterp16Entries && src_base == dst_base) return;
+    if (!skip_multi && fr.hi - (fr.lo & ~3u) >= (uint32_t)kInterp16Entries && src_base == dst_base) { if (t == 0) wide_seen(wide_hint, 1); return; }
     // The table only has to cover the values this workgroup's pixels can have: they lie in (at most) the four tiles whose LUTs it blends,
     // so the union of THOSE tiles' ranges replaces the frame's (a hot pixel, a bright corner widen the table of their own rectangles
     // only; tile_lut16_kernel writes every LUT over its tile's 3 x 3 neighbourhood, which contains these four).
+    bool any_full;
     {
         const Range16* tr = tile_ranges + (size_t)f * g.tiles_x * g.tiles_y;
         const Range16 r00 = tr[ty1 * g.tiles_x + tx1], r01 = tr[ty1 * g.tiles_x + tx2], r10 = tr[ty2 * g.tiles_x + tx1], r11 = tr[ty2 * g.tiles_x + tx2];
         fr.lo = min(min(range_lo(r00.lo), range_lo(r01.lo)), min(range_lo(r10.lo), range_lo(r11.lo))) >> sft;
         fr.hi = max(max(range_hi(r00.hi), range_hi(r01.hi)), max(range_hi(r10.hi), range_hi(r11.hi))) >> sft;
+        any_full = ((r00.hi | r01.hi | r10.hi | r11.hi) & kLutFull) != 0u;
     }
     const uint32_t start = fr.lo & ~3u;
     const bool multi = fr.hi - start >= (uint32_t)kInterp16Entries;
-    if (multi && skip_multi) return;                                // uniform: clahe_interp16_acc_kernel's rectangle
+    if (multi && t == 0) wide_seen(wide_hint, 1);
+    if (skip_multi && rect_goes_wide(start, fr.hi, any_full, src_base == dst_base)) return;      // uniform: clahe_interp16_acc_kernel's rectangle
     // A range of at most kInterp16F32Entries values (every 12-bit source) gets the table as FLOATS, {a, c, b, d} in 16 bytes: one
     // ds_read_b128 per pixel feeds v_pk_mul / v_pk_add directly and the four ushort -> float conversions per pixel are gone
     // (the blend was VALU-bound: ~25 instructions per pixel, now ~12).  Same 64 KiB of LDS either way.

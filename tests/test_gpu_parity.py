@@ -1177,7 +1177,9 @@ def test_clahe16_wide_content_one_sweep_and_register_held_interpolation(ctx):
     for cfg in ((2.0, 8, 8), (40.0, 8, 8)):
         want = [oracle.clahe16(f, *cfg) for f in frames]
         try:
-            for wide in (1, 0):
+            # 2: the wide kernels are always launched; 0: never (the round-3 paths); 1 (the default): when the context's last calls met wide
+            # content -- the first such call runs the round-3 paths, the pinned hint word turns, the following ones run the new kernels
+            for wide in (2, 0, 1, 1, 1):
                 ctx.set_option("clahe16_wide", wide)
                 d_in = dev(np.stack(frames).view(np.int16))
                 d_out = torch.zeros_like(d_in)
@@ -1195,8 +1197,11 @@ def test_clahe16_wide_content_one_sweep_and_register_held_interpolation(ctx):
                 del d_in
         finally:
             ctx.set_option("clahe16_wide", 1)
-    # other tile grids: tiles too small to wrap a counter, a grid with more pairs than a workgroup has row phases, one tile
-    for (cw, chh, tx, ty) in [(640, 368, 8, 8), (1280, 96, 16, 2), (512, 512, 1, 1), (1024, 64, 2, 4)]:
+    # other tile grids: tiles too small to wrap a counter, a grid with more pairs than a workgroup has row phases, one tile, and one
+    # whose pair edges do not fall on multiples of eight pixels (1000 / 5 = 200-pixel tiles: edges at 100 + 200 k) -- that one keeps the
+    # round-3 interpolation whatever the option says
+    ctx.set_option("clahe16_wide", 2)
+    for (cw, chh, tx, ty) in [(640, 368, 8, 8), (1280, 96, 16, 2), (512, 512, 1, 1), (1024, 64, 2, 4), (1000, 120, 5, 3)]:
         fs = [rng.integers(0, 65536, (chh, cw), dtype=np.uint16), rng.integers(0, 16384, (chh, cw), dtype=np.uint16),
               rng.integers(20000, 45000, (chh, cw), dtype=np.uint16)]
         fs.append(fs[0].copy()); fs[-1][: chh // 2] = 4242                                 # flat half: wave-uniform vectors
@@ -1211,6 +1216,7 @@ def test_clahe16_wide_content_one_sweep_and_register_held_interpolation(ctx):
             ctx.clahe16_batch_dev(d_in, d_in, cw, chh, len(fs), clip, tx, ty)
             ctx.synchronize()
             assert np.array_equal(host(d_in).view(np.uint16), out), (cw, chh, tx, ty, clip, "in place")
+    ctx.set_option("clahe16_wide", 1)
 
 
 def test_clahe16_frame_done_flags_over_many_frames(ctx):
@@ -1241,6 +1247,25 @@ def test_clahe16_frame_done_flags_over_many_frames(ctx):
         ctx.clahe16_batch_dev(d_in, d_in, w, h, n, 2.0, 8, 8)
         ctx.synchronize()
         assert np.array_equal(host(d_in).view(np.uint16), want[:n]), (n, "in place")
+
+
+def test_clahe16_suite_again_with_the_wide_kernels_always_launched(ctx):
+    """With the option at its default the wide kernels are launched only after wide content was seen (a hint in pinned memory), so which
+    kernels the tests above ran depends on their order.  Here every one of them runs again with the kernels ALWAYS launched: small
+    frames, mixed batches (frames whose tiles were all / partly / not at all left to the one-sweep kernel), MSB-aligned content,
+    hot pixels, 150-frame calls."""
+    try:
+        ctx.set_option("clahe16_wide", 2)
+        for cfg in [(2.0, 8, 8), (40.0, 3, 5), (0.0, 4, 4)]:
+            test_clahe16_value_ranges(ctx, cfg)
+        test_clahe16_twelve_bit_bet_mixed_outcomes(ctx)
+        test_clahe16_msb_aligned_content(ctx)
+        test_clahe16_tables_follow_the_local_range(ctx)
+        test_clahe16_frame_done_flags_over_many_frames(ctx)
+        for shape in [(270, 480), (360, 640)]:
+            test_clahe16(ctx, shape, (2.0, 8, 8))
+    finally:
+        ctx.set_option("clahe16_wide", 1)
 
 
 def test_clahe16_batch_and_errors(ctx):
