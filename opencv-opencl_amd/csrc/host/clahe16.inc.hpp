@@ -4,7 +4,7 @@
 // ---- CLAHE on CV_16UC1 ----------------------------------------------------------------------
 namespace {
 
-constexpr int kWideHintWord = 32;          // h_mirror[32], [33]: sequence number of the last call that met wide content (tile histograms, interpolation)
+constexpr int kWideHintWord = 32;          // h_mirror[32], [33]: sequence number of the last call that met wide content (tile histograms, interpolation); [34]: of the last call executed
 constexpr uint32_t kWideHintCalls = 8;     // ... and for how many calls after it the wide kernels are still launched
 
 // clahe_interp16_acc_kernel takes whole 8-pixel groups only: every group [8k, 8k + 8) of a row must lie inside the frame and belong
@@ -73,8 +73,10 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         // sees 10 / 12-bit content never launches them; 2 = always (tests), 0 = never.
         const uint32_t seq = ++c->c16_seq;
         WideHint wh{c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 2, c->h_mirror + kWideHintWord, seq};
-        auto recent = [&](int which) {
-            return c->clahe16_wide >= 2 || (c->clahe16_wide == 1 && seq - __atomic_load_n(c->h_mirror + kWideHintWord + which, __ATOMIC_RELAXED) <= kWideHintCalls);
+        auto recent = [&](int which) {       // the last call that met wide content lies at most kWideHintCalls EXECUTED calls back
+            const uint32_t executed = __atomic_load_n(c->h_mirror + kWideHintWord + 2, __ATOMIC_RELAXED);
+            // (signed: the wide stamp of the call being executed right now is AHEAD of "executed", which that call's LUT kernel writes)
+            return c->clahe16_wide >= 2 || (c->clahe16_wide == 1 && (int32_t)(executed - __atomic_load_n(c->h_mirror + kWideHintWord + which, __ATOMIC_RELAXED)) <= (int32_t)kWideHintCalls);
         };
         const bool wide_hist = bet12 && recent(0);
         const bool wide_interp = c->clahe16_wide && !(tiles <= 64 && c->clahe16_transposed) && nf <= 1024 && recent(1) &&
@@ -95,7 +97,7 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
                    c->d_sync16, franges, fdone, hint, tiles, nf);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, (const Range16*)ranges, g,
-               lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr), hint);
+               lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr), hint, wh);
         if (tiles <= 64 && c->clahe16_transposed) {
             // value-major LUTs (one cache line per pixel value): transposed into the histogram area, which is dead by now
             uint16_t* lutT = reinterpret_cast<uint16_t*>(hist);

@@ -316,11 +316,16 @@ constexpr int kBins12 = 4096;
 // 128 KiB of LDS that look at a few words and leave, cost 7 us of a 190 us call.  A kernel that meets such content (word 0: a tile
 // that lost the 12-bit bet at once on values of more than 14 bits; word 1: a rectangle whose range needs more than one window of
 // the small table) stamps the call's sequence number into a device word, and the first workgroup of the call to do so also into a
-// word of pinned host memory, which the next calls read.  A hint: what a call launches never changes a byte of its result.
+// word of pinned host memory, which the next calls read; tile_lut16_kernel, part of every call, stamps the number into host word 2
+// ("executed so far"), and the host launches the wide kernels while the last wide call lies at most eight EXECUTED calls back -- counted
+// in the device's progress, not the host's: a caller that enqueues twenty calls ahead must not see its own hint expire.
+// A hint: what a call launches never changes a byte of its result.
 struct WideHint { uint32_t* dev; uint32_t* host; uint32_t seq; };
 __device__ __forceinline__ void wide_seen(const WideHint& h, int which)      // one lane
 {
     if (!h.dev) return;
+    // (look before exchanging: a thousand workgroups exchanging on one word cost a call 100 us; a thousand loads of it cost nothing)
+    if (__hip_atomic_load(h.dev + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h.seq) return;
     if (__hip_atomic_exchange(h.dev + which, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != h.seq)
         __hip_atomic_store(h.host + which, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -534,15 +539,18 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
             r.hi = min(((((31u - (uint32_t)__builtin_clz(buckets)) << 8) | 255u) << fs), 0xffffu) | (fs << 16);
         }
         frame_ranges[f] = r;
-        // 2: EVERY tile of the frame lost its bet and was left to tile_hist16p_kernel, whose last tile then settles the frame
-        // ... 3: SOME tiles were; 0: none was (bets held with different shifts, or nothing is deferred)
-        frame_done[f] = done ? 1u : (defer_wide && nd < gridDim.x ? (nd == 0u ? 2u : 3u) : 0u);
+        frame_done[f] = done ? 1u : 0u;                              // (tile_hist16p_kernel turns it to 1 for a frame whose tiles were ALL left to it)
         if (done) hint_out(shift_hint, (uint32_t)__builtin_ctz(shifts));
     };
     if (early_wide && defer_wide) {
         // uniform over the workgroup: the tile holds values that do not fit 4096 bins at any shift.  It is left, marked, to
         // tile_hist16p_kernel, which follows on the same grid with 128 KiB of LDS: one sweep over 65536 packed counters, LUT folded in
-        if (t == 0) { Range16 r; r.lo = 0u; r.hi = kWideTodo; ranges[tile_id] = r; arrive(false, 0u, 0u); settle_frame(); }
+        // (how many of a frame's tiles were left: bits 48..63 of the frame's SECOND arrival word, which is tile_hist16p_kernel's)
+        if (t == 0) {
+            Range16 r; r.lo = 0u; r.hi = kWideTodo; ranges[tile_id] = r;
+            __hip_atomic_fetch_add(sy + 1, 1ull << 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrive(false, 0u, 0u); settle_frame();
+        }
         return;
     }
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
@@ -666,8 +674,10 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
 //     sum over bins <= b  =  (clipped counts of the populated bins <= b)  +  batch * (b + 1)  +  min(residual, b / rstep + 1).
 __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __restrict__ hist, const Range16* __restrict__ ranges, ClaheGeom g,
                                                          float lut_scale16, int clip16, uint16_t* __restrict__ luts, Range16* __restrict__ frame_ranges,
-                                                         const uint32_t* __restrict__ frame_done, uint32_t* __restrict__ shift_hint)
+                                                         const uint32_t* __restrict__ frame_done, uint32_t* __restrict__ shift_hint, WideHint wide_hint)
 {
+    if (wide_hint.host && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)       // "this call has been executed": see WideHint
+        __hip_atomic_store(wide_hint.host + 2, wide_hint.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // tile_hist12_kernel has written every LUT of this frame (bins 0..4095: all anybody reads) and the frame's range: one scalar load
     if (frame_done && frame_done[blockIdx.y] == 1u) return;
     __shared__ uint32_t s_w[16];

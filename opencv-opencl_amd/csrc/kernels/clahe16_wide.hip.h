@@ -58,11 +58,13 @@ __device__ __forceinline__ void hist16p_vec(uint32_t* h, const u32x4& q)
 // work items are (tile, frame) pairs.  Vector geometry only: tile_hist12_kernel ran before it and left the tiles that lost its bet
 // marked kWideTodo, and frame_done[f] says whether a frame has any (2: all of its tiles, 3: some) -- frames without are skipped on one
 // scalar load, so on 12-bit content this launch is 256 workgroups that look at a few words.
-// `sync`: the per-frame 64-bit word NEXT to tile_hist12_kernel's (zero between launches): bits 0..15 arrivals, 16..31 tiles that
-// wrote their LUT here, 32..47 which 4096-value buckets hold a tile's lowest / highest value.  Used only for frames in which EVERY
-// tile was left to this kernel (frame_done == 2): their last tile to arrive settles the frame's range and frame_done = 1, so that
-// tile_lut16_kernel leaves such frames on one scalar load.  Mixed frames go through tile_lut16_kernel, which returns early for the
-// tiles written here (kLutFull) and extends the LUTs of their 12-bit neighbours from the neighbours' own histograms.
+// `sync`: the per-frame 64-bit word NEXT to tile_hist12_kernel's (zero between launches): bits 48..63 how many of the frame's tiles
+// tile_hist12_kernel left to this kernel (complete when this kernel starts), bits 0..15 how many of them have arrived, 16..31 how many
+// wrote their LUT here, 32..47 which 4096-value buckets hold a tile's lowest / highest value.  A frame without left tiles is skipped
+// on one scalar load.  The last left tile of a frame to arrive zeroes the word; if EVERY tile of the frame was left and all of them
+// wrote their LUT here, it also settles the frame's range and frame_done = 1, so that tile_lut16_kernel leaves such frames on one scalar
+// load.  Mixed frames go through tile_lut16_kernel, which returns early for the tiles written here (kLutFull) and extends the LUTs of
+// their neighbours from the neighbours' own histograms.
 __global__ __launch_bounds__(kWideThreads) void tile_hist16p_kernel(const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
                                                                    ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
                                                                    float lut_scale16, int clip16, uint16_t* __restrict__ luts,
@@ -80,8 +82,9 @@ __global__ __launch_bounds__(kWideThreads) void tile_hist16p_kernel(const uint8_
     const int vitems = g.tile_h * slots;
     for (long long id = blockIdx.x; id < (long long)tiles * n_frames; id += gridDim.x) {
     const int f = (int)(id / tiles), tile = (int)(id - (long long)f * tiles);
-    const uint32_t fd = frame_done[f];
-    if (fd != 2u && fd != 3u) continue;                             // uniform: no tile of this frame was left to this kernel
+    unsigned long long* const sy = reinterpret_cast<unsigned long long*>(sync) + 2 * (size_t)f + 1;
+    const uint32_t left = (uint32_t)(__hip_atomic_load(sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 48);
+    if (left == 0u) continue;                                       // uniform: no tile of this frame was left to this kernel
     const size_t tile_id = (size_t)f * tiles + tile;
     if (!(ranges[tile_id].hi & kWideTodo)) continue;                // uniform: not a tile that was left to this kernel
     const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
@@ -155,17 +158,14 @@ __global__ __launch_bounds__(kWideThreads) void tile_hist16p_kernel(const uint8_
         if (k < wv) before += a - e;                                // clipped counts of the values below this wave's
         if (a) mask |= 1u << k;
     }
-    unsigned long long* const sy = reinterpret_cast<unsigned long long*>(sync) + 2 * (size_t)f + 1;
-    const bool frame_mine = fd == 2u;                               // every tile of the frame is here: the last one settles it
     auto arrive_and_settle = [&](bool ok, uint32_t lo, uint32_t hi) {   // thread 0
-        if (!frame_mine) return;
         const uint32_t bits = ok ? (1u << (lo >> 12)) | (1u << (hi >> 12)) : 0u;
         if (ok) __hip_atomic_fetch_or(sy, (unsigned long long)bits << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long b64 = __hip_atomic_fetch_add(sy, ok ? 0x10001ull : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(b64 & 0xffffu) != (uint32_t)tiles - 1u) return;
+        if ((uint32_t)(b64 & 0xffffu) != left - 1u) return;         // not the last of the frame's left tiles
         __hip_atomic_store(sy, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t nd = (uint32_t)((b64 >> 16) & 0xffffu) + (ok ? 1u : 0u);
-        if (nd != (uint32_t)tiles) { frame_done[f] = 0u; return; }  // some tile fell back: tile_lut16_kernel does the frame
+        if (left != (uint32_t)tiles || nd != (uint32_t)tiles) return;   // a mixed frame, or a tile fell back: tile_lut16_kernel does the frame
         const uint32_t buckets = ((uint32_t)(b64 >> 32) | bits) & 0xffffu;
         Range16 r;
         r.lo = (uint32_t)__builtin_ctz(buckets) << 12;
