@@ -37,10 +37,10 @@
 #define MI_OPT_CLAHE16_FAST12      "clahe16_fast12"      /* 1/0, default 1: tile histograms bet on values < 4096 (4096 bins x 4 LDS copies,
                                                            * LUT folded in); a tile that loses the bet is redone with 16 384 counters   */
 #define MI_OPT_CLAHE16_TRANSPOSED  "clahe16_transposed"  /* 1/0, default 0: value-major LUT layout for the 16-bit interpolation       */
-#define MI_OPT_CLAHE16_WIDE        "clahe16_wide"        /* 1/0, default 1: content wider than 8192 values (14-bit sensors, full-range
-                                                           * words, a hot pixel): tiles that lose the 12-bit bet are swept ONCE into 65 536
-                                                           * packed 16-bit counters with the LUT folded in, and the interpolation holds its
-                                                           * pixels in registers over all table windows; 0 = the round-3 paths         */
+#define MI_OPT_CLAHE16_WIDE        "clahe16_wide"        /* 0/1/2, default 1: rectangles whose range needs 8193..16384 table entries (14-bit
+                                                           * sensors) are interpolated by a kernel with ONE 128-KiB table window instead of two
+                                                           * windows of the 64-KiB table; 1 = launched while such content was seen in the
+                                                           * context's last calls, 2 = always, 0 = never                                 */
 
 /* colour neighbours */
 #define MI_OPT_BGR_FUSED           "bgr_fused"           /* 1/0, default 1: mi_bgr_luma_op_u8c3 as two passes over the interleaved

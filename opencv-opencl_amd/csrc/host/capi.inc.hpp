@@ -126,14 +126,16 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
             return MI_ERR_HIP;
         }
         c->h_mirror = (uint32_t*)q;
-        memset(c->h_mirror, 0, 256);                             // [0..31] the fused path's words, [32..34] the 16-bit CLAHE's wide-content hint
-        c->h_mirror[34] = c->c16_seq;                            // "executed so far" starts far ahead of "wide content last seen" (0): no wide kernels at first
+        memset(c->h_mirror, 0, 256);                             // [0..31] the fused path's words, [32..33] the 16-bit CLAHE's 14-bit-content hint
+        c->h_mirror[33] = c->c16_seq;                            // "executed so far" starts far ahead of "such content last seen" (0): no mid kernel at first
     }
     // the 16-bit tile histogram uses 128 KiB of dynamic LDS (above the 64 KiB default limit)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHalf16 * (int)sizeof(uint32_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_hist12_kernel<kHist12Threads, kCopies12>), hipFuncAttributeMaxDynamicSharedMemorySize, kHist12Words * (int)sizeof(uint32_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16Entries * (int)sizeof(uint2));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16Entries * (int)sizeof(uint2));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_mid_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16MidEntries * (int)sizeof(uint2));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clahe_interp16_mid_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kInterp16MidEntries * (int)sizeof(uint2));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount;
     if (device < kMaxDevices) {

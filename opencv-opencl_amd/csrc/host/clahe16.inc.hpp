@@ -4,27 +4,8 @@
 // ---- CLAHE on CV_16UC1 ----------------------------------------------------------------------
 namespace {
 
-constexpr int kWideHintWord = 32;          // h_mirror[32], [33]: sequence number of the last call that met wide content (tile histograms, interpolation); [34]: of the last call executed
-constexpr uint32_t kWideHintCalls = 8;     // ... and for how many calls after it the wide kernels are still launched
-
-// clahe_interp16_acc_kernel takes whole 8-pixel groups only: every group [8k, 8k + 8) of a row must lie inside the frame and belong
-// to ONE tile pair -- decided with the interpolation's own float expression (kernels/clahe.hip.h tile_coord: p * inv - 0.5, one FMA
-// in the contracted mode), evaluated here exactly as the device evaluates it (this file is built with -ffp-contract=off).  True for 4K,
-// 1080p and 720p at 8x8; other geometries keep the round-3 interpolation.
-bool acc_geometry_ok(const ClaheGeom& g)
-{
-    if (g.width % 8 != 0) return false;
-    if ((g.tile_w + 2 * kBandMargin + 7) / 8 + 1 > kAccThreads) return false;          // a pair's groups: one lane each
-    auto pair_of = [&](int x) {
-        const float txf = g.contract ? std::fmaf((float)x, g.inv_tw, -0.5f) : ((float)x * g.inv_tw) - 0.5f;
-        const int i = (int)txf;
-        int q = i - ((float)i > txf) + 1;                                                // cvFloor + 1
-        return q < 0 ? 0 : (q > g.tiles_x ? g.tiles_x : q);
-    };
-    for (int x0 = 0; x0 < g.width; x0 += 8)
-        if (pair_of(x0) != pair_of(x0 + 7)) return false;                                // (monotone: equal ends, equal in between)
-    return true;
-}
+constexpr int kWideHintWord = 32;          // h_mirror[32]: sequence number of the last call that met a 14-bit rectangle; [33]: of the last call executed
+constexpr int32_t kWideHintCalls = 8;      // ... and for how many executed calls after it clahe_interp16_mid_kernel is still launched
 
 mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_step, size_t src_frame, uint8_t* dst, size_t dst_step,
                       size_t dst_frame, int width, int height, int n_frames, double clip_limit, int tiles_x, int tiles_y)
@@ -64,38 +45,29 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         Range16* franges = ranges + (size_t)nf * tiles;
         uint32_t* fdone = reinterpret_cast<uint32_t*>(franges + nf);
         const bool bet12 = vec && c->clahe16_fast12;
-        // Content wider than 8192 values (round 6, kernels/clahe16_wide.hip.h): tiles that lose the 12-bit bet are left to a one-sweep
-        // kernel with 65536 packed counters, and the interpolation's wide rectangles to a kernel that holds its pixels in registers
-        // over all table windows.  Both need 16-byte aligned planes and pitches (what `vec` asks of the source; the interpolation
-        // also of the destination); option "clahe16_wide" = 0 keeps the round-3 paths (careful sweeps, pixel re-reads per window).
-        // ... Each of the two costs a launch (7 us of a 12-bit call's 190) whether or not it finds work, so with the option at its default
-        // (1 = when wide content was seen in one of the context's last calls: kernels/clahe16.hip.h WideHint) a context that only ever
-        // sees 10 / 12-bit content never launches them; 2 = always (tests), 0 = never.
+        // Rectangles whose range needs 8193..16384 table entries (14-bit content) have a kernel of their own since round 6
+        // (clahe_interp16_mid_kernel: one window of a 128-KiB table).  Its launch costs ~8 us whether or not it finds work, so with the
+        // option at its default (1) it is launched only while such a rectangle was seen in one of the context's last executed calls
+        // (kernels/clahe16.hip.h WideHint); 2 = always (tests), 0 = never.  Out of place only: in place, frames with a wide range keep
+        // the gathering kernel, whole.
         const uint32_t seq = ++c->c16_seq;
-        WideHint wh{c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 2, c->h_mirror + kWideHintWord, seq};
-        auto recent = [&](int which) {       // the last call that met wide content lies at most kWideHintCalls EXECUTED calls back
-            const uint32_t executed = __atomic_load_n(c->h_mirror + kWideHintWord + 2, __ATOMIC_RELAXED);
-            // (signed: the wide stamp of the call being executed right now is AHEAD of "executed", which that call's LUT kernel writes)
-            return c->clahe16_wide >= 2 || (c->clahe16_wide == 1 && (int32_t)(executed - __atomic_load_n(c->h_mirror + kWideHintWord + which, __ATOMIC_RELAXED)) <= (int32_t)kWideHintCalls);
-        };
-        const bool wide_hist = bet12 && recent(0);
-        const bool wide_interp = c->clahe16_wide && !(tiles <= 64 && c->clahe16_transposed) && nf <= 1024 && recent(1) &&
-                                 (((uintptr_t)src | (uintptr_t)dst | src_step | dst_step | src_frame | dst_frame) & 15) == 0 && acc_geometry_ok(g);
+        const WideHint wh{c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 2, c->h_mirror + kWideHintWord, seq};
+        const bool mid_recent = c->clahe16_wide >= 2 ||
+            (c->clahe16_wide == 1 && (int32_t)(__atomic_load_n(c->h_mirror + kWideHintWord + 1, __ATOMIC_RELAXED) -
+                                               __atomic_load_n(c->h_mirror + kWideHintWord, __ATOMIC_RELAXED)) <= kWideHintCalls);
+        // (signed: the stamp of the call being executed right now is AHEAD of "executed", which that call's LUT kernel writes)
+        const bool mid_runs = mid_recent && nf <= 1024 && !(tiles <= 64 && c->clahe16_transposed) &&
+                              src + (size_t)f0 * src_frame != dst + (size_t)f0 * dst_frame;
         // the context's shift hint: two words at the end of the arrival scratch (read / collect, rolled over by the interpolation kernel)
         uint32_t* hint = bet12 ? c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 4 : nullptr;
         // 12-bit bet (kernels/clahe16.hip.h): vector geometry only; a tile that loses it is redone the careful way in the same workgroup
         if (bet12)
             LAUNCH(c, s, MI_K_TILE_HIST, (tile_hist12_kernel<kHist12Threads, kCopies12>), dim3(tiles, nf), dim3(kHist12Threads), kHist12Words * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
-                   c->d_sync16, franges, fdone, hint, wide_hist ? 1 : 0, wh);
+                   c->d_sync16, franges, fdone, hint);
         else
             LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16_kernel, dim3(tiles, nf), dim3(1024), kHalf16 * sizeof(uint32_t),
                    src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, vec);
-        if (wide_hist)
-            LAUNCH(c, s, MI_K_TILE_HIST, tile_hist16p_kernel, dim3((unsigned)std::min<long long>((long long)tiles * nf, std::max(c->cu_count, 8))),
-                   dim3(kWideThreads), kWideWords * sizeof(uint32_t),
-                   src + (size_t)f0 * src_frame, (long long)src_step, (long long)src_frame, g, hist, ranges, lut_scale16, clip16, luts,
-                   c->d_sync16, franges, fdone, hint, tiles, nf);
         LAUNCH(c, s, MI_K_TILE_LUT, tile_lut16_kernel, dim3(tiles, nf), dim3(1024), 0, (const uint32_t*)hist, (const Range16*)ranges, g,
                lut_scale16, clip16, luts, franges, (const uint32_t*)(bet12 ? fdone : nullptr), hint, wh);
         if (tiles <= 64 && c->clahe16_transposed) {
@@ -125,36 +97,27 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<true>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
                        dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint,
-                       wide_interp ? 1 : 0, wh);
+                       mid_runs ? 1 : 0, wh);
             else
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_kernel<false>, dim3((unsigned)grid), dim3(kInterp16Threads),
                        (size_t)kInterp16Entries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
                        dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint,
-                       wide_interp ? 1 : 0, wh);
-            if (wide_interp) {
-                // rectangles whose four tiles populate 8192 values or more.  A workgroup walks its item in blocks of the rows it holds
-                // (kAccRows per lane) and a one-window rectangle stages its table once per item, so items are COARSE: two sub-bands per
-                // band, more only while the launch has fewer than two items per CU (few frames)
-                const long long per_sub_acc = (long long)npairs * bands * nf;
-                const int subs_acc = (int)std::max<long long>(1, std::min<long long>({std::max<long long>(2, (2LL * c->cu_count + per_sub_acc - 1) / per_sub_acc),
-                                                                                      (long long)std::max(1, g.tile_h / 16), 16LL}));
-                const long long rows_acc = (long long)bands * subs_acc * nf;
-                const long long grid_acc = (rows_acc + 7) / 8 * 8 * npairs;
-                if (grid_acc > 0x7fffffffLL) return fail(c, MI_ERR_UNSUPPORTED, "16-bit CLAHE: tile grid too large");
-                // persistent: one workgroup per CU walks the items (a multiple of 8 workgroups, so that each stays on its XCD)
-                const long long grid_p = std::min<long long>(grid_acc, (long long)(std::max(c->cu_count, 8) + 7) / 8 * 8);
+                       mid_runs ? 1 : 0, wh);
+            if (mid_runs) {
+                // the same work items, walked by one persistent workgroup per CU (a multiple of 8 workgroups: each stays on its XCD)
+                const long long grid_p = std::min<long long>(grid, (long long)(std::max(c->cu_count, 8) + 7) / 8 * 8);
                 if (g.contract)
-                    LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_acc_kernel<true>, dim3((unsigned)grid_p), dim3(kAccThreads),
-                           (size_t)kAccEntries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                           dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs_acc, nf, (const Range16*)ranges);
+                    LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_mid_kernel<true>, dim3((unsigned)grid_p), dim3(kInterp16MidThreads),
+                           (size_t)kInterp16MidEntries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
+                           dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges);
                 else
-                    LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_acc_kernel<false>, dim3((unsigned)grid_p), dim3(kAccThreads),
-                           (size_t)kAccEntries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
-                           dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs_acc, nf, (const Range16*)ranges);
+                    LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_mid_kernel<false>, dim3((unsigned)grid_p), dim3(kInterp16MidThreads),
+                           (size_t)kInterp16MidEntries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
+                           dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges);
             }
             // IN-PLACE frames whose range does not fit the LDS table (their workgroups above returned at once); the launch is a no-op for
             // every other frame, and is left out altogether when the call is not in place (it cost 8 us per call)
-            if (sp == dp && !wide_interp) {
+            if (sp == dp) {
                 const long long wide_items = (long long)((width + kThreads - 1) / kThreads) * height;
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_wide_kernel, dim3((unsigned)std::min<long long>(wide_items, std::max(512, 2048 / nf)), 1, nf), dim3(kThreads), 0,
                        sp, (long long)src_step, (long long)src_frame, dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges);

@@ -33,6 +33,31 @@ constexpr int kHalf16 = 32768;
 constexpr int kInterp16F32Entries = 4096;                  // ... or 4096 entries of four floats
 constexpr int kInterp16Entries = 8192;               // LDS pair-table entries (64 KiB): two workgroups of 512 threads per CU
 constexpr int kInterp16Threads = 512;
+// ... and, since round 6, the same kernel body with a table TWICE that size for the rectangles whose range needs 8193..16384 entries
+// (14-bit sensors: thermal, medical -- every rectangle of such a frame): ONE window of 128 KiB and the vector path instead of two
+// windows of the small table and the scalar multi-window path (466 us -> see docs/experiments.md R6.3).  128 KiB of LDS is one
+// workgroup of 1024 threads per CU (the same 16 waves per CU), persistent: clahe_interp16_mid_kernel.
+constexpr int kInterp16MidEntries = 16384;
+constexpr int kInterp16MidThreads = 1024;
+// "A 14-bit rectangle was seen": what lets the HOST decide, without waiting for anything, whether a call should launch
+// clahe_interp16_mid_kernel -- on narrower content that launch, 256 workgroups with 128 KiB of LDS that look at a few words and
+// leave, costs ~8 us of a 12-bit call's 190.  A workgroup of clahe_interp16_kernel that meets such a rectangle stamps the call's
+// sequence number into a device word, and the first one of the call to do so also into word 0 of two words of pinned host memory;
+// tile_lut16_kernel, part of every call, stamps the number into host word 1 ("executed so far"); the host launches the mid kernel
+// while the last stamped call lies at most eight EXECUTED calls back (counted in the device's progress, not the host's: a caller
+// that enqueues twenty calls ahead must not see its own hint expire).  A hint: what a call launches never changes a byte of its result.
+struct WideHint { uint32_t* dev; uint32_t* host; uint32_t seq; };
+__device__ __forceinline__ void wide_seen(const WideHint& h)        // one lane
+{
+    if (!h.dev) return;
+    // (look before exchanging: a thousand workgroups exchanging on one word cost a call 100 us; a thousand loads of it cost nothing)
+    if (__hip_atomic_load(h.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h.seq) return;
+    if (__hip_atomic_exchange(h.dev, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != h.seq)
+        __hip_atomic_store(h.host, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// which rectangles are the mid kernel's when it runs beside clahe_interp16_kernel (both ask, with the same numbers): span = highest
+// value - lowest value rounded down to a multiple of four, in the frame's domain
+__device__ __forceinline__ bool rect_is_mid(uint32_t span) { return span >= (uint32_t)kInterp16Entries && span < (uint32_t)kInterp16MidEntries; }
 
 struct Range16 { uint32_t lo, hi; };                 // populated value range of a tile / frame (lo > hi: empty -- cannot happen, a tile has pixels)
 // hi carries more than the bound: bits 0..15 the highest value, bits 16..19 a SHIFT -- every value of the tile (frame) is a multiple
@@ -148,16 +173,14 @@ __device__ __forceinline__ void hist16_fast_vec(uint32_t* h16, const u32x4& q, u
 template <int kWinBits, int NT = 1024>
 __device__ __forceinline__ void tile_hist16_careful(uint32_t* h16 /* [1 << kWinBits] LDS */, uint32_t& s_lo, uint32_t& s_hi, uint32_t& s_or,
                                                     const uint8_t* __restrict__ src_base, long long step, long long frame_stride,
-                                                    const ClaheGeom& g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec,
-                                                    int tile_of_item = -1, int frame_of_item = 0, int tiles_of_grid = 0)
+                                                    const ClaheGeom& g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges, int vec)
 {
     constexpr int kWin = 1 << kWinBits;
     const int t = threadIdx.x;
-    // (tile, frame) = the workgroup's position in a (tiles, frames) grid, or given by a persistent caller (tile_hist16p_kernel)
-    const int tile = tile_of_item >= 0 ? tile_of_item : (int)blockIdx.x, f = tile_of_item >= 0 ? frame_of_item : (int)blockIdx.y;
+    const int tile = blockIdx.x, f = blockIdx.y;
     const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
     const uint8_t* src = src_base + (long long)f * frame_stride;
-    const size_t tile_id = (size_t)f * (tile_of_item >= 0 ? (unsigned)tiles_of_grid : gridDim.x) + tile;
+    const size_t tile_id = (size_t)f * gridDim.x + tile;
     uint32_t* out = hist + tile_id * kHist16;
     const long long items = (long long)g.tile_h * g.tile_w;
     const int drow = NT / g.tile_w, dcol = NT - drow * g.tile_w;
@@ -308,40 +331,7 @@ __global__ __launch_bounds__(1024) void tile_hist16_kernel(const uint8_t* __rest
 // tile_hist16_careful (as many counters per sweep as fit the same LDS: 8192 with two copies, up to eight sweeps) in the same workgroup.  ranges[tile].hi carries bit 31 when the tile's LUT was written here.
 constexpr uint32_t kLutDone = 0x80000000u;
 constexpr uint32_t kHistCompressed = 0x40000000u;   // Range16.hi of a tile: its histogram is stored at index value >> shift (tile_hist12_kernel with a shift)
-constexpr uint32_t kWideTodo = 0x20000000u;         // Range16.hi of a tile: it lost tile_hist12_kernel's bet and was LEFT to tile_hist16p_kernel (clahe16_wide.hip.h)
-constexpr uint32_t kLutFull = 0x10000000u;          // Range16.hi of a tile: tile_hist16p_kernel wrote its LUT over all 65536 values, raw domain (shift 0)
 constexpr int kBins12 = 4096;
-// "Wide content was seen": what lets the HOST decide, without waiting for anything, whether a call should launch round 6's two
-// kernels for content wider than 8192 values (clahe16_wide.hip.h) -- on 12-bit content each of those launches, 256 workgroups with
-// 128 KiB of LDS that look at a few words and leave, cost 7 us of a 190 us call.  A kernel that meets such content (word 0: a tile
-// that lost the 12-bit bet at once on values of more than 14 bits; word 1: a rectangle whose range needs more than one window of
-// the small table) stamps the call's sequence number into a device word, and the first workgroup of the call to do so also into a
-// word of pinned host memory, which the next calls read; tile_lut16_kernel, part of every call, stamps the number into host word 2
-// ("executed so far"), and the host launches the wide kernels while the last wide call lies at most eight EXECUTED calls back -- counted
-// in the device's progress, not the host's: a caller that enqueues twenty calls ahead must not see its own hint expire.
-// A hint: what a call launches never changes a byte of its result.
-struct WideHint { uint32_t* dev; uint32_t* host; uint32_t seq; };
-__device__ __forceinline__ void wide_seen(const WideHint& h, int which)      // one lane
-{
-    if (!h.dev) return;
-    // (look before exchanging: a thousand workgroups exchanging on one word cost a call 100 us; a thousand loads of it cost nothing)
-    if (__hip_atomic_load(h.dev + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == h.seq) return;
-    if (__hip_atomic_exchange(h.dev + which, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != h.seq)
-        __hip_atomic_store(h.host + which, h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// Which interpolation kernel does a rectangle belong to when clahe_interp16_acc_kernel runs beside clahe_interp16_kernel (both ask
-// this, with the same numbers)?  [lo4, hi]: the range of the rectangle's four tiles in the frame's domain, lo4 rounded down to a
-// multiple of four.  Up to 8192 values: the small table, one window.  Up to 16384: ONE window of the large table.  Beyond: the large
-// table's windows if one of the four tiles was written by tile_hist16p_kernel (dense wide content), or if the call is in place (the
-// small table's several windows re-read their pixels); a 12-bit rectangle with a hot pixel keeps the small table's windows, which
-// skip the empty ones.
-constexpr int kInterp16AccEntries = 16384;
-__device__ __forceinline__ bool rect_goes_wide(uint32_t lo4, uint32_t hi, bool any_lut_full, bool in_place)
-{
-    const uint32_t span = hi - lo4;
-    if (span < 8192u) return false;
-    return span < (uint32_t)kInterp16AccEntries || any_lut_full || in_place;
-}
 // Shipped shape: 1024 threads, 4 copies = 64 KiB of LDS, two workgroups per CU.  512 threads x 2 copies (32 KiB, four workgroups per
 // CU) measured the same on 12-bit content (16 4K frames: 59.6 us alone either way; the sweep on its own 45 us either way,
 // tools/hist12_probe.hip) and leaves the careful path half the counters per sweep, so the larger shape stays.
@@ -401,7 +391,7 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
                                                         ClaheGeom g, uint32_t* __restrict__ hist, Range16* __restrict__ ranges,
                                                         float lut_scale16, int clip16, uint16_t* __restrict__ luts,
                                                         uint32_t* __restrict__ sync, Range16* __restrict__ frame_ranges, uint32_t* __restrict__ frame_done,
-                                                        uint32_t* __restrict__ shift_hint, int defer_wide, WideHint wide_hint)
+                                                        uint32_t* __restrict__ shift_hint)
 {
     static_assert(COPIES == 2 || COPIES == 4, "copies");
     constexpr int NW = NT / 64, BPT = kBins12 / NT;                // waves; bins per thread
@@ -475,12 +465,6 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
     const uint32_t sft = (uint32_t)__builtin_amdgcn_readfirstlane((int)sft_v);       // in SGPRs: the sweep has no VGPR to spare
     const uint32_t wl = min(12u, 16u - sft);
     bool lost = (o16 >> sft) >= (uint32_t)kBins12;                  // uniform
-    // Lost at once, on values of more than 14 bits that are not all even: dense wide content in the raw domain, what tile_hist16p_kernel
-    // is for (one sweep instead of two to four).  Up to 14 bits the careful path needs ONE sweep and runs two workgroups per CU; samples
-    // in the high bits of the word (even values) keep its compressed domain; a tile that loses LATE holds an outlier (a hot pixel), and
-    // the careful path sweeps only the windows that hold something.
-    const bool early_wide = lost && o16 >= 16384u && (o16 & 1u);
-    if (early_wide && t == 0) wide_seen(wide_hint, 0);
     if (!lost) {
         uint32_t por = 0;
         for (int it = t; it < vitems; it += 4 * NT) {
@@ -539,20 +523,9 @@ __global__ __launch_bounds__(NT, 8) void tile_hist12_kernel(const uint8_t* __res
             r.hi = min(((((31u - (uint32_t)__builtin_clz(buckets)) << 8) | 255u) << fs), 0xffffu) | (fs << 16);
         }
         frame_ranges[f] = r;
-        frame_done[f] = done ? 1u : 0u;                              // (tile_hist16p_kernel turns it to 1 for a frame whose tiles were ALL left to it)
+        frame_done[f] = done ? 1u : 0u;
         if (done) hint_out(shift_hint, (uint32_t)__builtin_ctz(shifts));
     };
-    if (early_wide && defer_wide) {
-        // uniform over the workgroup: the tile holds values that do not fit 4096 bins at any shift.  It is left, marked, to
-        // tile_hist16p_kernel, which follows on the same grid with 128 KiB of LDS: one sweep over 65536 packed counters, LUT folded in
-        // (how many of a frame's tiles were left: bits 48..63 of the frame's SECOND arrival word, which is tile_hist16p_kernel's)
-        if (t == 0) {
-            Range16 r; r.lo = 0u; r.hi = kWideTodo; ranges[tile_id] = r;
-            __hip_atomic_fetch_add(sy + 1, 1ull << 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            arrive(false, 0u, 0u); settle_frame();
-        }
-        return;
-    }
     if (lost) {                                                   // uniform over the workgroup: redo the tile the careful way
         __syncthreads();
         tile_hist16_careful<kCarefulBits, NT>(h16, s_lo, s_hi, s_or, src_base, step, frame_stride, g, hist, ranges, 1);   // its counters fill the same LDS
@@ -677,9 +650,9 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
                                                          const uint32_t* __restrict__ frame_done, uint32_t* __restrict__ shift_hint, WideHint wide_hint)
 {
     if (wide_hint.host && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)       // "this call has been executed": see WideHint
-        __hip_atomic_store(wide_hint.host + 2, wide_hint.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(wide_hint.host + 1, wide_hint.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // tile_hist12_kernel has written every LUT of this frame (bins 0..4095: all anybody reads) and the frame's range: one scalar load
-    if (frame_done && frame_done[blockIdx.y] == 1u) return;
+    if (frame_done && frame_done[blockIdx.y]) return;
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_flo, s_fhi, s_fs;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -735,8 +708,6 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
     // tile_hist12_kernel has already written this tile's LUT for bins 0..4095 of ITS domain: that is all anybody reads if that domain
     // is the frame's and the neighbourhood stayed inside it
     if ((own_r.hi & kLutDone) && ((own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u) == sft && (need_hi >> sft) < (uint32_t)kBins12) return;
-    // tile_hist16p_kernel has written this tile's LUT over all 65536 values (raw domain; such a tile reports shift 0, so the frame's is 0)
-    if ((own_r.hi & kLutFull) && sft == 0u) return;
     const uint32_t own_lo = range_lo(own_r.lo), own_hi = range_hi(own_r.hi);
     // where this tile's counts are: at index value (careful sweeps, unshifted bets) or at index value >> own shift (shifted bets)
     const uint32_t own_store = (own_r.hi & kHistCompressed) ? range_shift(own_r.hi) : 0u;      // >= sft: sft is the minimum over the tiles
@@ -835,23 +806,24 @@ __global__ __launch_bounds__(1024) void tile_lut16_kernel(const uint32_t* __rest
 // of fixed columns -- column weights and ownership are lane constants -- and walks down the band's rows.  Ownership is decided by
 // the reference's own float expressions on ranges widened by a few pixels, so a pair / band edge can never be mis-assigned;
 // an 8-pixel group cut by a pair edge is visited by both neighbours, each storing only its own pixels.
-template <bool FMA>
-__global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
-                                                                         uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
-                                                                         ClaheGeom g, const uint16_t* __restrict__ luts,
-                                                                         const Range16* __restrict__ frame_ranges, int subs, int n_frames,
-                                                                         const Range16* __restrict__ tile_ranges, uint32_t* shift_hint, int skip_multi,
-                                                                         WideHint wide_hint)
+// ENTRIES / THREADS: the table and the workgroup (8192 / 512: clahe_interp16_kernel; 16384 / 1024: clahe_interp16_mid_kernel).
+// `id`: the work item (clahe_interp16_kernel: the workgroup's index).  mid_runs: clahe_interp16_mid_kernel is part of this call and takes
+// the rectangles rect_is_mid() names; everybody else's are the small table's.
+template <bool FMA, int ENTRIES, int THREADS>
+__device__ __forceinline__ void interp16_item(long long id, const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
+                                              uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
+                                              const ClaheGeom& g, const uint16_t* __restrict__ luts,
+                                              const Range16* __restrict__ frame_ranges, int subs, int n_frames,
+                                              const Range16* __restrict__ tile_ranges, int mid_runs, const WideHint& wide_hint)
 {
-    extern __shared__ __attribute__((aligned(16))) uint2 tab[];      // [kInterp16Entries] {a | b << 16, c | d << 16}
+    constexpr bool MID = ENTRIES == kInterp16MidEntries;
+    extern __shared__ __attribute__((aligned(16))) uint2 tab[];      // [ENTRIES] {a | b << 16, c | d << 16}
     const int t = threadIdx.x;
-    hint_roll(shift_hint);
     const int npairs = g.tiles_x + 1, bands = g.tiles_y + 1;
     // Workgroups reach the 8 XCDs round-robin in launch order.  A ROW of workgroups -- the tiles_x + 1 pairs of one (frame, band,
     // sub-band) -- is given to ONE XCD, its pairs one after the other: the rectangles of neighbouring pairs meet in the middle of a
     // 128-byte line (a 4K pair is 960 bytes wide and starts at byte 480), and only an L2 that sees both halves writes whole lines
     // back.  grid = 8 * ceil(rows / 8) * (tiles_x + 1) workgroups, one dimension; rows beyond the last return at once.
-    const long long id = blockIdx.x;
     const int xcd = (int)(id & 7);
     const long long k = id >> 3;
     const int pr = (int)(k % npairs);
@@ -872,27 +844,29 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const Range16 fr_raw = frame_ranges[f];
     const uint32_t sft = range_shift(fr_raw.hi);
     Range16 fr; fr.lo = fr_raw.lo >> sft; fr.hi = range_hi(fr_raw.hi) >> sft;
-    // A range wider than the table is walked in WINDOWS of kInterp16Entries values: the table is staged once per window and a pixel is
+    // A range wider than the table is walked in WINDOWS of ENTRIES values: the table is staged once per window and a pixel is
     // finished in the window its value falls into (2-byte stores).  That re-reads the workgroup's pixels once per window, so it
     // cannot be done in place: in-place calls on a FRAME with a wide range are left to clahe_interp16_wide_kernel, whole.
-    // (skip_multi: clahe_interp16_acc_kernel runs beside this one and takes every rectangle whose OWN range needs more than one
-    // window, in place or not; this kernel then keeps the single-window rectangles of such frames, which are safe in place)
-    if (!skip_multi && fr.hi - (fr.lo & ~3u) >= (uint32_t)kInterp16Entries && src_base == dst_base) { if (t == 0) wide_seen(wide_hint, 1); return; }
+    if (!MID && fr.hi - (fr.lo & ~3u) >= (uint32_t)ENTRIES && src_base == dst_base) return;      // (the mid kernel is never launched in place)
     // The table only has to cover the values this workgroup's pixels can have: they lie in (at most) the four tiles whose LUTs it blends,
     // so the union of THOSE tiles' ranges replaces the frame's (a hot pixel, a bright corner widen the table of their own rectangles
     // only; tile_lut16_kernel writes every LUT over its tile's 3 x 3 neighbourhood, which contains these four).
-    bool any_full;
     {
         const Range16* tr = tile_ranges + (size_t)f * g.tiles_x * g.tiles_y;
         const Range16 r00 = tr[ty1 * g.tiles_x + tx1], r01 = tr[ty1 * g.tiles_x + tx2], r10 = tr[ty2 * g.tiles_x + tx1], r11 = tr[ty2 * g.tiles_x + tx2];
         fr.lo = min(min(range_lo(r00.lo), range_lo(r01.lo)), min(range_lo(r10.lo), range_lo(r11.lo))) >> sft;
         fr.hi = max(max(range_hi(r00.hi), range_hi(r01.hi)), max(range_hi(r10.hi), range_hi(r11.hi))) >> sft;
-        any_full = ((r00.hi | r01.hi | r10.hi | r11.hi) & kLutFull) != 0u;
     }
     const uint32_t start = fr.lo & ~3u;
-    const bool multi = fr.hi - start >= (uint32_t)kInterp16Entries;
-    if (multi && t == 0) wide_seen(wide_hint, 1);
-    if (skip_multi && rect_goes_wide(start, fr.hi, any_full, src_base == dst_base)) return;      // uniform: clahe_interp16_acc_kernel's rectangle
+    if (MID) {
+        if (!rect_is_mid(fr.hi - start)) return;                    // uniform: the small table's rectangle
+    } else {
+        if (rect_is_mid(fr.hi - start)) {                           // uniform
+            if (t == 0) wide_seen(wide_hint);
+            if (mid_runs) return;                                   // clahe_interp16_mid_kernel's rectangle
+        }
+    }
+    const bool multi = fr.hi - start >= (uint32_t)ENTRIES;
     // A range of at most kInterp16F32Entries values (every 12-bit source) gets the table as FLOATS, {a, c, b, d} in 16 bytes: one
     // ds_read_b128 per pixel feeds v_pk_mul / v_pk_add directly and the four ushort -> float conversions per pixel are gone
     // (the blend was VALU-bound: ~25 instructions per pixel, now ~12).  Same 64 KiB of LDS either way.
@@ -913,13 +887,13 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
     const int x_hi = (int)min((long long)g.width, ((long long)(2 * pr + 1) * g.tile_w + 1) / 2 + kBandMargin);
     if (x_lo >= x_hi || y_lo >= y_hi) return;                       // uniform over the workgroup
     const int g_lo = x_lo >> 3, ngroups = ((x_hi + 7) >> 3) - g_lo;
-    const int phases = max(1, kInterp16Threads / ngroups);
-    const int passes = (ngroups + kInterp16Threads - 1) / kInterp16Threads;          // > 1 only for tiles wider than 4096 pixels
+    const int phases = max(1, THREADS / ngroups);
+    const int passes = (ngroups + THREADS - 1) / THREADS;          // > 1 only for tiles wider than 4096 pixels
     const uint8_t* src = src_base + (long long)f * src_frame;
     uint8_t* dst = dst_base + (long long)f * dst_frame;
 
     // Which windows does this workgroup's rectangle populate at all?  (One extra read of its pixels: real images are locally much
-    // narrower than their frame.)  Bit w of s_windows: some owned pixel has (value - start) / kInterp16Entries == w; at most 8 windows.
+    // narrower than their frame.)  Bit w of s_windows: some owned pixel has (value - start) / ENTRIES == w; at most 8 windows.
     __shared__ uint32_t s_windows;
     if (multi) {
         if (t == 0) s_windows = 0;
@@ -927,11 +901,11 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
         uint32_t seen = 0;
         const bool al16 = ((((uintptr_t)src | (unsigned long long)src_step) & 15) == 0);
         for (int pass = 0; pass < passes; ++pass) {
-            const int gi = pass * kInterp16Threads + (passes > 1 ? t : t % ngroups);
+            const int gi = pass * THREADS + (passes > 1 ? t : t % ngroups);
             const int phase = passes > 1 ? 0 : t / ngroups;
             if (gi >= ngroups || phase >= phases) continue;
             const int x0 = (g_lo + gi) << 3;
-            auto note = [&](uint32_t v) { seen |= 1u << (((v >> sft) - start) / (uint32_t)kInterp16Entries); };
+            auto note = [&](uint32_t v) { seen |= 1u << (((v >> sft) - start) / (uint32_t)ENTRIES); };
             if (al16 && x0 + 8 <= g.width) {                        // a superset of the owned pixels is fine here
                 for (int y = y_lo + phase; y < y_hi; y += phases) {
                     const u32x4 q = *reinterpret_cast<const u32x4*>(src + (long long)y * src_step + 2 * (long long)x0);
@@ -968,24 +942,44 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
         }
     }
 
-    for (uint32_t w0 = start, wi = 0; w0 <= fr.hi; w0 += (uint32_t)kInterp16Entries, ++wi) {
+    for (uint32_t w0 = start, wi = 0; w0 <= fr.hi; w0 += (uint32_t)ENTRIES, ++wi) {
         if (!((windows >> wi) & 1u)) continue;                      // uniform: nothing of this rectangle lives in that window
         __syncthreads();                                            // the previous window's table is no longer read
         {
-            const uint32_t w1 = min(fr.hi, w0 + (uint32_t)kInterp16Entries - 1);
+            const uint32_t w1 = min(fr.hi, w0 + (uint32_t)ENTRIES - 1);
             // One table entry per lane and step, consecutive lanes -> consecutive entries: conflict-free LDS writes; the sixteen 2-byte
             // loads of four steps are in flight together.
             const uint32_t n = w1 - w0 + 1;
-            for (uint32_t i0 = 0; i0 < n; i0 += 4 * kInterp16Threads) {
+            if (MID) {
+                // four entries per lane and step from four 8-byte loads, written as two 16-byte stores, two steps in flight: 16384
+                // entries are two trips to the LUTs (another XCD's tile kernels wrote them: ~2 us each) instead of the four that the
+                // 2-byte loads below would make.  w0 is a multiple of four; the last step may read up to three entries past the range
+                // (inside the 65536-entry LUT: the range ends at 65535 at most; never looked up).
+                const uint32_t n4 = (n + 3u) & ~3u;
+#pragma unroll 2
+                for (uint32_t i4 = (uint32_t)t * 4u; i4 < n4; i4 += (uint32_t)THREADS * 4u) {
+                    const uint32_t v = w0 + i4;
+                    const uint2 A = *reinterpret_cast<const uint2*>(la + v), B = *reinterpret_cast<const uint2*>(lb + v);
+                    const uint2 C = *reinterpret_cast<const uint2*>(lc + v), D = *reinterpret_cast<const uint2*>(ld + v);
+                    u32x4 e0, e1;
+                    e0.x = (A.x & 0xffffu) | (B.x << 16);         e0.y = (C.x & 0xffffu) | (D.x << 16);
+                    e0.z = (A.x >> 16) | (B.x & 0xffff0000u);     e0.w = (C.x >> 16) | (D.x & 0xffff0000u);
+                    e1.x = (A.y & 0xffffu) | (B.y << 16);         e1.y = (C.y & 0xffffu) | (D.y << 16);
+                    e1.z = (A.y >> 16) | (B.y & 0xffff0000u);     e1.w = (C.y >> 16) | (D.y & 0xffff0000u);
+                    u32x4* o = reinterpret_cast<u32x4*>(tab + i4);
+                    o[0] = e0; o[1] = e1;
+                }
+            } else
+            for (uint32_t i0 = 0; i0 < n; i0 += 4 * THREADS) {
                 uint32_t va[4], vb[4], vc[4], vd[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t v = min(w0 + i0 + (uint32_t)(k * kInterp16Threads + t), w1);
+                    const uint32_t v = min(w0 + i0 + (uint32_t)(k * THREADS + t), w1);
                     va[k] = la[v]; vb[k] = lb[v]; vc[k] = lc[v]; vd[k] = ld[v];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t i = i0 + (uint32_t)(k * kInterp16Threads + t);
+                    const uint32_t i = i0 + (uint32_t)(k * THREADS + t);
                     if (i >= n) continue;
                     if (f32tab) {
                         const f32x4 e = {(float)va[k], (float)vc[k], (float)vb[k], (float)vd[k]};      // {a, c, b, d}
@@ -999,7 +993,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
         }
         __syncthreads();
         for (int pass = 0; pass < passes; ++pass) {
-            const int gi = pass * kInterp16Threads + (passes > 1 ? t : t % ngroups);
+            const int gi = pass * THREADS + (passes > 1 ? t : t % ngroups);
             const int phase = passes > 1 ? 0 : t / ngroups;
             if (gi >= ngroups || phase >= phases) continue;
             const int x0 = (g_lo + gi) << 3;
@@ -1042,7 +1036,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     // owned pixels of this window index the table directly; anything else is masked out later: clamp its index
-                    const uint32_t idx = min((px[j] >> sft) - w0, (uint32_t)kInterp16Entries - 1);
+                    const uint32_t idx = min((px[j] >> sft) - w0, (uint32_t)ENTRIES - 1);
                     const uint2 e = tab[idx];
                     const float a = (float)(e.x & 0xffffu), b = (float)(e.x >> 16), c = (float)(e.y & 0xffffu), d = (float)(e.y >> 16);
                     int r = __float2int_rn(clahe_blend_f<FMA>(a, b, c, d, xa[j], xa1[j], ya, ya1));
@@ -1098,7 +1092,7 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                         for (int j = 0; j < 8; ++j) px[j] = (own >> j) & 1u ? *reinterpret_cast<const uint16_t*>(sp + 2 * j) : 0xffffffffu;
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) if (((own >> j) & 1u) && (px[j] >> sft) - w0 < (uint32_t)kInterp16Entries) todo |= 1u << j;   // this window's pixels
+                    for (int j = 0; j < 8; ++j) if (((own >> j) & 1u) && (px[j] >> sft) - w0 < (uint32_t)ENTRIES) todo |= 1u << j;   // this window's pixels
                     if (!todo) continue;
                     blend_row(y, px, res);
 #pragma unroll
@@ -1106,6 +1100,60 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
                 }
             }
         }
+    }
+}
+
+
+template <bool FMA>
+__global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
+                                                                         uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
+                                                                         ClaheGeom g, const uint16_t* __restrict__ luts,
+                                                                         const Range16* __restrict__ frame_ranges, int subs, int n_frames,
+                                                                         const Range16* __restrict__ tile_ranges, uint32_t* shift_hint,
+                                                                         int mid_runs, WideHint wide_hint)
+{
+    hint_roll(shift_hint);
+    interp16_item<FMA, kInterp16Entries, kInterp16Threads>(blockIdx.x, src_base, src_step, src_frame, dst_base, dst_step, dst_frame, g, luts,
+                                                           frame_ranges, subs, n_frames, tile_ranges, mid_runs, wide_hint);
+}
+
+// PERSISTENT: grid = min(work items, CUs rounded to a multiple of 8) workgroups of 1024 threads with 128 KiB of dynamic LDS (one per CU
+// is all that fits; launched one per item, the thousands that only return cost 23 us).  The work items are clahe_interp16_kernel's,
+// item for item (same `subs`, same XCD dealing: item & 7 -- the grid is a multiple of 8, so a workgroup stays on its XCD).  Frames whose
+// whole range fits the small table are known from a bit mask built once per workgroup.  Out of place only (the host sees to it).
+template <bool FMA>
+__global__ __launch_bounds__(kInterp16MidThreads) void clahe_interp16_mid_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
+                                                                                uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
+                                                                                ClaheGeom g, const uint16_t* __restrict__ luts,
+                                                                                const Range16* __restrict__ frame_ranges, int subs, int n_frames,
+                                                                                const Range16* __restrict__ tile_ranges)
+{
+    __shared__ unsigned long long s_wide[16];                        // bit f % 64 of word f / 64: frame f may hold such a rectangle (<= 1024 frames per launch)
+    const int t = threadIdx.x;
+    for (int f0 = 0; f0 < n_frames; f0 += kInterp16MidThreads) {
+        const int f = f0 + t;
+        bool wide = false;
+        if (f < n_frames) {
+            const Range16 fr = frame_ranges[f];
+            const uint32_t sft = range_shift(fr.hi);
+            wide = (range_hi(fr.hi) >> sft) - ((fr.lo >> sft) & ~3u) >= (uint32_t)kInterp16Entries;
+        }
+        const unsigned long long m = __ballot(wide);
+        if ((t & 63) == 0 && f0 + t < 1024) s_wide[(f0 + t) >> 6] = m;
+    }
+    __syncthreads();
+    const int npairs = g.tiles_x + 1, bands = g.tiles_y + 1;
+    const long long rows_total = (long long)bands * subs * n_frames;
+    const long long items = (rows_total + 7) / 8 * 8 * npairs;
+    const WideHint none{nullptr, nullptr, 0u};
+    for (long long id = blockIdx.x; id < items; id += gridDim.x) {
+        const long long row = ((id >> 3) / npairs) * 8 + (id & 7);
+        if (row >= rows_total) continue;
+        const int f = n_frames - 1 - (int)(row / ((long long)subs * bands));
+        if (!((s_wide[(f >> 6) & 15] >> (f & 63)) & 1ull)) continue;  // uniform: no such rectangle in this frame
+        __syncthreads();                                            // the previous item's table is no longer read
+        interp16_item<FMA, kInterp16MidEntries, kInterp16MidThreads>(id, src_base, src_step, src_frame, dst_base, dst_step, dst_frame, g, luts,
+                                                                     frame_ranges, subs, n_frames, tile_ranges, 1, none);
     }
 }
 

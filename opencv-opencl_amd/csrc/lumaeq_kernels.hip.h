@@ -26,7 +26,6 @@
 //   kernels/equalize_fused.hip.h  KF fused single-read equalizeHist
 //   kernels/clahe.hip.h           K4 tile hist, K5 clip/redistribute/LUT, K6 interpolation
 //   kernels/clahe16.hip.h         CLAHE on CV_16UC1 (N4)
-//   kernels/clahe16_wide.hip.h    ... its kernels for content wider than 8192 values (14-bit, full range, hot pixels)
 //   kernels/color.hip.h           cvtColor BGR2YUV / YUV2BGR + fused split/merge, 4:2:0 codes, NV12 per-channel equalize (N3)
 //   kernels/color_clahe.hip.h     CLAHE on the luma of interleaved BGR in two passes (N3)
 //   kernels/diff.hip.h            absdiff + analyzeDiff: the reference's own device-vs-CPU check (1frameMeasure.cpp:91-100)
@@ -36,7 +35,6 @@
 #include "kernels/equalize_fused.hip.h"
 #include "kernels/clahe.hip.h"
 #include "kernels/clahe16.hip.h"
-#include "kernels/clahe16_wide.hip.h"
 #include "kernels/color.hip.h"
 #include "kernels/color_clahe.hip.h"
 #include "kernels/diff.hip.h"

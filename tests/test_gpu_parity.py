@@ -1147,15 +1147,15 @@ def test_clahe16_tables_follow_the_local_range(ctx):
                 assert np.array_equal(got[k], want[k]), (w, h, cfg, "in place", k)
 
 
-def test_clahe16_wide_content_one_sweep_and_register_held_interpolation(ctx):
-    """Round 6 (kernels/clahe16_wide.hip.h): content wider than 8192 values.  Tiles that lose the 12-bit bet are swept ONCE into 65 536
-    packed 16-bit counters with the LUT folded in, and the interpolation holds its pixels in registers over all table windows.  Full-size
-    4K frames, 8x8 tiles of 129 600 pixels: full-range noise, 14-bit, 15-bit, a smooth full-range ramp (few windows per rectangle), a
-    12-bit frame with one hot pixel (ONE deferred tile, its neighbours' LUTs extended), a frame whose tile (3, 2) holds 70 000 pixels of
-    one value among full-range noise (a 16-bit counter WRAPS: the tile must fall back to the careful sweeps -- and the frame, all of
-    whose tiles were deferred, must not be declared done), a half 12-bit / half full-range frame (mixed frame: tile_lut16_kernel
-    extends the 12-bit tiles next to wide ones), and 14-bit samples in the high bits of the word.  Out of place and IN PLACE, with the
-    option on (default) and off (the round-3 paths): every frame bit-exact against the oracle."""
+def test_clahe16_wide_content_full_size(ctx):
+    """Content wider than 8192 values on full-size 4K frames, 8x8 tiles of 129 600 pixels (round 6).  Rectangles whose range needs
+    8193..16384 table entries -- every rectangle of a 14-bit frame -- are interpolated by clahe_interp16_mid_kernel (ONE window of a
+    128-KiB table, persistent, launched while such content was seen lately: option clahe16_wide 1 = that hint, 2 = always, 0 = never);
+    wider ones keep the 64-KiB table's windows.  Full-range noise, 14-bit, 15-bit, a smooth full-range ramp (rectangles of every
+    width), a 12-bit frame with one hot pixel, full-range noise with 70 000 pixels of ONE value in tile (3, 2), a half 12-bit / half
+    full-range frame, and 14-bit samples in the high bits of the word (16384 entries in the compressed domain).  Out of place and IN
+    PLACE (where the mid kernel is never launched), every option value, the hint turning on over consecutive calls: every frame
+    bit-exact against the oracle."""
     w, h = 3840, 2160
     rng = np.random.default_rng(606)
     def noise(lo, hi): return rng.integers(lo, hi, (h, w), dtype=np.uint16)
@@ -1177,8 +1177,8 @@ def test_clahe16_wide_content_one_sweep_and_register_held_interpolation(ctx):
     for cfg in ((2.0, 8, 8), (40.0, 8, 8)):
         want = [oracle.clahe16(f, *cfg) for f in frames]
         try:
-            # 2: the wide kernels are always launched; 0: never (the round-3 paths); 1 (the default): when the context's last calls met wide
-            # content -- the first such call runs the round-3 paths, the pinned hint word turns, the following ones run the new kernels
+            # 2: the mid kernel is always launched; 0: never; 1 (the default): when the context's last calls met a 14-bit rectangle -- the
+            # first such call runs without it, the pinned hint word turns, the following ones launch it
             for wide in (2, 0, 1, 1, 1):
                 ctx.set_option("clahe16_wide", wide)
                 d_in = dev(np.stack(frames).view(np.int16))
@@ -1197,9 +1197,8 @@ def test_clahe16_wide_content_one_sweep_and_register_held_interpolation(ctx):
                 del d_in
         finally:
             ctx.set_option("clahe16_wide", 1)
-    # other tile grids: tiles too small to wrap a counter, a grid with more pairs than a workgroup has row phases, one tile, and one
-    # whose pair edges do not fall on multiples of eight pixels (1000 / 5 = 200-pixel tiles: edges at 100 + 200 k) -- that one keeps the
-    # round-3 interpolation whatever the option says
+    # other tile grids: small tiles, a grid with more pairs than a workgroup has row phases, one tile, and one whose pair edges do not
+    # fall on multiples of eight pixels (1000 / 5 = 200-pixel tiles: edges at 100 + 200 k: 8-pixel groups cut by an edge)
     ctx.set_option("clahe16_wide", 2)
     for (cw, chh, tx, ty) in [(640, 368, 8, 8), (1280, 96, 16, 2), (512, 512, 1, 1), (1024, 64, 2, 4), (1000, 120, 5, 3)]:
         fs = [rng.integers(0, 65536, (chh, cw), dtype=np.uint16), rng.integers(0, 16384, (chh, cw), dtype=np.uint16),
@@ -1249,11 +1248,10 @@ def test_clahe16_frame_done_flags_over_many_frames(ctx):
         assert np.array_equal(host(d_in).view(np.uint16), want[:n]), (n, "in place")
 
 
-def test_clahe16_suite_again_with_the_wide_kernels_always_launched(ctx):
-    """With the option at its default the wide kernels are launched only after wide content was seen (a hint in pinned memory), so which
-    kernels the tests above ran depends on their order.  Here every one of them runs again with the kernels ALWAYS launched: small
-    frames, mixed batches (frames whose tiles were all / partly / not at all left to the one-sweep kernel), MSB-aligned content,
-    hot pixels, 150-frame calls."""
+def test_clahe16_suite_again_with_the_mid_kernel_always_launched(ctx):
+    """With the option at its default clahe_interp16_mid_kernel is launched only after a 14-bit rectangle was seen (a hint in pinned
+    memory), so which kernels the tests above ran depends on their order.  Here every one of them runs again with the kernel ALWAYS
+    launched: small frames, mixed batches, MSB-aligned content, hot pixels, 150-frame calls."""
     try:
         ctx.set_option("clahe16_wide", 2)
         for cfg in [(2.0, 8, 8), (40.0, 3, 5), (0.0, 4, 4)]:
