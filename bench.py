@@ -290,23 +290,46 @@ def device_for_collectives(torch, backend, local_rank):
 
 
 def opencv_cross_check(ctx, w, h, dist_name):
-    """the oracle is a restatement (parity unpinned).  Wherever a real OpenCV is importable, compare the GPU
-    path with cv2 itself on one frame and say so in the JSON line; None when there is no cv2 (this image has none)."""
+    """the oracle is a restatement (parity unpinned).  Wherever a real OpenCV is importable, compare the GPU path with cv2
+    itself and say so in the JSON line; None when there is no cv2 (this image has none).  The bench's own resolution AND 1920x1080
+    (BASELINE config 1), equalizeHist and CLAHE 8x8 clip 2.0 in whichever of the two arithmetic modes this cv2 build computes, and
+    config 5 in both readings: Y equalize + UV passthrough (what ColoropenCVCwqualHist.cpp does) and, literally,
+    NV12 -> BGR -> equalizeHist on B, G, R -> NV12.  The C++ front end's own pin is tests/test_opencv_pin.py."""
     try:
         import cv2
     except Exception:
         return None
     import numpy as np
+    import mi_lumaeq
     from mi_lumaeq import synth
-    y = synth.nv12_frame(w, h, dist_name, 4242)[: w * h].reshape(h, w)
-    res = {"version": cv2.__version__}
+    res = {"version": cv2.__version__, "shapes": {}}
     try:
-        res["equalizeHist_bit_exact"] = bool(np.array_equal(ctx.equalize_hist(y), cv2.equalizeHist(y)))
-        want = cv2.createCLAHE(2.0, (8, 8)).apply(y)
-        res["clahe_2.0_8x8_bit_exact"] = bool(np.array_equal(ctx.clahe(y, 2.0, 8, 8), want))          # x86-64 baseline arithmetic
-        ctx.set_option("clahe_fp_contract", 1)                                                      # GCC FMA contraction (aarch64 builds)
-        res["clahe_2.0_8x8_bit_exact_fp_contract"] = bool(np.array_equal(ctx.clahe(y, 2.0, 8, 8), want))
-        ctx.set_option("clahe_fp_contract", 0)
+        for (cw, ch) in sorted({(w, h), (1920, 1080)}):
+            frame = synth.nv12_frame(cw, ch, dist_name, 4242)
+            y = frame[: cw * ch].reshape(ch, cw)
+            r = {"equalizeHist_bit_exact": bool(np.array_equal(ctx.equalize_hist(y), cv2.equalizeHist(y)))}
+            want = cv2.createCLAHE(2.0, (8, 8)).apply(y)
+            r["clahe_2.0_8x8_bit_exact"] = bool(np.array_equal(ctx.clahe(y, 2.0, 8, 8), want))          # x86-64 baseline arithmetic
+            ctx.set_option("clahe_fp_contract", 1)                                                      # GCC FMA contraction (aarch64 builds)
+            r["clahe_2.0_8x8_bit_exact_fp_contract"] = bool(np.array_equal(ctx.clahe(y, 2.0, 8, 8), want))
+            ctx.set_option("clahe_fp_contract", 0)
+            # config 5 as the named file does it: Y equalized, UV passed through
+            out = ctx.equalize_hist_nv12(frame, cw, ch, mi_lumaeq.UV_COPY)
+            want5 = frame.copy()
+            want5[: cw * ch] = cv2.equalizeHist(y).reshape(-1)
+            r["config5_y_equalize_uv_passthrough_bit_exact"] = bool(np.array_equal(out, want5))
+            # config 5 read literally: cvtColor(YUV2BGR_NV12) -> split -> equalizeHist x 3 -> merge -> cvtColor(BGR2YUV_I420) -> interleave U, V
+            bgr = cv2.cvtColor(frame.reshape(ch * 3 // 2, cw), cv2.COLOR_YUV2BGR_NV12)
+            bgr = cv2.merge([cv2.equalizeHist(p) for p in cv2.split(bgr)])
+            i420 = cv2.cvtColor(bgr, cv2.COLOR_BGR2YUV_I420).reshape(-1)
+            lit = np.empty_like(frame)
+            lit[: cw * ch] = i420[: cw * ch]
+            lit[cw * ch:: 2] = i420[cw * ch: cw * ch * 5 // 4]
+            lit[cw * ch + 1:: 2] = i420[cw * ch * 5 // 4:]
+            r["config5_literal_bgr_channels_bit_exact"] = bool(np.array_equal(ctx.nv12_bgr_equalize(frame, cw, ch), lit))
+            res["shapes"][f"{cw}x{ch}"] = r
+        first = res["shapes"][f"{w}x{h}"]                            # (the round-2 keys, for whoever reads them)
+        res.update({k: first[k] for k in ("equalizeHist_bit_exact", "clahe_2.0_8x8_bit_exact", "clahe_2.0_8x8_bit_exact_fp_contract")})
     except Exception as e:                 # a broken cv2 build must not take the bench line down
         res["error"] = repr(e)
     return res

@@ -185,6 +185,11 @@ inline mi_ctx* thread_ctx()
                         std::string("mi_ctx_create(device=") + std::to_string(dev) + ") failed: " + mi_status_str(st) +
                             " (this backend has no CPU fallback)");
         it = ctxs.emplace(dev, std::unique_ptr<mi_ctx, CtxDeleter>(c)).first;
+        // CLAHE's float steps as the program's OWN OpenCV build computes them: 0 = every multiply and add rounded (x86-64 baseline
+        // builds, the default), 1 = GCC's FMA contraction (aarch64 builds such as the reference's board).  For programs that cannot
+        // call setOption themselves -- an unmodified binary under the LD_PRELOAD interposer -- the environment decides;
+        // tests/cxx/test_adapter_opencv finds out which of the two a given OpenCV needs.
+        if (const char* e = std::getenv("MI_CV_CLAHE_FP_CONTRACT")) (void)mi_ctx_set_option(c, "clahe_fp_contract", std::atoi(e) != 0);
     }
     return it->second.get();
 }

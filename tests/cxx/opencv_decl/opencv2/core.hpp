@@ -1,6 +1,8 @@
 // opencv2/core.hpp -- DECLARATION-ONLY stand-in used by tests/test_cxx_adapter.py::test_opencv_front_end_compiles.
 //
-// This is NOT OpenCV and pins nothing.  OpenCV 4.4 is not installed in the authoring image, so the
+// This is NOT OpenCV and pins nothing.  (Round 6: extended by what tests/cxx/test_adapter_opencv.cpp and interpose_probe.cpp touch --
+// Rect, Mat's ROI / external-data constructors, split / merge, getBuildInformation, CV_VERSION -- so that the programs which make
+// first contact with a REAL OpenCV elsewhere at least go through a compiler here.)  OpenCV 4.4 is not installed in the authoring image, so the
 // real-cv::Mat front end of cxx/mi_cv.hpp (namespace mi_cv) and the interposer (cxx/interpose/) had never been
 // through a compiler.  This header declares, with OpenCV 4.4's public names and signatures, exactly the API
 // surface those two files touch -- nothing is implemented -- so that a syntax / override check can run on the CPU:
@@ -13,9 +15,11 @@
 #include <memory>
 #include <string>
 #include <utility>
+#include <vector>
 
 #define CV_VERSION_MAJOR 4
 #define CV_VERSION_MINOR 4
+#define CV_VERSION "4.4.0-declarations-only"
 #define CV_OVERRIDE override
 #define CV_EXPORTS
 #define CV_EXPORTS_W
@@ -25,6 +29,7 @@
 #define CV_MAKETYPE(depth, cn) (((depth) & 7) + (((cn) - 1) << CV_CN_SHIFT))
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
 #define CV_16UC1 CV_MAKETYPE(CV_16U, 1)
+#define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
 
 namespace cv {
 
@@ -46,6 +51,16 @@ public:
 typedef Size_<int> Size2i;
 typedef Size2i Size;
 
+template <typename _Tp> class Rect_ {
+public:
+    Rect_();
+    Rect_(_Tp _x, _Tp _y, _Tp _width, _Tp _height);
+    _Tp x, y, width, height;
+};
+typedef Rect_<int> Rect;
+
+const String& getBuildInformation();
+
 template <typename T> struct Ptr : public std::shared_ptr<T> {
     Ptr() = default;
     Ptr(const std::shared_ptr<T>& o) : std::shared_ptr<T>(o) {}
@@ -61,10 +76,16 @@ struct MatStep {
 class Mat {
 public:
     Mat();
+    Mat(int rows, int cols, int type);
     Mat(int rows, int cols, int type, void* data, size_t step = 0);
+    Mat(const Mat& m, const Rect& roi);
+    Mat operator()(const Rect& roi) const;
+    Mat clone() const;
     int type() const;
     Size size() const;
     bool empty() const;
+    bool isContinuous() const;
+    size_t elemSize() const;
     template <typename _Tp> _Tp* ptr(int i0 = 0);
     template <typename _Tp> const _Tp* ptr(int i0 = 0) const;
     int flags, dims, rows, cols;
@@ -76,6 +97,7 @@ class _InputArray {
 public:
     _InputArray();
     _InputArray(const Mat& m);
+    _InputArray(const std::vector<Mat>& vec);
     Mat getMat(int idx = -1) const;
     int type(int i = -1) const;
     bool empty() const;
@@ -84,10 +106,16 @@ class _OutputArray : public _InputArray {
 public:
     _OutputArray();
     _OutputArray(Mat& m);
+    _OutputArray(std::vector<Mat>& vec);
     void create(Size sz, int type, int i = -1, bool allowTransposed = false, int fixedDepthMask = 0) const;
 };
 typedef const _InputArray& InputArray;
 typedef const _OutputArray& OutputArray;
+typedef InputArray InputArrayOfArrays;
+typedef OutputArray OutputArrayOfArrays;
+
+void split(InputArray m, OutputArrayOfArrays mv);
+void merge(InputArrayOfArrays mv, OutputArray dst);
 
 class FileStorage;
 class FileNode;

@@ -16,5 +16,7 @@ public:
 };
 Ptr<CLAHE> createCLAHE(double clipLimit = 40.0, Size tileGridSize = Size(8, 8));
 void equalizeHist(InputArray src, OutputArray dst);
+enum ColorConversionCodes { COLOR_BGR2YUV = 82, COLOR_YUV2BGR = 84, COLOR_YUV2BGR_NV12 = 91, COLOR_BGR2YUV_I420 = 128 };
+void cvtColor(InputArray src, OutputArray dst, int code, int dstCn = 0);
 }  // namespace cv
 #endif

@@ -154,7 +154,8 @@ def test_opencv_front_end_and_interposer_compile(tmp_path):
     assert r.returncode == 0, r.stderr
     syms = subprocess.run(["nm", str(obj)], capture_output=True, text=True, check=True).stdout
     defined = {ln.split()[-1] for ln in syms.splitlines() if " T " in ln}
-    assert defined == {"_ZN2cv12equalizeHistERKNS_11_InputArrayERKNS_12_OutputArrayE", "_ZN2cv11createCLAHEEdNS_5Size_IiEE"}, defined
+    # ... plus the counter an unmodified program can look up to prove its calls were taken here (tests/cxx/interpose_probe.cpp)
+    assert defined == {"_ZN2cv12equalizeHistERKNS_11_InputArrayERKNS_12_OutputArrayE", "_ZN2cv11createCLAHEEdNS_5Size_IiEE", "mi_cv_interpose_calls"}, defined
     # without the define (or without OpenCV on the include path) the header stays OpenCV-free
     tu2 = tmp_path / "plain.cpp"
     tu2.write_text('#include "mi_cv.hpp"\n#ifdef MI_CV_HAVE_OPENCV_FRONT_END\n#error "front end leaked"\n#endif\nint main() { return 0; }\n')
