@@ -592,6 +592,24 @@ def main():
                     "frac_slowest_rank": round(alg_bytes / (dom_ms_max * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "ranks": world, "per": "GPU (each rank's own launches; mean over ranks)",
                     "launch_ms_p10_p50_p90_rank0": [kinfo[dom]["p10_ms"], kinfo[dom]["p50_ms"], kinfo[dom]["p90_ms"]]}
+        # ONE CLOCK (round 6).  `frac` uses HIP events stamped by the dispatches; the committed profiles use rocprofv3's kernel trace.
+        # profiles/clock.json holds, for this kernel and workload, ONE run in which the same 50 launches were timed by both
+        # (tools/one_clock.sh): `avg_launch_ms_rocprof` / `frac_rocprof` are that run's rocprofv3 figures (another box, like `traffic`), and
+        # `frac_this_run_on_rocprof_clock` rescales THIS run's launches by the ratio of the two clocks on those same launches -- so
+        # a reader never has to choose a clock, or a box.
+        cfile = ROOT / "profiles" / "clock.json"
+        if cfile.exists():
+            try:
+                ent = json.loads(cfile.read_text()).get(f"{dom}:{args.op}:{w}x{h}x{B}:{args.uv}")
+                if ent:
+                    ratio = ent["avg_launch_ms_rocprof"] / ent["avg_launch_ms_hip_events_same_launches"]
+                    roofline["avg_launch_ms_rocprof"] = ent["avg_launch_ms_rocprof"]
+                    roofline["frac_rocprof"] = round(alg_bytes / (ent["avg_launch_ms_rocprof"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    roofline["rocprof_over_hip_events_same_launches"] = round(ratio, 4)
+                    roofline["frac_this_run_on_rocprof_clock"] = round(alg_bytes / (avg_ms_all * ratio * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    roofline["clock_source"] = ent["source"]
+            except Exception:
+                pass
         # the same launch priced on the bytes that MOVE: the fused kernel reads Y once (2*W*H + UV per frame), every other
         # kernel moves its algorithmic bytes.  frac_moved_bytes is against the 8 TB/s peak, and the second figure against the
         # 6.29 TB/s a plain copy kernel reaches on this chip (MI355X_MICROARCH.md).

@@ -326,6 +326,11 @@ def test_bench_line_contract_on_gpu():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.3 < rf["frac"] < 1.0
     assert rf["traffic"] and "profiles/" in rf["traffic_source"] and 0.2 < rf["frac_moved_bytes"] < rf["frac"]
     assert abs(rf["achieved"] - rf["alg_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-3
+    # one clock: the committed rocprofv3 figure of the same kernel and workload, and this run's launches on that clock
+    assert 0.1 < rf["avg_launch_ms_rocprof"] < 1.0 and "profiles/" in rf["clock_source"]
+    assert abs(rf["frac_rocprof"] - rf["alg_bytes_per_launch"] / (rf["avg_launch_ms_rocprof"] * 1e-3) / 1e9 / rf["peak"]) < 1e-3
+    assert 0.9 < rf["rocprof_over_hip_events_same_launches"] < 1.1
+    assert abs(rf["frac_this_run_on_rocprof_clock"] - rf["frac"] / rf["rocprof_over_hip_events_same_launches"]) < 2e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and "3840x2160" in cb["sample"]
     assert d["nv12_1080p"]["value"] > d["value"]                       # four times fewer pixels per frame
