@@ -1,7 +1,7 @@
 """Bounded random differential run, HIP vs oracle, aimed at the code paths a fixed test list visits only at a few points: ROI pitches
 (multiples of 16 and not) with random origins, wide CLAHE grids at sizes where the per-segment float tables apply, large batches of small
 tiles (several tiles per histogram workgroup), 16-bit CLAHE at random value ranges, the 4:2:0 codes at random aligned / unaligned sizes.
-    python tools/stress_random.py [seconds] [seed]        prints a line every ~15 s, exits non-zero on the first mismatch"""
+    python tools/stress_random.py [seconds] [seed] [option=value ...]        prints a line every ~15 s, exits non-zero on the first mismatch"""
 import sys, time
 sys.path.insert(0, "opencv-opencl_amd/python"); sys.path.insert(0, ".")
 import numpy as np, torch
@@ -10,6 +10,8 @@ from mi_lumaeq import xfer
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = mi_lumaeq.Context(0)
+for kv in sys.argv[3:]:                                          # name=value options for the whole run, e.g. clahe16_wide=2 (mid kernel always launched)
+    k_, v_ = kv.split("="); ctx.set_option(k_, int(v_)); print("option", k_, "=", v_, flush=True)
 t0 = last = time.time(); n = {"roi": 0, "grid": 0, "small": 0, "c16": 0, "420": 0, "nv12": 0}
 def dev(a): return xfer.to_device(np.ascontiguousarray(a))
 def fail(what, *info):
@@ -60,7 +62,14 @@ while time.time() - t0 < budget:
             r = int(rng.integers(0, 4))
             if r == 0: y[: h // 3] = 0                                  # a black bar: tiles with a larger shift than the frame's
             elif r == 1: y[int(rng.integers(0, h)), int(rng.integers(0, w))] |= 1 << int(rng.integers(0, sh))   # one value voids (or lowers) the shift
-        if not np.array_equal(ctx.clahe16(y, 2.0, 4, 4), oracle.clahe16(y, 2.0, 4, 4)): fail("c16", w, h, lo, hi, sh)
+        want16 = oracle.clahe16(y, 2.0, 4, 4)
+        if not np.array_equal(ctx.clahe16(y, 2.0, 4, 4), want16): fail("c16", w, h, lo, hi, sh)
+        if rng.integers(0, 3) == 0:                                   # the same frame three times in a device batch, out of place and in place
+            d16 = dev(np.stack([y, y, y]).view(np.int16)); o16 = torch.zeros_like(d16)
+            ctx.clahe16_batch_dev(d16, o16, w, h, 3, 2.0, 4, 4); ctx.synchronize()
+            if not all(np.array_equal(xfer.to_host(o16)[f].view(np.uint16), want16) for f in range(3)): fail("c16 batch", w, h, lo, hi, sh)
+            ctx.clahe16_batch_dev(d16, d16, w, h, 3, 2.0, 4, 4); ctx.synchronize()
+            if not all(np.array_equal(xfer.to_host(d16)[f].view(np.uint16), want16) for f in range(3)): fail("c16 in place", w, h, lo, hi, sh)
         n["c16"] += 1
     elif k == 5:    # NV12 batches of random even sizes through the fused kernel (or the three-kernel path where it does not apply), both ops
         w, h, nf = int(rng.integers(1, 400)) * 2, int(rng.integers(1, 200)) * 2, int(rng.integers(1, 9))
