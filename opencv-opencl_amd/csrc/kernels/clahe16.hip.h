@@ -27,6 +27,9 @@ namespace mi {
 //                 pixels are re-read once per window, from L2; windows none of them falls into are skipped -- a locally smooth
 //                 image needs one or two of the eight).  Only in-place calls on wide-range frames still gather from L2
 //                 (clahe_interp16_wide_kernel): re-reading pixels that earlier windows have overwritten is not an option.
+//   clahe_interp16_mid  (round 6) the SAME body with a 16384-entry table and 1024 threads, persistent, for the rectangles whose range
+//                 needs 8193..16384 entries (every rectangle of a 14-bit frame: one window, the vector path) and for dense wider ones
+//                 (half as many window passes); launched only while such content was seen lately (WideHint), out of place only.
 // =============================================================================================
 constexpr int kHist16 = 65536;
 constexpr int kHalf16 = 32768;
