@@ -52,10 +52,8 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         // the gathering kernel, whole.
         const uint32_t seq = ++c->c16_seq;
         const WideHint wh{c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 2, c->h_mirror + kWideHintWord, seq};
-        const bool mid_recent = c->clahe16_wide >= 2 ||
-            (c->clahe16_wide == 1 && (int32_t)(__atomic_load_n(c->h_mirror + kWideHintWord + 1, __ATOMIC_RELAXED) -
-                                               __atomic_load_n(c->h_mirror + kWideHintWord, __ATOMIC_RELAXED)) <= kWideHintCalls);
-        // (signed: the stamp of the call being executed right now is AHEAD of "executed", which that call's LUT kernel writes)
+        const bool mid_recent = mi_host::mid_kernel_wanted(c->clahe16_wide, __atomic_load_n(c->h_mirror + kWideHintWord + 1, __ATOMIC_RELAXED),
+                                                           __atomic_load_n(c->h_mirror + kWideHintWord, __ATOMIC_RELAXED), kWideHintCalls);      // host/wide_hint.hpp
         const bool mid_runs = mid_recent && nf <= 1024 && !(tiles <= 64 && c->clahe16_transposed) &&
                               src + (size_t)f0 * src_frame != dst + (size_t)f0 * dst_frame;
         // the context's shift hint: two words at the end of the arrival scratch (read / collect, rolled over by the interpolation kernel)

@@ -26,6 +26,7 @@
 #include "host/pending_ranges.hpp"
 #include "host/pin_registry.hpp"
 #include "host/numa_affinity.hpp"
+#include "host/wide_hint.hpp"
 
 using namespace mi;
 

@@ -18,6 +18,7 @@
 #include "../../opencv-opencl_amd/csrc/host/numa_affinity.hpp"
 #include "../../opencv-opencl_amd/csrc/host/pending_ranges.hpp"
 #include "../../opencv-opencl_amd/csrc/host/pin_registry.hpp"
+#include "../../opencv-opencl_amd/csrc/host/wide_hint.hpp"
 
 #include <thread>
 
@@ -441,8 +442,23 @@ static void test_pin_registry()
     }
 }
 
+// ---- the host half of the 16-bit CLAHE's wide-content hint (host/wide_hint.hpp)
+static void test_wide_hint()
+{
+    using mi_host::mid_kernel_wanted;
+    CHECK(mid_kernel_wanted(2, 0, 0, 8) && mid_kernel_wanted(2, 5000, 0, 8));            // always
+    CHECK(!mid_kernel_wanted(0, 1000, 1000, 8));                                         // never
+    CHECK(!mid_kernel_wanted(1, 1000, 0, 8));                                            // a fresh context: "seen" = 0 lies 1000 calls back
+    CHECK(mid_kernel_wanted(1, 1010, 1010, 8) && mid_kernel_wanted(1, 1018, 1010, 8));   // seen in this call ... eight executed calls ago
+    CHECK(!mid_kernel_wanted(1, 1019, 1010, 8));                                         // nine: off again
+    CHECK(mid_kernel_wanted(1, 1010, 1011, 8) && mid_kernel_wanted(1, 1010, 1030, 8));   // "seen" AHEAD of "executed" (the call in flight, a caller
+                                                                                         // enqueueing ahead): recent, not 4 billion calls ago
+    CHECK(mid_kernel_wanted(1, 3, 0xfffffffeu, 8) && !mid_kernel_wanted(1, 20, 0xfffffffeu, 8));      // across the wrap of the sequence numbers
+}
+
 int main()
 {
+    test_wide_hint();
     test_pin_registry();
     test_drain_guard();
     test_pending_ranges();
