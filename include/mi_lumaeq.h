@@ -365,7 +365,9 @@ mi_status mi_cvt_color_420_u8_batch_dev(mi_ctx* ctx, const void* d_src, size_t s
  * Other statistics (mi_ctx_get_stat): "error_drains" (error returns that had to wait for a stream first),
  * "host_copies_shared" (staging copies of the host forms the context's helper thread took half of), "host_planes_staged" /
  * "host_planes_direct" (host planes -- inputs and outputs of the host forms and of pipe frames -- packed through the library's
- * pinned staging / DMA'd as the caller pinned them: the library never gives the runtime memory it did not find pinned). */
+ * pinned staging / DMA'd as the caller pinned them: the library never gives the runtime memory it did not find pinned),
+ * "clahe16_mid_launches" (mi_clahe_u16* calls that launched the 16384-entry interpolation kernel for 14-bit content; see
+ * MI_OPT_CLAHE16_WIDE in mi_lumaeq_tuning.h). */
 mi_status mi_ctx_synchronize(mi_ctx* ctx, void* stream);
 mi_status mi_ctx_set_option(mi_ctx* ctx, const char* name, int value);
 mi_status mi_ctx_get_stat(mi_ctx* ctx, const char* name, uint64_t* out);

@@ -335,7 +335,8 @@ mi_status mi_ctx_synchronize(mi_ctx* c, void* stream)
 // flag / histogram total, 2 = LUT checksum) -- these read device words with a blocking copy on the context's stream: call after the
 // stream the work ran on has been synchronised.  Host-side counters: "fused_demotions" (times the context gave the fused path up
 // for a while after repeated repairs), "fused_demoted" (1 while it is given up), "error_drains" (error exits that had to wait for
-// a stream before returning), "host_copies_shared" (staging copies the helper thread took half of).
+// a stream before returning), "host_copies_shared" (staging copies the helper thread took half of), "clahe16_mid_launches" (16-bit
+// CLAHE calls that launched clahe_interp16_mid_kernel: by the pinned-memory hint, or always / never by option "clahe16_wide").
 mi_status mi_ctx_get_stat(mi_ctx* c, const char* name, uint64_t* out)
 {
     ENTER(c);
@@ -346,6 +347,7 @@ mi_status mi_ctx_get_stat(mi_ctx* c, const char* name, uint64_t* out)
     if (!strcmp(name, "host_planes_staged")) { *out = c->planes_staged; return MI_OK; }
     if (!strcmp(name, "host_planes_direct")) { *out = c->planes_direct; return MI_OK; }
     if (!strcmp(name, "host_copies_shared")) { *out = c->crew ? c->crew->shared_jobs() : 0; return MI_OK; }
+    if (!strcmp(name, "clahe16_mid_launches")) { *out = c->c16_mid_launches; return MI_OK; }
     static const char* names[4] = {"fused_fallbacks", "fused_frames_repaired", "fused_hard_errors", "fused_last_status"};
     for (int k = 0; k < 4; ++k)
         if (!strcmp(name, names[k])) {

@@ -102,6 +102,7 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                        dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges, hint,
                        mid_runs ? 1 : 0, wh);
             if (mid_runs) {
+                ++c->c16_mid_launches;
                 // the same work items, walked by one persistent workgroup per CU (a multiple of 8 workgroups: each stays on its XCD)
                 const long long grid_p = std::min<long long>(grid, (long long)(std::max(c->cu_count, 8) + 7) / 8 * 8);
                 if (g.contract)

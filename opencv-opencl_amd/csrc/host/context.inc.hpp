@@ -135,6 +135,7 @@ struct mi_ctx {
     int clahe16_transposed = 0;                                  // option "clahe16_transposed": value-major LUTs for 16-bit interpolation (tiles <= 64)
     int clahe16_wide = 1;                                        // option "clahe16_wide": the 16384-entry interpolation kernel for 14-bit rectangles (round 6): 0 never, 1 when such a rectangle was seen lately, 2 always
     uint32_t c16_seq = 1000;                                     // sequence number of 16-bit CLAHE launches (WideHint: the pinned words start at 0 = "long ago")
+    uint64_t c16_mid_launches = 0;                               // statistic "clahe16_mid_launches"
     int clahe_hist_threads = 512;                                // option "clahe_hist_threads": 256 or 512 threads per tile-histogram workgroup
     int clahe_tiles_per_wg = 0;                                  // option "clahe_tiles_per_wg": tiles a tile-histogram workgroup walks in batches (0 = by tile size, 1, 2, 4, 8)
     int clahe_seg_pairs = 9;                                     // option "clahe_seg_pairs": pairs per float table when a wide grid is cut into column segments (4..15)

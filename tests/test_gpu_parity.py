@@ -1248,6 +1248,60 @@ def test_clahe16_frame_done_flags_over_many_frames(ctx):
         assert np.array_equal(host(d_in).view(np.uint16), want[:n]), (n, "in place")
 
 
+def test_clahe16_mid_kernel_follows_the_content_it_sees():
+    """The hint that launches clahe_interp16_mid_kernel (pinned host words stamped by the kernels, counted in EXECUTED calls): a fresh
+    context on 12-bit content never launches it; on 14-bit content the first call runs without it and, once that call has executed,
+    the following ones launch it -- also when twenty of them are enqueued without waiting; back on 12-bit content it is launched for at
+    most eight more executed calls (plus what was enqueued meanwhile) and then not again; option 0 / 2 = never / always; in place
+    never.  Results are compared with the oracle at every change of regime (the hint must never show in the bytes)."""
+    w, h, n = 640, 368, 2
+    rng = np.random.default_rng(1416)
+    f12 = rng.integers(0, 4096, (n, h, w), dtype=np.uint16)
+    f14 = rng.integers(0, 16384, (n, h, w), dtype=np.uint16)
+    want12 = np.stack([oracle.clahe16(f, 2.0, 8, 8) for f in f12])
+    want14 = np.stack([oracle.clahe16(f, 2.0, 8, 8) for f in f14])
+    with mi_lumaeq.Context(0) as c:
+        d12, d14 = dev(f12.view(np.int16)), dev(f14.view(np.int16))
+        out = torch.zeros_like(d12)
+        def run(d, sync=True):
+            c.clahe16_batch_dev(d, out, w, h, n, 2.0, 8, 8)
+            if sync:
+                c.synchronize()
+        def launched(): return c.get_stat("clahe16_mid_launches")
+        for _ in range(5):
+            run(d12)
+        assert launched() == 0                                           # narrow content: never
+        assert np.array_equal(host(out).view(np.uint16), want12)
+        run(d14)
+        assert launched() == 0                                           # the first 14-bit call: nothing was known yet
+        assert np.array_equal(host(out).view(np.uint16), want14)
+        run(d14)
+        assert launched() == 1                                           # ... now it is
+        assert np.array_equal(host(out).view(np.uint16), want14)
+        for _ in range(20):
+            run(d14, sync=False)                                         # a caller that enqueues far ahead of the device
+        c.synchronize()
+        assert launched() == 21 and np.array_equal(host(out).view(np.uint16), want14)
+        for _ in range(12):
+            run(d12)                                                     # narrow again: eight more executed calls, then no more
+        k = launched()
+        assert 21 + 8 <= k <= 21 + 9, k
+        assert np.array_equal(host(out).view(np.uint16), want12)
+        for _ in range(5):
+            run(d12)
+        assert launched() == k
+        c.set_option("clahe16_wide", 2)
+        run(d12)
+        assert launched() == k + 1                                       # always
+        c.clahe16_batch_dev(d14, d14, w, h, n, 2.0, 8, 8)               # in place: never, whatever the option
+        c.synchronize()
+        assert launched() == k + 1 and np.array_equal(host(d14).view(np.uint16), want14)
+        c.set_option("clahe16_wide", 0)
+        d14 = dev(f14.view(np.int16))
+        run(d14); run(d14)
+        assert launched() == k + 1 and np.array_equal(host(out).view(np.uint16), want14)      # never
+
+
 def test_clahe16_suite_again_with_the_mid_kernel_always_launched(ctx):
     """With the option at its default clahe_interp16_mid_kernel is launched only after a 14-bit rectangle was seen (a hint in pinned
     memory), so which kernels the tests above ran depends on their order.  Here every one of them runs again with the kernel ALWAYS
