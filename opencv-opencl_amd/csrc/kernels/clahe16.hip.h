@@ -904,12 +904,12 @@ __device__ __forceinline__ void interp16_item(long long id, const uint8_t* __res
     if (x_lo >= x_hi || y_lo >= y_hi) return;                       // uniform over the workgroup
     const int g_lo = x_lo >> 3, ngroups = ((x_hi + 7) >> 3) - g_lo;
     const int phases = max(1, THREADS / ngroups);
-    const int passes = (ngroups + THREADS - 1) / THREADS;          // > 1 only for tiles wider than 4096 pixels
+    const int passes = (ngroups + THREADS - 1) / THREADS;          // > 1 only for tiles wider than 8 * THREADS pixels
     const uint8_t* src = src_base + (long long)f * src_frame;
     uint8_t* dst = dst_base + (long long)f * dst_frame;
 
     // Which windows does this workgroup's rectangle populate at all?  (One extra read of its pixels: real images are locally much
-    // narrower than their frame.)  Bit w of s_windows: some owned pixel has (value - start) / ENTRIES == w; at most 8 windows.
+    // narrower than their frame.)  Bit w of s_windows: some owned pixel has (value - start) / ENTRIES == w; at most 8 (mid kernel: 4) windows.
     __shared__ uint32_t s_windows;
     if (multi) {
         if (t == 0) s_windows = 0;
