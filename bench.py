@@ -276,12 +276,62 @@ def cpu_baseline(args, w, h):
         pass
     # `cores` is the number of OpenMP THREADS the figure was measured with -- the best of the sweep above -- not a count of physical
     # cores: the box's affinity mask is far wider than the CPU share it grants, and the sample string says all three numbers
-    return {"value": round(multi, 2), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": cpu_model,
+    port = {"value": round(multi, 2), "unit": "frames/s", "cores": threads, "kind": "port", "cpu": cpu_model,
             "sample": f"{done} x {w}x{h} NV12 frames ({args.dist}, {args.op}, uv={args.uv}) in {el:.1f} s, "
                       f"OpenMP row/tile-striped CPU restatement of OpenCV 4.4 (oracle/lumaeq_oracle.c); "
                       f"{threads} OpenMP threads = best of a sweep over {swept} threads, affinity mask {avail} CPUs, "
                       f"host has {os.cpu_count()} logical CPUs",
             "threads_swept": swept, "affinity_cpus": avail,
+            "value_1thread": round(single, 2), "value_1080p": round(fps1080, 2)}
+    # Where a real OpenCV is importable the baseline is the REFERENCE itself -- cv::equalizeHist / CLAHE::apply on the Y plane and the
+    # NV12 rebuild around it, as OpenCVequalHist.cpp:140-162 / clahevideo.cpp:178-201 do it (1frameMeasure.cpp:43-47 times the same
+    # call) -- kind "reference"; the port's figures stay beside it.  Never on this pool (no cv2): kind "port".
+    ref = reference_cpu_baseline(frames, f1080, w, h, uv_mode, op, min(6.0, max(1.0, args.cpu_seconds / 2)))
+    if ref is None:
+        return port
+    ref.update({"cpu": cpu_model, "port": {k: port[k] for k in ("value", "cores", "value_1thread", "value_1080p", "sample")}})
+    return ref
+
+
+def reference_cpu_baseline(frames, f1080, w, h, uv_mode, op, seconds):
+    """cv2 (the real OpenCV) on the same NV12 frames: frames/s with OpenCV's own thread count and with one thread; None without cv2."""
+    try:
+        import cv2
+    except Exception:
+        return None
+    import numpy as np
+    clahe = cv2.createCLAHE(2.0, (8, 8)) if op else None
+
+    def one(frame, cw, ch, out):
+        y = frame[: cw * ch].reshape(ch, cw)
+        out[: cw * ch] = (clahe.apply(y) if op else cv2.equalizeHist(y)).reshape(-1)
+        if uv_mode:
+            out[cw * ch:] = frame[cw * ch:]
+        else:
+            out[cw * ch:] = 128
+
+    def rate(fs, cw, ch, secs):
+        out = np.empty_like(fs[0])
+        one(fs[0], cw, ch, out)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < secs:
+            one(fs[n % len(fs)], cw, ch, out)
+            n += 1
+        return n / (time.perf_counter() - t0), n
+    try:
+        default_threads = cv2.getNumThreads()
+        multi, n = rate(frames, w, h, seconds)
+        fps1080, _ = rate(f1080, 1920, 1080, 1.0)
+        cv2.setNumThreads(1)
+        single, _ = rate(frames, w, h, min(3.0, seconds / 2))
+        cv2.setNumThreads(default_threads)
+    except Exception as e:               # a broken cv2 build must not take the bench line down: the port stands
+        print(f"[bench] reference_cpu_baseline failed: {e!r}", file=sys.stderr, flush=True)
+        return None
+    return {"value": round(multi, 2), "unit": "frames/s", "cores": int(default_threads), "kind": "reference",
+            "sample": f"{n} x {w}x{h} NV12 frames in {seconds:.1f} s through cv2 {cv2.__version__} "
+                      f"({'createCLAHE(2.0, (8, 8)).apply' if op else 'equalizeHist'} on the Y plane + UV {'copy' if uv_mode else '= 128'}), "
+                      f"OpenCV's own thread count ({default_threads})",
             "value_1thread": round(single, 2), "value_1080p": round(fps1080, 2)}
 
 

@@ -30,6 +30,34 @@ def test_cpu_baseline_fields():
     assert "640x360" in cb["sample"]
 
 
+def test_cpu_baseline_turns_to_kind_reference_where_cv2_exists(monkeypatch):
+    """Where a real OpenCV is importable the CPU baseline is the reference itself (cv2.equalizeHist / CLAHE on the Y plane + the NV12
+    rebuild, OpenCVequalHist.cpp:140-162), kind "reference", with the port's figures beside it.  No cv2 on this pool: the plumbing
+    runs here against a STAND-IN module named cv2 whose two functions are the oracle's -- it times nothing real and pins nothing."""
+    import types
+    import numpy as np
+    import bench
+    import oracle
+    fake = types.ModuleType("cv2")
+    fake.__version__ = "stand-in (oracle)"
+    threads = {"n": 7}
+    fake.getNumThreads = lambda: threads["n"]
+    fake.setNumThreads = lambda n: threads.__setitem__("n", n)
+    fake.equalizeHist = lambda a: oracle.equalize_hist(np.ascontiguousarray(a))
+
+    class _Clahe:
+        def apply(self, a): return oracle.clahe(np.ascontiguousarray(a), 2.0, 8, 8)
+    fake.createCLAHE = lambda clip, tiles: _Clahe()
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    for op in ("equalize", "clahe"):
+        args = argparse.Namespace(dist="D2", uv="copy", op=op, cpu_seconds=1.0)
+        cb = bench.cpu_baseline(args, 640, 360)
+        assert cb["kind"] == "reference" and cb["unit"] == "frames/s" and cb["value"] > 0 and cb["cores"] == 7
+        assert "cv2 stand-in (oracle)" in cb["sample"] and "640x360" in cb["sample"]
+        assert cb["value_1thread"] > 0 and cb["value_1080p"] > 0 and threads["n"] == 7          # thread count restored
+        assert cb["port"]["value"] > 0 and cb["port"]["cores"] >= 1 and "restatement" in cb["port"]["sample"]
+
+
 _STUB = r'''
 import json, os, sys, time
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
