@@ -29,7 +29,7 @@ namespace mi {
 //                 (clahe_interp16_wide_kernel): re-reading pixels that earlier windows have overwritten is not an option.
 //   clahe_interp16_mid  (round 6) the SAME body with a 16384-entry table and 1024 threads, persistent, for the rectangles whose range
 //                 needs 8193..16384 entries (every rectangle of a 14-bit frame: one window, the vector path) and for dense wider ones
-//                 (half as many window passes); launched only while such content was seen lately (WideHint), out of place only.
+//                 (half as many window passes); launched only while such content was seen lately (WideHint).
 // =============================================================================================
 constexpr int kHist16 = 65536;
 constexpr int kHalf16 = 32768;
@@ -861,7 +861,15 @@ __device__ __forceinline__ void interp16_item(long long id, const uint8_t* __res
     // A range wider than the table is walked in WINDOWS of ENTRIES values: the table is staged once per window and a pixel is
     // finished in the window its value falls into (2-byte stores).  That re-reads the workgroup's pixels once per window, so it
     // cannot be done in place: in-place calls on a FRAME with a wide range are left to clahe_interp16_wide_kernel, whole.
-    if (!MID && fr.hi - (fr.lo & ~3u) >= (uint32_t)ENTRIES && src_base == dst_base) return;      // (the mid kernel is never launched in place)
+    // (With the mid kernel in the call, a frame of up to 16384 values stays here in place as well: each of its rectangles is ONE window
+    // of one of the two tables, and a single window reads every pixel before it writes it.)
+    if (src_base == dst_base) {
+        const uint32_t fspan = fr.hi - (fr.lo & ~3u);
+        if (fspan >= (uint32_t)(mid_runs ? kInterp16MidEntries : kInterp16Entries)) {
+            if (!MID && t == 0 && fspan < (uint32_t)kInterp16MidEntries) wide_seen(wide_hint);       // the mid kernel would have kept this frame here
+            return;
+        }
+    }
     // The table only has to cover the values this workgroup's pixels can have: they lie in (at most) the four tiles whose LUTs it blends,
     // so the union of THOSE tiles' ranges replaces the frame's (a hot pixel, a bright corner widen the table of their own rectangles
     // only; tile_lut16_kernel writes every LUT over its tile's 3 x 3 neighbourhood, which contains these four).
@@ -1136,7 +1144,8 @@ __global__ __launch_bounds__(kInterp16Threads) void clahe_interp16_kernel(const 
 // PERSISTENT: grid = min(work items, CUs rounded to a multiple of 8) workgroups of 1024 threads with 128 KiB of dynamic LDS (one per CU
 // is all that fits; launched one per item, the thousands that only return cost 23 us).  The work items are clahe_interp16_kernel's,
 // item for item (same `subs`, same XCD dealing: item & 7 -- the grid is a multiple of 8, so a workgroup stays on its XCD).  Frames whose
-// whole range fits the small table are known from a bit mask built once per workgroup.  Out of place only (the host sees to it).
+// whole range fits the small table are known from a bit mask built once per workgroup.  In place it keeps to frames of at most 16384
+// values (one window per rectangle); wider ones are the gathering kernel's, whole.
 template <bool FMA>
 __global__ __launch_bounds__(kInterp16MidThreads) void clahe_interp16_mid_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                                 uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
@@ -1182,12 +1191,13 @@ __global__ __launch_bounds__(kInterp16MidThreads) void clahe_interp16_mid_kernel
 __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                       uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                       ClaheGeom g, const uint16_t* __restrict__ luts,
-                                                                      const Range16* __restrict__ frame_ranges)
+                                                                      const Range16* __restrict__ frame_ranges, int mid_runs)
 {
     const int f = blockIdx.z;
     const Range16 fr = frame_ranges[f];
     const uint32_t sft = range_shift(fr.hi);                        // the LUTs are stored at index value >> sft
-    if ((range_hi(fr.hi) >> sft) - ((fr.lo >> sft) & ~3u) < (uint32_t)kInterp16Entries || src_base != dst_base) return;   // done from LDS tables (one window, or several when not in place)
+    // done from LDS tables: one window (of the small table, or -- with the mid kernel in the call -- of either), or several when not in place
+    if ((range_hi(fr.hi) >> sft) - ((fr.lo >> sft) & ~3u) < (uint32_t)(mid_runs ? kInterp16MidEntries : kInterp16Entries) || src_base != dst_base) return;
     const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
     const int bx = (g.width + kThreads - 1) / kThreads;
     const long long items = (long long)bx * g.height;

@@ -1154,7 +1154,7 @@ def test_clahe16_wide_content_full_size(ctx):
     wider ones keep the 64-KiB table's windows.  Full-range noise, 14-bit, 15-bit, a smooth full-range ramp (rectangles of every
     width), a 12-bit frame with one hot pixel, full-range noise with 70 000 pixels of ONE value in tile (3, 2), a half 12-bit / half
     full-range frame, and 14-bit samples in the high bits of the word (16384 entries in the compressed domain).  Out of place and IN
-    PLACE (where the mid kernel is never launched), every option value, the hint turning on over consecutive calls: every frame
+    PLACE (where frames wider than 16384 values keep the gathering kernel), every option value, the hint turning on over consecutive calls: every frame
     bit-exact against the oracle."""
     w, h = 3840, 2160
     rng = np.random.default_rng(606)
@@ -1253,7 +1253,7 @@ def test_clahe16_mid_kernel_follows_the_content_it_sees():
     context on 12-bit content never launches it; on 14-bit content the first call runs without it and, once that call has executed,
     the following ones launch it -- also when twenty of them are enqueued without waiting; back on 12-bit content it is launched for at
     most eight more executed calls (plus what was enqueued meanwhile) and then not again; option 0 / 2 = never / always; in place
-    never.  Results are compared with the oracle at every change of regime (the hint must never show in the bytes)."""
+    as well (a frame of up to 16384 values is one window per rectangle).  Results are compared with the oracle at every change of regime (the hint must never show in the bytes)."""
     w, h, n = 640, 368, 2
     rng = np.random.default_rng(1416)
     f12 = rng.integers(0, 4096, (n, h, w), dtype=np.uint16)
@@ -1293,13 +1293,13 @@ def test_clahe16_mid_kernel_follows_the_content_it_sees():
         c.set_option("clahe16_wide", 2)
         run(d12)
         assert launched() == k + 1                                       # always
-        c.clahe16_batch_dev(d14, d14, w, h, n, 2.0, 8, 8)               # in place: never, whatever the option
+        c.clahe16_batch_dev(d14, d14, w, h, n, 2.0, 8, 8)               # in place too: a 14-bit frame is one window per rectangle
         c.synchronize()
-        assert launched() == k + 1 and np.array_equal(host(d14).view(np.uint16), want14)
+        assert launched() == k + 2 and np.array_equal(host(d14).view(np.uint16), want14)
         c.set_option("clahe16_wide", 0)
         d14 = dev(f14.view(np.int16))
         run(d14); run(d14)
-        assert launched() == k + 1 and np.array_equal(host(out).view(np.uint16), want14)      # never
+        assert launched() == k + 2 and np.array_equal(host(out).view(np.uint16), want14)      # never
 
 
 def test_clahe16_suite_again_with_the_mid_kernel_always_launched(ctx):
