@@ -48,8 +48,8 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
         // Rectangles whose range needs 8193..16384 table entries (14-bit content) have a kernel of their own since round 6
         // (clahe_interp16_mid_kernel: one window of a 128-KiB table).  Its launch costs ~8 us whether or not it finds work, so with the
         // option at its default (1) it is launched only while such a rectangle was seen in one of the context's last executed calls
-        // (kernels/clahe16.hip.h WideHint); 2 = always (tests), 0 = never.  In place, frames of up to 16384 values are done by the two
-        // table kernels together (9 k -> 44 k frames/s for 14-bit content); wider ones keep the gathering kernel, whole.
+        // (kernels/clahe16.hip.h WideHint); 2 = always (tests), 0 = never.  In place a frame is shared out by RECTANGLES: one window of the
+        // small table, one window of the mid kernel's, or -- several windows -- the kernel that gathers from the LUTs in L2.
         const uint32_t seq = ++c->c16_seq;
         const WideHint wh{c->d_sync16 + c->sync16_bytes / sizeof(uint32_t) - 2, c->h_mirror + kWideHintWord, seq};
         const bool mid_recent = mi_host::mid_kernel_wanted(c->clahe16_wide, __atomic_load_n(c->h_mirror + kWideHintWord + 1, __ATOMIC_RELAXED),
@@ -113,12 +113,12 @@ mi_status clahe16_dev(mi_ctx* c, hipStream_t s, const uint8_t* src, size_t src_s
                            (size_t)kInterp16MidEntries * sizeof(uint2), sp, (long long)src_step, (long long)src_frame,
                            dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, subs, nf, (const Range16*)ranges);
             }
-            // IN-PLACE frames whose range does not fit the LDS table (their workgroups above returned at once); the launch is a no-op for
-            // every other frame, and is left out altogether when the call is not in place (it cost 8 us per call)
+            // IN-PLACE rectangles whose range does not fit one window of a table (their workgroups above returned at once); the launch is a
+            // no-op for frames without any, and is left out altogether when the call is not in place (it cost 8 us per call)
             if (sp == dp) {
                 const long long wide_items = (long long)((width + kThreads - 1) / kThreads) * height;
                 LAUNCH(c, s, MI_K_CLAHE_INTERP, clahe_interp16_wide_kernel, dim3((unsigned)std::min<long long>(wide_items, std::max(512, 2048 / nf)), 1, nf), dim3(kThreads), 0,
-                       sp, (long long)src_step, (long long)src_frame, dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, mid_runs ? 1 : 0);
+                       sp, (long long)src_step, (long long)src_frame, dp, (long long)dst_step, (long long)dst_frame, g, (const uint16_t*)luts, (const Range16*)franges, mid_runs ? 1 : 0, (const Range16*)ranges);
             }
         }
     }

@@ -25,8 +25,8 @@ namespace mi {
 //                 kInterp16Entries 8-byte entries fit at a time (every 13-bit source in one go); a wider range
 //                 is walked in windows of that size, each pixel finished in the window its value falls into (the workgroup's
 //                 pixels are re-read once per window, from L2; windows none of them falls into are skipped -- a locally smooth
-//                 image needs one or two of the eight).  Only in-place calls on wide-range frames still gather from L2
-//                 (clahe_interp16_wide_kernel): re-reading pixels that earlier windows have overwritten is not an option.
+//                 image needs one or two of the eight).  Only the in-place RECTANGLES that need several windows still gather from
+//                 L2 (clahe_interp16_wide_kernel): re-reading pixels that earlier windows have overwritten is not an option.
 //   clahe_interp16_mid  (round 6) the SAME body with a 16384-entry table and 1024 threads, persistent, for the rectangles whose range
 //                 needs 8193..16384 entries (every rectangle of a 14-bit frame: one window, the vector path) and for dense wider ones
 //                 (half as many window passes); launched only while such content was seen lately (WideHint).
@@ -71,6 +71,16 @@ __device__ __forceinline__ bool rect_is_mid(uint32_t span, uint32_t presence)
     if (span < (uint32_t)kInterp16MidEntries) return true;
     const uint32_t m = presence >> (presence ? __builtin_ctz(presence) : 0);     // lowest populated stretch at bit 0
     return m != 0u && (m & (m + 1u)) == 0u;                                        // ... and ones without a hole above it
+}
+
+// IN PLACE (src == dst) a rectangle that needs several windows cannot be done from a table (a window's pass would re-read pixels an earlier
+// one has overwritten): 0 = the small table's (clahe_interp16_kernel), 1 = ONE window of the mid kernel's table, if it runs,
+// 2 = clahe_interp16_wide_kernel gathers its pixels from the LUTs in L2.  All three kernels ask this with the same numbers, so a
+// frame is shared out by rectangles: a 12-bit frame with a hot pixel leaves four of its 81 rectangles to the gathers, not all.
+__device__ __forceinline__ int rect_owner_in_place(uint32_t span, int mid_runs)
+{
+    if (span < (uint32_t)kInterp16Entries) return 0;
+    return (mid_runs && span < (uint32_t)kInterp16MidEntries) ? 1 : 2;
 }
 
 struct Range16 { uint32_t lo, hi; };                 // populated value range of a tile / frame (lo > hi: empty -- cannot happen, a tile has pixels)
@@ -860,16 +870,7 @@ __device__ __forceinline__ void interp16_item(long long id, const uint8_t* __res
     Range16 fr; fr.lo = fr_raw.lo >> sft; fr.hi = range_hi(fr_raw.hi) >> sft;
     // A range wider than the table is walked in WINDOWS of ENTRIES values: the table is staged once per window and a pixel is
     // finished in the window its value falls into (2-byte stores).  That re-reads the workgroup's pixels once per window, so it
-    // cannot be done in place: in-place calls on a FRAME with a wide range are left to clahe_interp16_wide_kernel, whole.
-    // (With the mid kernel in the call, a frame of up to 16384 values stays here in place as well: each of its rectangles is ONE window
-    // of one of the two tables, and a single window reads every pixel before it writes it.)
-    if (src_base == dst_base) {
-        const uint32_t fspan = fr.hi - (fr.lo & ~3u);
-        if (fspan >= (uint32_t)(mid_runs ? kInterp16MidEntries : kInterp16Entries)) {
-            if (!MID && t == 0 && fspan < (uint32_t)kInterp16MidEntries) wide_seen(wide_hint);       // the mid kernel would have kept this frame here
-            return;
-        }
-    }
+    // cannot be done in place: in-place RECTANGLES that need several windows are left to clahe_interp16_wide_kernel (below).
     // The table only has to cover the values this workgroup's pixels can have: they lie in (at most) the four tiles whose LUTs it blends,
     // so the union of THOSE tiles' ranges replaces the frame's (a hot pixel, a bright corner widen the table of their own rectangles
     // only; tile_lut16_kernel writes every LUT over its tile's 3 x 3 neighbourhood, which contains these four).
@@ -882,6 +883,11 @@ __device__ __forceinline__ void interp16_item(long long id, const uint8_t* __res
         presence = range_mask(r00.lo) | range_mask(r01.lo) | range_mask(r10.lo) | range_mask(r11.lo);
     }
     const uint32_t start = fr.lo & ~3u;
+    if (src_base == dst_base) {                                     // in place: by rectangles (rect_owner_in_place), uniform
+        const int owner = rect_owner_in_place(fr.hi - start, mid_runs);
+        if (!MID && owner != 0) { if (t == 0 && fr.hi - start < (uint32_t)kInterp16MidEntries) wide_seen(wide_hint); return; }
+        if (MID && owner != 1) return;
+    }
     if (MID) {
         if (!rect_is_mid(fr.hi - start, presence)) return;                    // uniform: the small table's rectangle
     } else {
@@ -1182,8 +1188,8 @@ __global__ __launch_bounds__(kInterp16MidThreads) void clahe_interp16_mid_kernel
     }
 }
 
-// IN-PLACE calls on frames whose populated range does not fit the LDS table (full-range 16-bit sources, MSB-aligned video; out of place
-// such frames go through the table in several windows): one pixel per lane, four ushort gathers from the per-tile LUTs in L2 -- bound by the divergent gathers themselves (up to 64 cache lines per wave
+// IN-PLACE calls, the RECTANGLES whose populated range does not fit one window of a table (rect_owner_in_place; full-range 16-bit
+// sources, the neighbourhood of a hot pixel; out of place such rectangles go through the table in several windows): one pixel per lane, four ushort gathers from the per-tile LUTs in L2 -- bound by the divergent gathers themselves (up to 64 cache lines per wave
 // instruction).  Launched after clahe_interp16_kernel on every call; a workgroup whose frame was handled there returns at once, so
 // the grid is kept small: grid = (min(items, max(512, 2048 / frames)), 1, frames) workgroups walking (row, 256-pixel block) items in row-major order
 // with stride gridDim.x -- the rows in flight at any moment are neighbours, so the LUTs they gather from (two tile rows) stay in L2
@@ -1191,13 +1197,37 @@ __global__ __launch_bounds__(kInterp16MidThreads) void clahe_interp16_mid_kernel
 __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uint8_t* __restrict__ src_base, long long src_step, long long src_frame,
                                                                       uint8_t* __restrict__ dst_base, long long dst_step, long long dst_frame,
                                                                       ClaheGeom g, const uint16_t* __restrict__ luts,
-                                                                      const Range16* __restrict__ frame_ranges, int mid_runs)
+                                                                      const Range16* __restrict__ frame_ranges, int mid_runs,
+                                                                      const Range16* __restrict__ tile_ranges)
 {
     const int f = blockIdx.z;
     const Range16 fr = frame_ranges[f];
     const uint32_t sft = range_shift(fr.hi);                        // the LUTs are stored at index value >> sft
-    // done from LDS tables: one window (of the small table, or -- with the mid kernel in the call -- of either), or several when not in place
+    // a frame whose whole range is one window of a table that runs has no rectangle for this kernel; nor has a call that is not in place
     if ((range_hi(fr.hi) >> sft) - ((fr.lo >> sft) & ~3u) < (uint32_t)(mid_runs ? kInterp16MidEntries : kInterp16Entries) || src_base != dst_base) return;
+    const Range16* tr = tile_ranges + (size_t)f * g.tiles_x * g.tiles_y;
+    // Which rectangles -- (tile pair, band) -- are this kernel's?  (rect_owner_in_place on the range of the rectangle's four tiles, as the
+    // table kernels compute it.)  Worked out once per workgroup into LDS, one byte per rectangle, so that a pixel costs one LDS read and
+    // a 256-pixel block whose ends are both somebody else's (and which is no wider than a tile: at most two rectangles) nothing more.
+    constexpr int kMaxRects = 4096;
+    __shared__ uint8_t s_mine[kMaxRects];
+    const int npairs = g.tiles_x + 1, nbands = g.tiles_y + 1;
+    const bool tabled = npairs * nbands <= kMaxRects;               // (more rectangles than that: every pixel asks the tiles' ranges itself)
+    auto rect_mine = [&](int pr, int band) {
+        const int tx1 = max(pr - 1, 0), tx2 = min(pr, g.tiles_x - 1), ty1 = max(band - 1, 0), ty2 = min(band, g.tiles_y - 1);
+        const Range16 r00 = tr[ty1 * g.tiles_x + tx1], r01 = tr[ty1 * g.tiles_x + tx2], r10 = tr[ty2 * g.tiles_x + tx1], r11 = tr[ty2 * g.tiles_x + tx2];
+        const uint32_t rlo = min(min(range_lo(r00.lo), range_lo(r01.lo)), min(range_lo(r10.lo), range_lo(r11.lo))) >> sft;
+        const uint32_t rhi = max(max(range_hi(r00.hi), range_hi(r01.hi)), max(range_hi(r10.hi), range_hi(r11.hi))) >> sft;
+        return rect_owner_in_place(rhi - (rlo & ~3u), mid_runs) == 2;
+    };
+    if (tabled) {
+        for (int i = threadIdx.x; i < npairs * nbands; i += kThreads) s_mine[i] = rect_mine(i % npairs, i / npairs) ? 1 : 0;
+        __syncthreads();
+    }
+    auto pair_of = [&](int x) { const int q = floor_f32_to_int(tile_coord(x, g.inv_tw, g.contract)) + 1; return q < 0 ? 0 : (q > g.tiles_x ? g.tiles_x : q); };
+    auto band_of = [&](int y) { const int q = floor_f32_to_int(tile_coord(y, g.inv_th, g.contract)) + 1; return q < 0 ? 0 : (q > g.tiles_y ? g.tiles_y : q); };
+    auto mine = [&](int pr, int band) { return tabled ? s_mine[band * npairs + pr] != 0 : rect_mine(pr, band); };
+    const bool by_block = tabled && g.tile_w >= kThreads;
     const uint16_t* lf = luts + (size_t)f * g.tiles_x * g.tiles_y * kHist16;
     const int bx = (g.width + kThreads - 1) / kThreads;
     const long long items = (long long)bx * g.height;
@@ -1214,6 +1244,10 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uin
             ys[k] = (int)(it / bx);
             xs[k] = (int)(it - (long long)ys[k] * bx) * kThreads + threadIdx.x;
             on[k] = it < items && xs[k] < g.width;
+            if (by_block && it < items) {                            // uniform over the workgroup
+                const int xb = (int)(it - (long long)ys[k] * bx) * kThreads, band = band_of(ys[k]);
+                if (!mine(pair_of(xb), band) && !mine(pair_of(min(xb + kThreads - 1, g.width - 1)), band)) on[k] = false;
+            }
             v[k] = on[k] ? (uint32_t)*reinterpret_cast<const uint16_t*>(src + (long long)ys[k] * src_step + 2 * (long long)xs[k]) >> sft : 0u;
         }
         float a[kChains], b[kChains], c[kChains], d[kChains], xa[kChains], ya[kChains];
@@ -1227,6 +1261,7 @@ __global__ __launch_bounds__(kThreads) void clahe_interp16_wide_kernel(const uin
             int ty1 = floor_f32_to_int(tyf);
             ya[k] = __fsub_rn(tyf, (float)ty1);
             int ty2 = ty1 + 1; ty1 = max(ty1, 0); ty2 = min(ty2, g.tiles_y - 1);
+            if (on[k]) on[k] = mine(min(max(floor_f32_to_int(txf) + 1, 0), g.tiles_x), min(max(floor_f32_to_int(tyf) + 1, 0), g.tiles_y));
             if (on[k]) {
                 a[k] = (float)lf[((size_t)ty1 * g.tiles_x + tx1) * kHist16 + v[k]]; b[k] = (float)lf[((size_t)ty1 * g.tiles_x + tx2) * kHist16 + v[k]];
                 c[k] = (float)lf[((size_t)ty2 * g.tiles_x + tx1) * kHist16 + v[k]]; d[k] = (float)lf[((size_t)ty2 * g.tiles_x + tx2) * kHist16 + v[k]];

@@ -16,11 +16,12 @@ cases = (("12-bit", lambda: u16(0, 4096)), ("10-bit << 6 (P010)", lambda: (torch
          ("13-bit", lambda: u16(0, 8192)), ("14-bit", lambda: u16(0, 16384)),
          ("14-bit << 2", lambda: (torch.randint(0, 16384, (n, h, w), dtype=torch.int32, device="cuda") << 2).to(torch.int16)),
          ("12-bit + one hot pixel", hot), ("15-bit", lambda: u16(0, 32768)), ("full range", lambda: u16(0, 65536)), ("full range, smooth ramp", ramp))
-cases = cases + (("14-bit, IN PLACE (+ a copy)", "inplace14"), ("full range, IN PLACE (+ a copy)", "inplace16"))
+cases = cases + (("12-bit, IN PLACE (+ a copy)", "inplace12"), ("14-bit, IN PLACE (+ a copy)", "inplace14"), ("12-bit + hot pixel, IN PLACE (+ a copy)", "inplacehot"),
+                 ("full range, IN PLACE (+ a copy)", "inplace16"))
 for name, make in cases:
     inplace = isinstance(make, str)
     if inplace:                                                  # the call overwrites its input with a full-range result, so the input is copied back
-        make = (lambda: u16(0, 16384)) if make == "inplace14" else (lambda: u16(0, 65536))       # before every call: both columns include that copy
+        make = {"inplace12": lambda: u16(0, 4096), "inplace14": lambda: u16(0, 16384), "inplacehot": hot, "inplace16": lambda: u16(0, 65536)}[make]     # before every call: both columns include that copy
     s16 = make(); o16 = torch.empty_like(s16)
     work = torch.empty_like(s16) if inplace else None
     def call():
@@ -39,6 +40,6 @@ for name, make in cases:
             for _ in range(10): call()
             torch.cuda.synchronize()
             best[wide] = max(best[wide], 10 * n / (time.perf_counter() - t0))
-    print(f"{name:32s} {n} per call: round-3 paths {best[0]:9.0f} frames/s ({n / best[0] * 1e6:7.1f} us per call)   clahe16_wide {best[1]:9.0f} frames/s "
+    print(f"{name:40s} {n} per call: round-3 paths {best[0]:9.0f} frames/s ({n / best[0] * 1e6:7.1f} us per call)   clahe16_wide {best[1]:9.0f} frames/s "
           f"({n / best[1] * 1e6:7.1f} us per call)   x{best[1] / best[0]:.2f}", flush=True)
     del s16, o16, work
