@@ -1200,7 +1200,8 @@ def test_clahe16_wide_content_full_size(ctx):
     # other tile grids: small tiles, a grid with more pairs than a workgroup has row phases, one tile, and one whose pair edges do not
     # fall on multiples of eight pixels (1000 / 5 = 200-pixel tiles: edges at 100 + 200 k: 8-pixel groups cut by an edge)
     ctx.set_option("clahe16_wide", 2)
-    for (cw, chh, tx, ty) in [(640, 368, 8, 8), (1280, 96, 16, 2), (512, 512, 1, 1), (1024, 64, 2, 4), (1000, 120, 5, 3)]:
+    # ... and 64 x 64 tiles: 65 x 65 rectangles, more than the in-place gathering kernel's ownership table holds (it then asks per pixel)
+    for (cw, chh, tx, ty) in [(640, 368, 8, 8), (1280, 96, 16, 2), (512, 512, 1, 1), (1024, 64, 2, 4), (1000, 120, 5, 3), (1024, 1024, 64, 64)]:
         fs = [rng.integers(0, 65536, (chh, cw), dtype=np.uint16), rng.integers(0, 16384, (chh, cw), dtype=np.uint16),
               rng.integers(20000, 45000, (chh, cw), dtype=np.uint16)]
         fs.append(fs[0].copy()); fs[-1][: chh // 2] = 4242                                 # flat half: wave-uniform vectors
